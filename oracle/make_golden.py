@@ -1,0 +1,124 @@
+"""Freeze outputs of the REAL reference into tests/golden/  -- TEST INFRASTRUCTURE ONLY.
+
+Run in the build container:  python -m oracle.make_golden
+The reference (``/root/reference/Emu2/emu``) is imported on CPU in fp32 with tiny seeded
+configs, loaded with ``emu_amd.synth`` weights (regenerable from the seed, so the fixtures hold
+only inputs and outputs), and its ``encode_image`` / ``lm.model`` / ``generate`` /
+``generate_image`` outputs are stored.  ``tests/test_oracle_golden.py`` then pins
+``oracle/emu2_ref.py`` against these files on any machine.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_import  # noqa: E402
+from emu_amd import synth  # noqa: E402
+from emu_amd.conf.emu_conf import CLIPVisionCfg, LlamaCfg  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# tiny config shared with the tests (tests/golden_cfg.py reads the same numbers from the npz)
+TINY = dict(image_size=56, patch_size=14, width=224, layers=2, head_width=112, mlp_ratio=2.0,
+            n_query=4, v_query=4,
+            hidden=256, ffn=512, heads=2, llayers=2, instruct=True, seed=7, lm_head_scale=8.0)
+
+
+def tiny_cfgs(t=TINY):
+    v = CLIPVisionCfg(image_size=t["image_size"], patch_size=t["patch_size"], width=t["width"],
+                      layers=t["layers"], head_width=t["head_width"], mlp_ratio=t["mlp_ratio"],
+                      n_query=t["n_query"], v_query=t["v_query"])
+    l = LlamaCfg(hidden_size=t["hidden"], intermediate_size=t["ffn"], num_attention_heads=t["heads"],
+                 num_hidden_layers=t["llayers"])
+    vocab = 32274 if t["instruct"] else 32272
+    return v, l, vocab
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    t = TINY
+    v, l, vocab = tiny_cfgs(t)
+    sd = synth.synth_state_dict(synth.emu_param_shapes(v, l, vocab), seed=t["seed"],
+                                lm_head_scale=t["lm_head_scale"])
+    d = ref_import.tiny_llama_dir(t["hidden"], t["ffn"], t["heads"], t["llayers"])
+    vk = dict(image_size=v.image_size, patch_size=v.patch_size, width=v.width, layers=v.layers,
+              head_width=v.head_width, mlp_ratio=v.mlp_ratio, n_query=v.n_query, v_query=v.v_query)
+    m = ref_import.build_reference(vk, d, t["instruct"], sd)
+    tok = m.decoder.tokenizer
+    meta = {"cfg_" + k: np.array(val) for k, val in t.items()}
+
+    g = torch.Generator().manual_seed(101)
+    # --- 1. ViT + encode_image (emu.py:77-90, eva_vit.py:402-445)
+    image = torch.randn(2, 3, v.image_size, v.image_size, generator=g)
+    with torch.no_grad():
+        feats = m.visual(image)
+        enc = m.encode_image(image)
+        enc1 = m.encode_image(image, n_query=1)
+    np.savez(os.path.join(OUT, "vit_tiny.npz"), image=image.numpy(), feats=feats.numpy(),
+             encode=enc.numpy(), encode_nq1=enc1.numpy(), **meta)
+
+    # --- 2. lm.model on inputs_embeds (emu.py:133-138), ragged (left-padded) batch + logits
+    S = 12
+    embeds = torch.randn(2, S, l.hidden_size, generator=g) * 0.5
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[1, :3] = 0
+    with torch.no_grad():
+        out = m.decoder.lm.model(inputs_embeds=embeds, attention_mask=mask, output_hidden_states=True,
+                                 return_dict=True)
+        hidden = out.hidden_states[-1]
+        logits = m.decoder.lm.lm_head(hidden[:, -1, :])
+    np.savez(os.path.join(OUT, "llama_tiny.npz"), embeds=embeds.numpy(), mask=mask.numpy(),
+             hidden=hidden.numpy(), logits=logits.numpy(), **meta)
+
+    # --- 3. EmuModel.generate greedy (emu.py:155-235), B=1 with image and B=2 ragged text-only
+    img1 = torch.randn(1, 3, v.image_size, v.image_size, generator=g)
+    text1 = ["[<IMG_PLH>]describe the image in detail:"]
+    text2 = ["a photo of", "an image of a very large dog that"]
+
+    def run_generate(text, image, n_new):
+        exp = [x.replace("[<IMG_PLH>]", m.image_placeholder) for x in text]
+        enc_ = tok(exp, padding="longest", return_tensors="pt")
+        # the reference returns decoded strings; capture ids by calling lm.generate the same way
+        # (emu.py:184-229) through a thin hook on batch_decode
+        captured = {}
+        orig = tok.batch_decode
+
+        def hook(ids, **kw):
+            captured["ids"] = ids.clone()
+            return orig(ids, **kw)
+        tok.batch_decode = hook
+        try:
+            with torch.no_grad():
+                strs = m.generate(text=text, image=image, num_beams=1, max_new_tokens=n_new)
+        finally:
+            tok.batch_decode = orig
+        return enc_.input_ids, enc_.attention_mask, captured["ids"], strs
+
+    ids1, am1, new1, s1 = run_generate(text1, img1, 8)
+    ids2, am2, new2, s2 = run_generate(text2, None, 6)
+    np.savez(os.path.join(OUT, "generate_tiny.npz"), image=img1.numpy(),
+             ids1=ids1.numpy(), mask1=am1.numpy(), new1=new1.numpy(),
+             ids2=ids2.numpy(), mask2=am2.numpy(), new2=new2.numpy(), **meta)
+    print("generate B=1:", new1.tolist(), s1)
+    print("generate B=2:", new2.tolist(), s2)
+
+    # --- 4. EmuModel.generate_image (emu.py:92-153), text-only and with an image prompt
+    with torch.no_grad():
+        gi_text = m.generate_image(text=["a dog on the grass"])
+        gi_img = m.generate_image(text=["[<IMG_PLH>]make it red"], image=img1)
+    p_text = tok(["a dog on the grass"], return_tensors="pt").input_ids
+    p_img = tok([f"{m.image_placeholder}make it red"], return_tensors="pt").input_ids
+    # sanity: appending special tokens to the text == appending their ids (used by the restatement)
+    chk = tok(["a dog on the grass[IMG]<image><image>"], return_tensors="pt").input_ids
+    assert chk[0, -3:].tolist() == [32001, 32003, 32003] and torch.equal(chk[:, :-3], p_text), chk
+    np.savez(os.path.join(OUT, "generate_image_tiny.npz"), image=img1.numpy(),
+             prompt_text=p_text.numpy(), out_text=gi_text.numpy(),
+             prompt_img=p_img.numpy(), out_img=gi_img.numpy(), **meta)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
