@@ -1,0 +1,109 @@
+"""ctypes binding of libemu_hip.so (the C ABI declared in include/emu_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or cannot be loaded this module raises,
+and every operator raises ``EmuHipError`` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libemu_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "emu_hip.h")
+
+
+class EmuHipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+vp, i32, f32, lng, sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
+
+
+class LlamaCfgC(C.Structure):
+    _fields_ = [("hidden", i32), ("heads_local", i32), ("head_dim", i32), ("ffn_local", i32), ("layers", i32),
+                ("vocab", i32), ("max_pos", i32), ("rms_eps", f32)]
+
+
+class VitCfgC(C.Structure):
+    _fields_ = [("image_size", i32), ("patch_size", i32), ("width", i32), ("layers", i32), ("heads", i32),
+                ("head_width", i32), ("mlp_hidden", i32), ("kpad", i32), ("ln_eps", f32)]
+
+
+_PROTOS = {
+    "emu_version": (i32, []),
+    "emu_profile_gemv": (i32, [i32]),
+    "emu_profile_gemv_read": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "emu_ctx_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+    "emu_ctx_destroy": (None, [vp]),
+    "emu_last_error": (C.c_char_p, [vp]),
+    "emu_tp_unique_id": (i32, [vp]),
+    "emu_tp_init": (i32, [vp, vp]),
+    "emu_allreduce_bf16": (i32, [vp, vp, sz, vp]),
+    "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "emu_embed_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "emu_scatter_rows_bf16": (i32, [vp, vp, vp, i32, i32, vp]),
+    "emu_argmax_bf16": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "emu_patchify": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "emu_vit_assemble_bf16": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "emu_avgpool_tokens_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "emu_rope_kv_append_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "emu_transpose_v_bf16": (i32, [vp, lng, lng, lng, vp, i32, i32, i32, i32, i32, vp]),
+    "emu_flash_attn_bf16": (i32, [vp, lng, lng, lng, vp, lng, lng, lng, vp, vp, lng, lng, lng, vp,
+                                  i32, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "emu_decode_attn_ws_bytes": (sz, [i32, i32, i32, i32]),
+    "emu_decode_attn_bf16": (i32, [vp, lng, lng, vp, vp, vp, lng, lng, vp, vp, i32, i32, vp, i32, i32, i32, i32, f32, vp]),
+    "emu_llama_create": (i32, [vp, C.POINTER(LlamaCfgC), C.POINTER(vp)]),
+    "emu_llama_destroy": (None, [vp]),
+    "emu_llama_set_layer": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
+    "emu_llama_set_head": (i32, [vp, vp, vp, vp, vp, vp]),
+    "emu_llama_set_kv": (i32, [vp, vp, vp, i32, i32]),
+    "emu_llama_workspace_bytes": (sz, [vp, i32, i32]),
+    "emu_llama_forward": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "emu_llama_final_norm": (i32, [vp, vp, vp, i32, vp]),
+    "emu_llama_logits": (i32, [vp, vp, i32, i32, vp, i32, vp, sz, vp]),
+    "emu_llama_greedy_step": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "emu_vit_create": (i32, [vp, C.POINTER(VitCfgC), C.POINTER(vp)]),
+    "emu_vit_destroy": (None, [vp]),
+    "emu_vit_set_stem": (i32, [vp, vp, vp, vp, vp]),
+    "emu_vit_set_block": (i32, [vp, i32] + [vp] * 12),
+    "emu_vit_workspace_bytes": (sz, [vp, i32]),
+    "emu_vit_forward": (i32, [vp, vp, i32, i32, vp, vp, sz, vp]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libemu_hip.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EmuHipError(f"{LIB_PATH} not found: build it with `python -m emu_amd.build` "
+                              "(there is no CPU fallback in emu_amd)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str, ctx: Optional[int] = None) -> None:
+    if status != 0:
+        detail = ""
+        if ctx:
+            msg = lib().emu_last_error(ctx)
+            detail = f": {msg.decode()}" if msg else ""
+        raise EmuHipError(f"{what} failed with status {status}{detail}")
+
+
+def declared_symbols() -> list:
+    """Function names declared in include/emu_hip.h (used by the symbol-export test)."""
+    import re
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(emu_[a-z0-9_]+)\s*\(", txt)))

@@ -1,0 +1,400 @@
+// Attention kernels of the Emu2 hot path (gfx950).
+//
+//  rope_kv      : LLaMA RoPE on q,k (in place, bf16 rounding points of transformers' apply_rotary_pos_emb)
+//                 + append of k,v into the [B, H, S_max, D] KV cache.
+//  transpose_v  : V[s][d] -> Vt[d][s] (zero padded to a multiple of 64 keys) so that BOTH MFMA operands of
+//                 the P.V product are contiguous along the contraction (key) axis.
+//  flash_attn   : fused softmax(Q K^T * scale + mask) V for prefill / ViT / UNet shapes, D in {64, 128}.
+//                 v_mfma_f32_32x32x16_bf16 with SWAPPED operands (S^T = K Q^T, O^T = Vt P^T): every lane owns
+//                 one query column, so row max / row sum / rescale are lane-local (one cross-lane exchange
+//                 with lane^32), and P feeds the second MFMA straight from registers.  K rows are loaded
+//                 with bits 2<->3 of the MFMA row index swapped so that the accumulator registers
+//                 8*ks'..8*ks'+7 of a lane are exactly the 8 consecutive keys its B-fragment needs.
+//  decode_attn  : single-query attention over the KV cache, split over the context (HBM-bound), with an
+//                 fp32 log-sum-exp combine.
+//
+// Replaces: transformers LlamaAttention (eager/sdpa) reached from Emu2/emu/emu.py:133-138,213-229;
+// Attention.forward naive branch Emu2/emu/eva_vit.py:227-248.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ rope + kv
+__global__ __launch_bounds__(256) void rope_kv_kernel(const RopeKvArgs a) {
+    const int row = blockIdx.x;                       // b*T + t
+    const int b = row / a.T;
+    const int D = a.D, Hl = a.Hl, half = D >> 1;
+    const int pos = a.pos[row], slot = a.slot[row];
+    bf16_t* q = a.qkv + (size_t)row * 3 * Hl * D;
+    bf16_t* k = q + (size_t)Hl * D;
+    const bf16_t* v = k + (size_t)Hl * D;
+    const bf16_t* cs = a.cos + (size_t)pos * D;
+    const bf16_t* sn = a.sin + (size_t)pos * D;
+    const int vh = half >> 3;                         // 16-byte vectors per half head
+    // items: [0, Hl*vh) rotate q ; [Hl*vh, 2*Hl*vh) rotate k + store ; then v copy
+    for (int it = threadIdx.x; it < 2 * Hl * vh; it += 256) {
+        const bool isk = it >= Hl * vh;
+        const int r = isk ? it - Hl * vh : it;
+        const int h = r / vh, vi = r % vh;
+        bf16_t* base = (isk ? k : q) + (size_t)h * D + vi * 8;
+        float x1[8], x2[8], c[8], s[8], o1[8], o2[8];
+        unpack8(ld16(base), x1);
+        unpack8(ld16(base + half), x2);
+        unpack8(ld16(cs + vi * 8), c);
+        unpack8(ld16(sn + vi * 8), s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // q_embed = (q * cos) + (rotate_half(q) * sin), every product and the sum rounded to bf16
+            o1[j] = bfround(x1[j] * c[j]) + bfround(-x2[j] * s[j]);
+            o2[j] = bfround(x2[j] * c[j]) + bfround(x1[j] * s[j]);
+        }
+        const u32x4 p1 = pack8(o1), p2 = pack8(o2);
+        st16(base, p1);
+        st16(base + half, p2);
+        if (isk) {
+            bf16_t* dst = a.kcache + (((size_t)b * Hl + h) * a.S_max + slot) * D + vi * 8;
+            st16(dst, p1);
+            st16(dst + half, p2);
+        }
+    }
+    const int vd = D >> 3;
+    for (int it = threadIdx.x; it < Hl * vd; it += 256) {
+        const int h = it / vd, vi = it % vd;
+        st16(a.vcache + (((size_t)b * Hl + h) * a.S_max + slot) * D + vi * 8, ld16(v + (size_t)h * D + vi * 8));
+    }
+}
+
+// ------------------------------------------------------------------------------------------ V transpose
+__global__ __launch_bounds__(256) void transpose_v_kernel(const TransposeVArgs a) {
+    __shared__ bf16_t tile[64][72];                   // [token][d], padded
+    const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const int bh = blockIdx.z, b = bh / a.H, h = bh % a.H;
+    const bf16_t* src = a.v + (size_t)b * a.v_sb + (size_t)h * a.v_sh;
+    for (int q = threadIdx.x; q < 512; q += 256) {    // 64 tokens x 8 vectors
+        const int ts = q >> 3, c = q & 7;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (s0 + ts < a.S) val = ld16(src + (size_t)(s0 + ts) * a.v_ss + d0 + c * 8);
+        *reinterpret_cast<u32x4*>(&tile[ts][c * 8]) = val;
+    }
+    __syncthreads();
+    bf16_t* dst = a.vt + ((size_t)bh * a.D + d0) * a.S_pad + s0;
+    for (int q = threadIdx.x; q < 512; q += 256) {    // 64 d x 8 token-vectors
+        const int d = q >> 3, c = q & 7;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)tile[c * 8 + 2 * e][d] | ((uint32_t)tile[c * 8 + 2 * e + 1][d] << 16);
+        const u32x4 o = {w[0], w[1], w[2], w[3]};
+        st16(dst + (size_t)d * a.S_pad + c * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ flash attention
+template <int ROWB>                                   // bytes per LDS row: 128 or 256
+__device__ __forceinline__ int sw_off(int row, int chunk) {
+    if constexpr (ROWB == 256) return row * 256 + ((chunk ^ (row & 15)) << 4);
+    else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_kernel(const FlashArgs a) {
+    constexpr int KROWB = D * 2;                      // K tile [64 keys][D]
+    constexpr int KCH = D / 8;                        // 16-byte chunks per K row
+    constexpr int NKK = D / 16;                       // k-steps of QK^T
+    constexpr int NDB = D / 32;                       // 32-wide d blocks of O
+    constexpr int KT_BYTES = 64 * KROWB;
+    constexpr int VT_BYTES = D * 128;                 // Vt tile [D][64 keys]
+    constexpr int NLD = (KT_BYTES / 16) / 256;        // 16-byte chunks per thread per tile (= D/32)
+    __shared__ __attribute__((aligned(16))) char smem[KT_BYTES + VT_BYTES];
+    char* sK = smem;
+    char* sV = smem + KT_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qblk = blockIdx.x * 128;
+    const int q0 = qblk + wave * 32;
+    const int off = a.Sk - a.Sq;                      // causal: query i sees keys <= i + off
+    const int kstart = a.kstart ? a.kstart[b] : 0;
+
+    // Q fragments (B operand): column = query l31, k = 16*kk + 8*hi + j
+    int qi = q0 + l31;
+    const int qrow = qi < a.Sq ? qi : a.Sq - 1;
+    const bf16_t* qp = a.q + (size_t)b * a.q_sb + (size_t)h * a.q_sh + (size_t)qrow * a.q_ss + 8 * hi;
+    bf16x8_t qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * kk);
+
+    const bf16_t* kbase = a.k + (size_t)b * a.k_sb + (size_t)h * a.k_sh;
+    const bf16_t* vbase = a.vt + ((size_t)(b * a.H + h) * D) * a.Sk_pad;
+
+    int last_key = a.Sk - 1;
+    if (a.causal) {
+        int qmax = qblk + 127; qmax = qmax < a.Sq ? qmax : a.Sq - 1;
+        last_key = qmax + off < last_key ? qmax + off : last_key;
+    }
+    const int ntile = last_key < 0 ? 0 : last_key / 64 + 1;
+
+    u32x4 rk[NLD], rv[NLD];
+    auto gload = [&](int t) {
+        const int kt0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = tid + 256 * i;
+            { const int row = q / KCH, c = q % KCH;
+              int key = kt0 + row; key = key < a.Sk ? key : a.Sk - 1;
+              rk[i] = ld16(kbase + (size_t)key * a.k_ss + c * 8); }
+            { const int row = q >> 3, c = q & 7;
+              rv[i] = ld16(vbase + (size_t)row * a.Sk_pad + kt0 + c * 8); }
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = tid + 256 * i;
+            st16(sK + sw_off<KROWB>(q / KCH, q % KCH), rk[i]);
+            st16(sV + sw_off<128>(q >> 3, q & 7), rv[i]);
+        }
+    };
+
+    f32x16_t o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = a.scale * 1.4426950408889634f;   // softmax in the exp2 domain
+
+    // MFMA row i of the K operand holds key pi(i) = i with bits 2 and 3 swapped
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+    if (ntile > 0) gload(0);
+    for (int t = 0; t < ntile; ++t) {
+        __syncthreads();                               // previous tile fully consumed
+        sstore();
+        __syncthreads();
+        if (t + 1 < ntile) gload(t + 1);               // overlap next tile's HBM latency with the MFMAs
+        const int kt0 = t * 64;
+
+        f32x16_t s[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + sw_off<KROWB>(blk * 32 + krow, kk * 2 + hi));
+                s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[blk], 0, 0, 0);
+            }
+        }
+        // lane (query qi) holds keys kt0 + 32*blk + 16*(r>>3) + 8*hi + (r&7)
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt0 + 32 * blk + 16 * (r >> 3) + 8 * hi + (r & 7);
+                const bool ok = key < a.Sk && key >= kstart && (!a.causal || key <= qi + off);
+                const float v = ok ? s[blk][r] * sc : -INFINITY;
+                s[blk][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m_run, mloc);
+        float alpha = 1.f;
+        const bool dead = (mnew == -INFINITY);         // every key so far masked for this query
+        if (!dead) alpha = exp2f(m_run - mnew);        // m_run = -inf -> 0
+        float psum = 0.f;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = dead ? 0.f : exp2f(s[blk][r] - mnew);
+                psum += p;
+                pf[blk * 2 + (r >> 3)][r & 7] = (__bf16)p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = mnew;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + sw_off<128>(db * 32 + l31, ks * 2 + hi));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
+            }
+    }
+
+    const float ltot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (qi < a.Sq) {
+        bf16_t* op = a.o + (size_t)b * a.o_sb + (size_t)h * a.o_sh + (size_t)qi * a.o_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 ov;
+                ov.x = packbf(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                ov.y = packbf(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + db * 32 + 8 * g + 4 * hi) = ov;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ decode attention
+constexpr int DEC_CHUNK = 256;                         // keys per workgroup
+
+template <int D>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeAttnArgs a, int nsplit) {
+    constexpr int VD = D / 8;                          // 16-byte vectors per row
+    constexpr int NG = 256 / VD;                       // key groups in the P.V phase
+    __shared__ float sq[D];
+    __shared__ float sp[DEC_CHUNK];
+    __shared__ float red[NG][D + 1];
+    __shared__ float scratch[4];
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int k0 = split * DEC_CHUNK;
+    const int ctx = a.ctx_ptr ? *a.ctx_ptr : a.ctx;
+    const int nk = min(DEC_CHUNK, ctx - k0);          // <= 0 for splits beyond the live context
+    const int kstart = a.kstart ? a.kstart[b] : 0;
+    if (tid < D) sq[tid] = bf2f(a.q[(size_t)b * a.q_sb + (size_t)h * a.q_sh + tid]);
+    __syncthreads();
+    const size_t rowbase = ((size_t)b * a.H + h) * a.S_max;
+    const bf16_t* kc = a.kcache + rowbase * D;
+    const bf16_t* vc = a.vcache + rowbase * D;
+
+    float sc = -INFINITY;
+    if (tid < nk && (k0 + tid) >= kstart) {
+        const bf16_t* kr = kc + (size_t)(k0 + tid) * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int vi = 0; vi < VD; ++vi) {
+            float f[8];
+            unpack8(ld16(kr + vi * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(f[j], sq[vi * 8 + j], acc);
+        }
+        sc = acc * a.scale;
+    }
+    // block max
+    float m = wave_max(sc);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    const float p = (sc == -INFINITY) ? 0.f : __expf(sc - m);
+    sp[tid] = p;
+    const float l = block_sum<4>(p, scratch);          // contains the barriers that publish sp[]
+
+    const int dv = tid % VD, kg = tid / VD;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = kg; j < nk; j += NG) {
+        float f[8];
+        unpack8(ld16(vc + (size_t)(k0 + j) * D + dv * 8), f);
+        const float pj = sp[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, f[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[kg][dv * 8 + e] = acc[e];
+    __syncthreads();
+    float* w = a.ws + (((size_t)b * a.H + h) * nsplit + split) * (D + 2);
+    if (tid < D) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < NG; ++g) t += red[g][tid];
+        w[tid] = t;
+    }
+    if (tid == 0) { w[D] = m; w[D + 1] = l; }
+}
+
+template <int D>
+__global__ void decode_combine_kernel(const DecodeAttnArgs a, int nsplit) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* w = a.ws + ((size_t)b * a.H + h) * nsplit * (D + 2);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, w[s * (D + 2) + D]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = w[s * (D + 2) + D];
+        const float f = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+        num += f * w[s * (D + 2) + d];
+        den += f * w[s * (D + 2) + D + 1];
+    }
+    a.o[(size_t)b * a.o_sb + (size_t)h * a.o_sh + d] = f2bf(den > 0.f ? num / den : 0.f);
+}
+
+}  // namespace
+
+int launch_rope_kv(const RopeKvArgs& a, hipStream_t s) {
+    if (a.B < 1 || a.T < 1 || (a.D & 15)) return -22;
+    hipLaunchKernelGGL(rope_kv_kernel, dim3(a.B * a.T), dim3(256), 0, s, a);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_transpose_v(const TransposeVArgs& a, hipStream_t s) {
+    if ((a.D & 63) || (a.S_pad & 63) || a.S_pad < a.S || (a.v_ss & 7) || (a.v_sh & 7) || (a.v_sb & 7)) return -22;
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(a.S_pad / 64, a.D / 64, a.B * a.H), dim3(256), 0, s, a);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_flash_attn(const FlashArgs& a, hipStream_t s) {
+    if (a.Sq < 1 || a.Sk < 1 || (a.Sk_pad & 63) || a.Sk_pad < a.Sk) return -22;
+    if ((a.q_ss & 7) || (a.k_ss & 7) || (a.o_ss & 3) || (a.q_sh & 7) || (a.k_sh & 7) || (a.o_sh & 3) ||
+        (a.q_sb & 7) || (a.k_sb & 7) || (a.o_sb & 3)) return -22;
+    const dim3 grid((a.Sq + 127) / 128, a.H, a.B), block(256);
+    if (a.D == 128) hipLaunchKernelGGL(flash_kernel<128>, grid, block, 0, s, a);
+    else if (a.D == 64) hipLaunchKernelGGL(flash_kernel<64>, grid, block, 0, s, a);
+    else return -22;
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+int decode_attn_nsplit(int ctx) { return ctx < 1 ? 1 : (ctx + DEC_CHUNK - 1) / DEC_CHUNK; }
+
+namespace {
+__global__ void greedy_advance_kernel(const int32_t* cur_ids, int32_t* pos, int32_t* slot, int32_t* ctx,
+                                      int32_t* step, int32_t* out_ids, int B) {
+    const int b = threadIdx.x;
+    const int st = *step;
+    if (b < B) {
+        out_ids[(size_t)st * B + b] = cur_ids[b];
+        pos[b] += 1;
+        slot[b] += 1;
+    }
+    __syncthreads();
+    if (b == 0) { *ctx += 1; *step = st + 1; }
+}
+
+}  // namespace
+
+int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, int32_t* ctx, int32_t* step,
+                          int32_t* out_ids, int B, hipStream_t s) {
+    if (B < 1 || B > 64) return -22;
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(64), 0, s, cur_ids, pos, slot, ctx, step, out_ids, B);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s) {
+    const int cmax = a.ctx_max > 0 ? a.ctx_max : a.ctx;
+    if (cmax < 1 || cmax > a.S_max || a.ctx > cmax) return -22;
+    const int ns = decode_attn_nsplit(cmax);
+    if (a.D == 128) {
+        hipLaunchKernelGGL(decode_attn_kernel<128>, dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        hipLaunchKernelGGL(decode_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a, ns);
+    } else if (a.D == 64) {
+        hipLaunchKernelGGL(decode_attn_kernel<64>, dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        hipLaunchKernelGGL(decode_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a, ns);
+    } else return -22;
+    EMU_CHECK_LAUNCH();
+    return 0;
+}

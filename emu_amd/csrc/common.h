@@ -1,0 +1,79 @@
+// Common device helpers for the Emu2 MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes; MFMA fragments follow the gfx950 32x32x16 bf16 layout:
+//   A/B operand: lane l holds row/col (l & 31), k = 8*(l >> 5) + j, j = 0..7  (8 bf16 = 4 VGPRs)
+//   C/D        : lane l holds col (l & 31), row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                             // raw bfloat16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));         // one MFMA A/B fragment
+typedef float f32x16_t __attribute__((ext_vector_type(16)));         // one 32x32 accumulator
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));           // 16-byte load/store unit (8 bf16)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define EMU_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN-preserving: bit-identical to torch's float -> bfloat16 cast
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+
+// low / high bf16 of a packed dword as float
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t packbf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+    f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+    f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+    v.x = packbf(f[0], f[1]); v.y = packbf(f[2], f[3]); v.z = packbf(f[4], f[5]); v.w = packbf(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blocks of NW waves; scratch must hold NW floats; all threads get the result
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) scratch[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += scratch[i];
+    return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// streaming (read-once) 16-byte load: weights are touched once per token, keep them out of L2
+__device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+#define EMU_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

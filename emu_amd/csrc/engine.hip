@@ -1,0 +1,466 @@
+// C ABI of libemu_hip.so (declared in include/emu_hip.h): context + RCCL communicator, primitive operator
+// entry points, and the LLaMA / EVA-ViT engines that chain the kernels on one HIP stream without any
+// allocation or synchronisation (so whole forwards are hipGraph / stream-capture safe).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/emu_hip.h"
+#include "kernels.h"
+
+struct emu_ctx {
+    int device = 0, tp_rank = 0, tp_size = 1;
+    ncclComm_t comm = nullptr;
+    std::string err;
+};
+
+namespace {
+inline hipStream_t S(emu_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline const bf16_t* B(const void* p) { return reinterpret_cast<const bf16_t*>(p); }
+inline bf16_t* B(void* p) { return reinterpret_cast<bf16_t*>(p); }
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+int fail(emu_ctx* c, int code, const char* what) {
+    if (c) { char buf[256]; snprintf(buf, sizeof buf, "%s (status %d)", what, code); c->err = buf; }
+    return code;
+}
+#define TRY(c, expr) do { int st__ = (expr); if (st__ != 0) return fail((c), st__, #expr); } while (0)
+
+// HIP-event timing of the weight-streaming GEMV launches (bench.py roofline leg; eager mode only)
+struct GemvProfiler {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double bytes = 0.0;
+} g_prof;
+
+int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* res, const bf16_t* norm_w,
+           bf16_t* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, hipStream_t s) {
+    if (M <= 8) {
+        GemvArgs g{A, W, norm_w, bias, res, C, M, N, K, lda, ldw, ldres, ldc, eps, epi, 0};
+        if (!g_prof.on) return launch_gemv(g, s);
+        if (g_prof.used == g_prof.ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -12;
+            g_prof.ev.emplace_back(a, b);
+        }
+        auto& e = g_prof.ev[g_prof.used++];
+        g_prof.bytes += 2.0 * (double)N * (double)K;
+        (void)hipEventRecord(e.first, s);
+        const int st = launch_gemv(g, s);
+        (void)hipEventRecord(e.second, s);
+        return st;
+    }
+    if (norm_w) return -22;
+    GemmArgs g{A, W, bias, res, C, M, N, K, lda, ldw, ldres, ldc, epi};
+    return launch_gemm(g, s);
+}
+}  // namespace
+
+extern "C" {
+
+int emu_version(void) { return 1; }
+
+int emu_profile_gemv(int enable) {
+    g_prof.on = enable != 0;
+    g_prof.used = 0;
+    g_prof.bytes = 0.0;
+    return 0;
+}
+
+int emu_profile_gemv_read(double* total_ms, double* weight_bytes, long* launches) {
+    double t = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i].second);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.ev[i].first, g_prof.ev[i].second);
+        if (e != hipSuccess) return (int)e;
+        t += ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (weight_bytes) *weight_bytes = g_prof.bytes;
+    if (launches) *launches = (long)g_prof.used;
+    return 0;
+}
+
+int emu_ctx_create(int device, int tp_rank, int tp_size, emu_ctx** out) {
+    if (!out || tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size) return -22;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device < 0 || device >= n) return e != hipSuccess ? (int)e : -19;
+    emu_ctx* c = new emu_ctx();
+    c->device = device; c->tp_rank = tp_rank; c->tp_size = tp_size;
+    *out = c;
+    return 0;
+}
+
+void emu_ctx_destroy(emu_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->comm) ncclCommDestroy(ctx->comm);
+    delete ctx;
+}
+
+const char* emu_last_error(const emu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int emu_tp_unique_id(void* out128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return 1000 + (int)r;
+    memcpy(out128, &id, sizeof id);
+    return 0;
+}
+
+int emu_tp_init(emu_ctx* ctx, const void* id128) {
+    if (!ctx) return -22;
+    if (ctx->comm) return 0;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, (int)e, "hipSetDevice");
+    ncclResult_t r = ncclCommInitRank(&ctx->comm, ctx->tp_size, id, ctx->tp_rank);
+    if (r != ncclSuccess) { ctx->comm = nullptr; return fail(ctx, 1000 + (int)r, "ncclCommInitRank"); }
+    return 0;
+}
+
+int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s) {
+    if (!ctx) return -22;
+    if (ctx->tp_size == 1) return 0;
+    if (!ctx->comm) return fail(ctx, -107, "emu_allreduce_bf16: communicator not initialised (emu_tp_init)");
+    ncclResult_t r = ncclAllReduce(buf, buf, n, ncclBfloat16, ncclSum, ctx->comm, S(s));
+    return r == ncclSuccess ? 0 : fail(ctx, 1000 + (int)r, "ncclAllReduce");
+}
+
+// ---------------------------------------------------------------------------------------------- primitives
+int emu_linear_bf16(const void* A, const void* W, const void* bias, const void* res, const void* norm_w, void* C,
+                    int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, emu_stream_t s) {
+    return linear(B(A), B(W), B(bias), B(res), B(norm_w), B(C), M, N, K, lda, ldw, ldres, ldc, eps, epi, S(s));
+}
+int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, int ldx, int ldy, float eps, emu_stream_t s) {
+    return launch_rmsnorm(B(x), B(w), B(y), rows, cols, ldx, ldy, eps, S(s));
+}
+int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* res, void* y, int rows, int cols,
+                       float eps, emu_stream_t s) {
+    return launch_layernorm(B(x), B(w), B(b), B(res), B(y), rows, cols, eps, S(s));
+}
+int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab, emu_stream_t s) {
+    return launch_embed_gather(ids, B(table), B(out), n_tok, hidden, vocab, S(s));
+}
+int emu_scatter_rows_bf16(const void* src, const int32_t* dst_rows, void* out, int n_rows, int hidden, emu_stream_t s) {
+    return launch_scatter_rows(B(src), dst_rows, B(out), n_rows, hidden, S(s));
+}
+int emu_argmax_bf16(const void* logits, int ld, int rows, int vocab, int suppress_id, int32_t* out, emu_stream_t s) {
+    return launch_argmax(B(logits), ld, rows, vocab, suppress_id, out, S(s));
+}
+int emu_patchify(const void* image, int image_is_f32, void* out, int Bn, int C, int HW, int patch, int Kpad, emu_stream_t s) {
+    return launch_patchify(image, image_is_f32, B(out), Bn, C, HW, patch, Kpad, S(s));
+}
+int emu_vit_assemble_bf16(const void* patches, const void* cls, const void* pos, void* x, int Bn, int T, int C, emu_stream_t s) {
+    return launch_vit_assemble(B(patches), B(cls), B(pos), B(x), Bn, T, C, S(s));
+}
+int emu_avgpool_tokens_bf16(const void* x, void* out, int Bn, int g, int C, int stride, emu_stream_t s) {
+    return launch_avgpool_tokens(B(x), B(out), Bn, g, C, stride, S(s));
+}
+int emu_rope_kv_append_bf16(void* qkv, const void* cos, const void* sin, const int32_t* pos, const int32_t* slot,
+                            void* kcache, void* vcache, int Bn, int T, int H, int D, int S_max, emu_stream_t s) {
+    RopeKvArgs a{B(qkv), B(cos), B(sin), pos, slot, B(kcache), B(vcache), Bn, T, H, D, S_max};
+    return launch_rope_kv(a, S(s));
+}
+int emu_transpose_v_bf16(const void* v, long v_sb, long v_sh, long v_ss, void* vt, int Bn, int H, int Sn, int D,
+                         int S_pad, emu_stream_t s) {
+    TransposeVArgs a{B(v), v_sb, v_sh, v_ss, B(vt), Bn, H, Sn, D, S_pad};
+    return launch_transpose_v(a, S(s));
+}
+int emu_flash_attn_bf16(const void* q, long q_sb, long q_sh, long q_ss, const void* k, long k_sb, long k_sh, long k_ss,
+                        const void* vt, void* o, long o_sb, long o_sh, long o_ss, const int32_t* kstart, int Bn, int H,
+                        int Sq, int Sk, int Sk_pad, int D, int causal, float scale, emu_stream_t s) {
+    FlashArgs a{B(q), q_sb, q_sh, q_ss, B(k), k_sb, k_sh, k_ss, B(vt), B(o), o_sb, o_sh, o_ss, kstart,
+                Bn, H, Sq, Sk, Sk_pad, D, causal, scale};
+    return launch_flash_attn(a, S(s));
+}
+size_t emu_decode_attn_ws_bytes(int Bn, int H, int D, int ctx_max) {
+    return (size_t)Bn * H * decode_attn_nsplit(ctx_max) * (D + 2) * sizeof(float);
+}
+int emu_decode_attn_bf16(const void* q, long q_sb, long q_sh, const void* kcache, const void* vcache, void* o,
+                         long o_sb, long o_sh, const int32_t* kstart, const int32_t* ctx_dev, int ctx, int ctx_max,
+                         void* ws, int Bn, int H, int D, int S_max, float scale, emu_stream_t s) {
+    DecodeAttnArgs a{B(q), q_sb, q_sh, B(kcache), B(vcache), B(o), o_sb, o_sh, kstart, ctx_dev,
+                     reinterpret_cast<float*>(ws), Bn, H, D, S_max, ctx, ctx_max, scale};
+    return launch_decode_attn(a, S(s));
+}
+
+}  // extern "C"
+
+// =============================================================================================== LLaMA engine
+struct emu_llama {
+    emu_ctx* ctx;
+    emu_llama_cfg cfg;
+    struct Layer { const bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2; };
+    std::vector<Layer> layers;
+    const bf16_t *final_norm = nullptr, *lm_head = nullptr, *embed = nullptr, *cos = nullptr, *sin = nullptr;
+    bf16_t *kcache = nullptr, *vcache = nullptr;
+    int kv_batch = 0, s_max = 0;
+};
+
+namespace {
+struct LlamaWs {
+    bf16_t *hB, *xn, *qkv, *attn, *act, *vt;
+    float* dec;
+    size_t total;
+};
+LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
+    const emu_llama_cfg& c = m->cfg;
+    const size_t M = (size_t)Bn * T, HD = (size_t)c.heads_local * c.head_dim;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    LlamaWs w;
+    w.hB = (bf16_t*)take(M * c.hidden * 2);
+    w.xn = (bf16_t*)take(M * c.hidden * 2);
+    w.qkv = (bf16_t*)take(M * 3 * HD * 2);
+    w.attn = (bf16_t*)take(M * HD * 2);
+    w.act = (bf16_t*)take(M * (size_t)c.ffn_local * 2);
+    const size_t spad = (size_t)((m->s_max + 63) / 64) * 64;
+    w.vt = (bf16_t*)take(T > 1 ? (size_t)Bn * HD * spad * 2 : 0);
+    w.dec = (float*)take(emu_decode_attn_ws_bytes(Bn, c.heads_local, c.head_dim, m->s_max > 0 ? m->s_max : 1));
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+int emu_llama_create(emu_ctx* ctx, const emu_llama_cfg* cfg, emu_llama** out) {
+    if (!ctx || !cfg || !out) return -22;
+    if ((cfg->head_dim != 128 && cfg->head_dim != 64) || (cfg->hidden & 7) || (cfg->ffn_local & 7) || cfg->layers < 1)
+        return fail(ctx, -22, "emu_llama_create: head_dim must be 64/128, hidden and ffn_local multiples of 8");
+    emu_llama* m = new emu_llama();
+    m->ctx = ctx; m->cfg = *cfg;
+    m->layers.resize(cfg->layers);
+    memset(m->layers.data(), 0, sizeof(emu_llama::Layer) * cfg->layers);
+    *out = m;
+    return 0;
+}
+void emu_llama_destroy(emu_llama* m) { delete m; }
+
+int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* wo, const void* wgu, const void* wdown,
+                        const void* ln1, const void* ln2) {
+    if (!m || layer < 0 || layer >= m->cfg.layers) return -22;
+    m->layers[layer] = {B(wqkv), B(wo), B(wgu), B(wdown), B(ln1), B(ln2)};
+    return 0;
+}
+int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed, const void* rope_cos,
+                       const void* rope_sin) {
+    if (!m) return -22;
+    m->final_norm = B(final_norm); m->lm_head = B(lm_head); m->embed = B(embed); m->cos = B(rope_cos); m->sin = B(rope_sin);
+    return 0;
+}
+int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max) {
+    if (!m || batch < 1 || s_max < 1) return -22;
+    m->kcache = B(kcache); m->vcache = B(vcache); m->kv_batch = batch; m->s_max = s_max;
+    return 0;
+}
+size_t emu_llama_workspace_bytes(const emu_llama* m, int Bn, int T) {
+    if (!m) return 0;
+    return llama_ws(m, Bn, T, nullptr).total;
+}
+
+int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* pos, const int32_t* slot,
+                      const int32_t* kstart, const int32_t* ctx_dev, int ctx, void* workspace, size_t ws_bytes,
+                      emu_stream_t s_) {
+    if (!m || !hidden || !pos || !slot) return -22;
+    emu_ctx* cx = m->ctx;
+    const emu_llama_cfg& c = m->cfg;
+    if (!m->kcache || Bn != m->kv_batch) return fail(cx, -22, "emu_llama_forward: KV cache not set for this batch size");
+    if (ctx < 1 || ctx > m->s_max) return fail(cx, -22, "emu_llama_forward: ctx out of range");
+    if (!m->cos) return fail(cx, -22, "emu_llama_forward: rope tables not set");
+    const LlamaWs w = llama_ws(m, Bn, T, workspace);
+    if (w.total > ws_bytes) return fail(cx, -12, "emu_llama_forward: workspace too small");
+    hipStream_t s = S(s_);
+    const int M = Bn * T, H = c.hidden, Hl = c.heads_local, D = c.head_dim, HD = Hl * D, Fl = c.ffn_local;
+    const bool tp = cx->tp_size > 1;
+    const int epi_res = (!tp || cx->tp_rank == 0) ? EPI_RESID : EPI_NONE;   // residual enters the all-reduce once
+    const float scale = 1.0f / sqrtf((float)D);
+    const size_t kv_layer = (size_t)Bn * Hl * m->s_max * D;
+    const int spad = (ctx + 63) / 64 * 64;
+    bf16_t* hA = B(hidden);
+    for (int l = 0; l < c.layers; ++l) {
+        const emu_llama::Layer& L = m->layers[l];
+        if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
+        bf16_t* kc = m->kcache + l * kv_layer;
+        bf16_t* vc = m->vcache + l * kv_layer;
+        // ---- attention
+        if (M <= 8) {
+            TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
+        } else {
+            TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
+            TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s));
+        }
+        { RopeKvArgs r{w.qkv, m->cos, m->sin, pos, slot, kc, vc, Bn, T, Hl, D, m->s_max};
+          TRY(cx, launch_rope_kv(r, s)); }
+        if (T == 1) {
+            DecodeAttnArgs a{w.qkv, (long)3 * HD, (long)D, kc, vc, w.attn, (long)HD, (long)D, kstart, ctx_dev, w.dec,
+                             Bn, Hl, D, m->s_max, ctx, ctx, scale};
+            TRY(cx, launch_decode_attn(a, s));
+        } else {
+            TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, w.vt, Bn, Hl, ctx, D, spad};
+            TRY(cx, launch_transpose_v(tv, s));
+            FlashArgs f{w.qkv, (long)T * 3 * HD, (long)D, (long)3 * HD,
+                        kc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D,
+                        w.vt, w.attn, (long)T * HD, (long)D, (long)HD, kstart,
+                        Bn, Hl, T, ctx, spad, D, 1, scale};
+            TRY(cx, launch_flash_attn(f, s));
+        }
+        TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s));
+        if (tp) TRY(cx, emu_allreduce_bf16(cx, w.hB, (size_t)M * H, s_));
+        // ---- SwiGLU MLP
+        if (M <= 8) {
+            TRY(cx, linear(w.hB, L.wgu, nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s));
+        } else {
+            TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
+            TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s));
+        }
+        TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s));
+        if (tp) TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)M * H, s_));
+    }
+    return 0;
+}
+
+int emu_llama_final_norm(emu_llama* m, const void* hidden, void* out, int rows, emu_stream_t s) {
+    if (!m || !m->final_norm) return -22;
+    return launch_rmsnorm(B(hidden), m->final_norm, B(out), rows, m->cfg.hidden, m->cfg.hidden, m->cfg.hidden,
+                          m->cfg.rms_eps, S(s));
+}
+
+int emu_llama_logits(emu_llama* m, const void* hidden, int ldh, int M, void* logits, int ld, void* workspace,
+                     size_t ws_bytes, emu_stream_t s) {
+    if (!m || !m->lm_head || !m->final_norm) return -22;
+    const emu_llama_cfg& c = m->cfg;
+    if (M <= 8)
+        return linear(B(hidden), m->lm_head, nullptr, nullptr, m->final_norm, B(logits), M, c.vocab, c.hidden, ldh,
+                      c.hidden, 0, ld, c.rms_eps, EPI_NONE, S(s));
+    if (ws_bytes < (size_t)M * c.hidden * 2) return fail(m->ctx, -12, "emu_llama_logits: workspace too small");
+    TRY(m->ctx, launch_rmsnorm(B(hidden), m->final_norm, B(workspace), M, c.hidden, ldh, c.hidden, c.rms_eps, S(s)));
+    return linear(B(workspace), m->lm_head, nullptr, nullptr, nullptr, B(logits), M, c.vocab, c.hidden, c.hidden, c.hidden,
+                  0, ld, 0.f, EPI_NONE, S(s));
+}
+
+int emu_llama_greedy_step(emu_llama* m, int Bn, int32_t* cur_ids, int32_t* pos, int32_t* slot, const int32_t* kstart,
+                          int32_t* ctx_dev, int32_t* step_dev, int32_t* out_ids, int ctx_upper, void* hidden,
+                          void* logits, int ld_logits, void* workspace, size_t ws_bytes, emu_stream_t s) {
+    if (!m || !m->embed) return -22;
+    const emu_llama_cfg& c = m->cfg;
+    TRY(m->ctx, launch_embed_gather(cur_ids, m->embed, B(hidden), Bn, c.hidden, c.vocab, S(s)));
+    TRY(m->ctx, emu_llama_forward(m, hidden, Bn, 1, pos, slot, kstart, ctx_dev, ctx_upper, workspace, ws_bytes, s));
+    TRY(m->ctx, emu_llama_logits(m, hidden, c.hidden, Bn, logits, ld_logits, workspace, ws_bytes, s));
+    TRY(m->ctx, launch_argmax(B(logits), ld_logits, Bn, c.vocab, -1, cur_ids, S(s)));
+    TRY(m->ctx, launch_greedy_advance(cur_ids, pos, slot, ctx_dev, step_dev, out_ids, Bn, S(s)));
+    return 0;
+}
+
+}  // extern "C"
+
+// =============================================================================================== ViT engine
+struct emu_vit {
+    emu_ctx* ctx;
+    emu_vit_cfg cfg;
+    const bf16_t *wpatch = nullptr, *bpatch = nullptr, *cls = nullptr, *pos = nullptr;
+    struct Block { const bf16_t *wqkv, *bqkv, *wproj, *bproj, *ln1w, *ln1b, *fc1w, *fc1b, *fc2w, *fc2b, *ln2w, *ln2b; };
+    std::vector<Block> blocks;
+};
+
+namespace {
+constexpr int VIT_DP = 128;      // padded head dim
+struct VitWs { bf16_t *patches, *pemb, *qkv, *vt, *attn, *tmp, *h1; size_t total; };
+VitWs vit_ws(const emu_vit* m, int Bn, void* base) {
+    const emu_vit_cfg& c = m->cfg;
+    const int g = c.image_size / c.patch_size, T = g * g, N = T + 1;
+    const size_t M = (size_t)Bn * N;
+    const size_t npad = (size_t)(N + 63) / 64 * 64;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    VitWs w;
+    w.patches = (bf16_t*)take((size_t)Bn * T * c.kpad * 2);
+    w.pemb = (bf16_t*)take((size_t)Bn * T * c.width * 2);
+    w.qkv = (bf16_t*)take(M * 3 * c.heads * VIT_DP * 2);
+    w.vt = (bf16_t*)take((size_t)Bn * c.heads * VIT_DP * npad * 2);
+    w.attn = (bf16_t*)take(M * c.heads * VIT_DP * 2);
+    w.tmp = (bf16_t*)take(M * c.width * 2);
+    w.h1 = (bf16_t*)take(M * (size_t)c.mlp_hidden * 2);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+int emu_vit_create(emu_ctx* ctx, const emu_vit_cfg* cfg, emu_vit** out) {
+    if (!ctx || !cfg || !out) return -22;
+    if (cfg->head_width > VIT_DP || (cfg->width & 7) || (cfg->mlp_hidden & 7) || (cfg->kpad & 7) ||
+        cfg->kpad < 3 * cfg->patch_size * cfg->patch_size || cfg->image_size % cfg->patch_size)
+        return fail(ctx, -22, "emu_vit_create: unsupported shape");
+    emu_vit* m = new emu_vit();
+    m->ctx = ctx; m->cfg = *cfg;
+    m->blocks.resize(cfg->layers);
+    memset(m->blocks.data(), 0, sizeof(emu_vit::Block) * cfg->layers);
+    *out = m;
+    return 0;
+}
+void emu_vit_destroy(emu_vit* m) { delete m; }
+int emu_vit_set_stem(emu_vit* m, const void* wpatch, const void* bpatch, const void* cls, const void* pos) {
+    if (!m) return -22;
+    m->wpatch = B(wpatch); m->bpatch = B(bpatch); m->cls = B(cls); m->pos = B(pos);
+    return 0;
+}
+int emu_vit_set_block(emu_vit* m, int layer, const void* wqkv, const void* bqkv, const void* wproj, const void* bproj,
+                      const void* ln1w, const void* ln1b, const void* fc1w, const void* fc1b, const void* fc2w,
+                      const void* fc2b, const void* ln2w, const void* ln2b) {
+    if (!m || layer < 0 || layer >= m->cfg.layers) return -22;
+    m->blocks[layer] = {B(wqkv), B(bqkv), B(wproj), B(bproj), B(ln1w), B(ln1b), B(fc1w), B(fc1b), B(fc2w), B(fc2b), B(ln2w), B(ln2b)};
+    return 0;
+}
+size_t emu_vit_workspace_bytes(const emu_vit* m, int Bn) { return m ? vit_ws(m, Bn, nullptr).total : 0; }
+
+int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, void* out_tokens, void* workspace,
+                    size_t ws_bytes, emu_stream_t s_) {
+    if (!m || !image || !out_tokens || !m->wpatch) return -22;
+    emu_ctx* cx = m->ctx;
+    const emu_vit_cfg& c = m->cfg;
+    const VitWs w = vit_ws(m, Bn, workspace);
+    if (w.total > ws_bytes) return fail(cx, -12, "emu_vit_forward: workspace too small");
+    hipStream_t s = S(s_);
+    const int g = c.image_size / c.patch_size, T = g * g, N = T + 1, M = Bn * N, C = c.width, Hh = c.heads;
+    const int QK = Hh * VIT_DP, F = c.mlp_hidden;
+    const int npad = (N + 63) / 64 * 64;
+    const float scale = 1.0f / sqrtf((float)c.head_width);
+    bf16_t* x = B(out_tokens);
+    TRY(cx, launch_patchify(image, image_is_f32, w.patches, Bn, 3, c.image_size, c.patch_size, c.kpad, s));
+    TRY(cx, linear(w.patches, m->wpatch, m->bpatch, nullptr, nullptr, w.pemb, Bn * T, C, c.kpad, c.kpad, c.kpad, 0, C, 0.f, EPI_NONE, s));
+    TRY(cx, launch_vit_assemble(w.pemb, m->cls, m->pos, x, Bn, T, C, s));
+    for (int l = 0; l < c.layers; ++l) {
+        const emu_vit::Block& Bk = m->blocks[l];
+        if (!Bk.wqkv) return fail(cx, -22, "emu_vit_forward: block weights not set");
+        TRY(cx, linear(x, Bk.wqkv, Bk.bqkv, nullptr, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, 0.f, EPI_NONE, s));
+        TransposeVArgs tv{w.qkv + 2 * QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK, w.vt, Bn, Hh, N, VIT_DP, npad};
+        TRY(cx, launch_transpose_v(tv, s));
+        FlashArgs f{w.qkv, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
+                    w.qkv + QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
+                    w.vt, w.attn, (long)N * QK, (long)VIT_DP, (long)QK, nullptr,
+                    Bn, Hh, N, N, npad, VIT_DP, 0, scale};
+        TRY(cx, launch_flash_attn(f, s));
+        TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s));
+        TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
+        TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
+        TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s));
+        TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+    }
+    return 0;
+}
+
+}  // extern "C"

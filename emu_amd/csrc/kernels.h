@@ -1,0 +1,102 @@
+// Internal launch interface between the C-ABI layer (capi.cpp / engine.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+enum EmuEpilogue { EPI_NONE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_SILU = 3, EPI_GELU = 4, EPI_GEGLU = 5 };
+
+struct GemvArgs {
+    const bf16_t* x;        // [M, ldx]
+    const bf16_t* W;        // [N, ldw]   (K contiguous)
+    const bf16_t* norm_w;   // [K] or null: fused RMSNorm prologue on x
+    const bf16_t* bias;     // [N] or null
+    const bf16_t* res;      // [M, ldres] (EPI_RESID)
+    bf16_t* out;            // [M, ldo]   (EPI_SWIGLU: N/2 columns)
+    int M, N, K;
+    int ldx, ldw, ldres, ldo;
+    float eps;
+    int epi;
+    int rows_per_block;     // 0 = heuristic
+};
+int launch_gemv(const GemvArgs& a, hipStream_t s);
+
+struct GemmArgs {
+    const bf16_t* A;        // [M, lda]  activations (K contiguous)
+    const bf16_t* W;        // [N, ldw]  weights     (K contiguous)
+    const bf16_t* bias;     // [N] or null
+    const bf16_t* res;      // [M, ldres] (EPI_RESID)
+    bf16_t* C;              // [M, ldc]  (EPI_SWIGLU / EPI_GEGLU: N/2 columns)
+    int M, N, K;
+    int lda, ldw, ldres, ldc;
+    int epi;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---- row-wise / elementwise (elementwise.hip)
+int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);
+// y = (res ? res : 0) + LayerNorm(x) * w + b       (ViT post-norm residual, eva_vit.py:298-300)
+int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* res, bf16_t* y,
+                     int rows, int cols, float eps, hipStream_t s);
+int launch_embed_gather(const int32_t* ids, const bf16_t* table, bf16_t* out, int n_tok, int hidden, int vocab, hipStream_t s);
+// out[dst_rows[i], :] = src[i, :]
+int launch_scatter_rows(const bf16_t* src, const int32_t* dst_rows, bf16_t* out, int n_rows, int hidden, hipStream_t s);
+int launch_argmax(const bf16_t* logits, int ld, int rows, int vocab, int suppress_id, int32_t* out, hipStream_t s);
+// NCHW fp32/bf16 image -> [B*gh*gw, Kpad] bf16 patch matrix (k = c*p*p + i*p + j, zero padded to Kpad)
+int launch_patchify(const void* image, int image_is_f32, bf16_t* out, int B, int C, int HW, int p, int Kpad, hipStream_t s);
+// tokens [B, 1+g*g, C] (cls dropped) -> [B, (g/s)^2, C] average over s x s windows (emu.py:82-89)
+int launch_avgpool_tokens(const bf16_t* x, bf16_t* out, int B, int g, int C, int s, hipStream_t s_);
+// x[b, 0, :] = cls + pos[0]; x[b, 1+t, :] = patches[b, t, :] + pos[1+t]   (eva_vit.py:406-409)
+int launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int T, int C, hipStream_t s);
+
+// ---- attention (attention.hip)
+struct RopeKvArgs {
+    bf16_t* qkv;            // [B*T, 3*Hl*D] rows; q at col 0, k at Hl*D, v at 2*Hl*D  (q, k rotated in place)
+    const bf16_t* cos;      // [max_pos, D] bf16 (cat(freqs, freqs) layout)
+    const bf16_t* sin;
+    const int32_t* pos;     // [B*T] rope position of every row
+    const int32_t* slot;    // [B*T] kv-cache slot of every row (absolute index into S_max)
+    bf16_t* kcache;         // [B, Hl, S_max, D]
+    bf16_t* vcache;         // [B, Hl, S_max, D]
+    int B, T, Hl, D, S_max;
+};
+int launch_rope_kv(const RopeKvArgs& a, hipStream_t s);
+
+// Vt[b, h, d, s] = V[b, h, s, d] for s < S (zero for S <= s < S_pad); strided source
+struct TransposeVArgs {
+    const bf16_t* v; long v_sb, v_sh, v_ss;    // element strides (batch, head, token); d contiguous
+    bf16_t* vt;                                // [B, H, D, S_pad]
+    int B, H, S, D, S_pad;
+};
+int launch_transpose_v(const TransposeVArgs& a, hipStream_t s);
+
+struct FlashArgs {
+    const bf16_t* q; long q_sb, q_sh, q_ss;    // element strides; d contiguous
+    const bf16_t* k; long k_sb, k_sh, k_ss;
+    const bf16_t* vt;                          // [B, H, D, Sk_pad]
+    bf16_t* o; long o_sb, o_sh, o_ss;
+    const int32_t* kstart;                     // [B] or null: keys < kstart[b] are masked (left padding)
+    int B, H, Sq, Sk, Sk_pad, D;               // D in {64, 128}
+    int causal;                                // query i attends keys <= i + (Sk - Sq)
+    float scale;
+};
+int launch_flash_attn(const FlashArgs& a, hipStream_t s);
+
+struct DecodeAttnArgs {
+    const bf16_t* q; long q_sb, q_sh;          // [B, H, D] strided
+    const bf16_t* kcache;                      // [B, H, S_max, D]
+    const bf16_t* vcache;
+    bf16_t* o; long o_sb, o_sh;
+    const int32_t* kstart;                     // [B] or null
+    const int32_t* ctx_ptr;                    // device int32 or null: overrides ctx (graph replay)
+    float* ws;                                 // workspace: B*H*nsplit*(D+2) floats
+    int B, H, D, S_max, ctx;                   // keys [0, ctx) valid
+    int ctx_max;                               // sizes the launch (>= ctx); 0 -> ctx
+    float scale;
+};
+int decode_attn_nsplit(int ctx);
+// out_ids[step, b] = cur_ids[b]; pos[b]++, slot[b]++; ctx++, step++   (greedy loop state, all on device)
+int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, int32_t* ctx, int32_t* step,
+                          int32_t* out_ids, int B, hipStream_t s);
+int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);

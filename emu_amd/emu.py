@@ -1,0 +1,238 @@
+"""``EmuModel`` -- drop-in for the reference's ``Emu2/emu/emu.py:19-235`` on MI355X.
+
+Same constructor configs, attribute names, method names, keyword arguments, defaults and return types
+(``encode_image`` / ``generate`` / ``generate_image``), and the same state-dict keys
+(``visual.*``, ``decoder.lm.model.*``, ``decoder.lm.lm_head.weight``, ``project_up.weight``,
+``project_down.weight``).  All arithmetic runs in libemu_hip.so (hand-written gfx950 kernels); this file is
+host orchestration only.  ``generate_image`` uses the KV-cached formulation (1 prefill + n_query-1 cached steps)
+that is mathematically identical to the reference's 64 uncached forwards.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .conf.emu_conf import CLIPVisionCfg, LlamaCfg, TextDecoderCfg
+from .constants import *  # noqa: F401,F403  (re-exported like the reference module does)
+from .constants import (DEFAULT_gIMG_TOKEN, DEFAULT_IMAGE_TOKEN, DEFAULT_IMG_END_TOKEN, DEFAULT_IMG_PLACEHOLDER,
+                        DEFAULT_IMG_TOKEN, DEFAULT_VID_PLACEHOLDER, EOS_TOKEN_ID, IMAGE_TOKEN_ID, IMG_TOKEN_ID,
+                        PAD_TOKEN_ID, VOCAB_EMU2, VOCAB_EMU2_CHAT, gIMG_TOKEN_ID, special_tokens_list)
+from .llama import EmuHipContext, LlamaEngine
+
+BF16 = torch.bfloat16
+
+
+def build_tokenizer(llama_config_path: str, instruct: bool):
+    """LlamaTokenizer + the Emu special tokens, exactly as the reference builds it (Emu2/emu/lm.py:40-63).
+    Pure host logic; needs ``tokenizer.model`` in ``llama_config_path`` (ship it with the checkpoint)."""
+    import transformers
+    from .constants import DEFAULT_BOS_TOKEN, DEFAULT_EOS_TOKEN, DEFAULT_PAD_TOKEN
+    if not os.path.exists(os.path.join(llama_config_path, "tokenizer.model")):
+        raise FileNotFoundError(
+            f"no tokenizer.model under {llama_config_path!r}: point TextDecoderCfg.llama_config_path (or the "
+            "EMU_LLAMA_CONFIG environment variable) at the checkpoint's llama_config directory")
+    tok = transformers.LlamaTokenizer.from_pretrained(llama_config_path)
+    tok.add_special_tokens(dict(pad_token=DEFAULT_PAD_TOKEN, bos_token=DEFAULT_BOS_TOKEN, eos_token=DEFAULT_EOS_TOKEN,
+                                additional_special_tokens=special_tokens_list(instruct)))
+    tok.truncation_side = tok.padding_side = "left"          # emu.py:58
+    return tok
+
+
+class _Decoder:
+    """Stand-in for ``EmuForClsAndRegression`` (Emu2/emu/lm.py:30-102): exposes ``.lm`` and ``.tokenizer``."""
+
+    def __init__(self, lm: LlamaEngine, cfg: TextDecoderCfg):
+        self.lm = lm
+        self.args = cfg
+        self._tokenizer = None
+        self.image_token_id = IMAGE_TOKEN_ID
+        self.img_token_id = IMG_TOKEN_ID
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            path = os.environ.get("EMU_LLAMA_CONFIG", self.args.llama_config_path)
+            self._tokenizer = build_tokenizer(path, self.args.instruct)
+        return self._tokenizer
+
+    @tokenizer.setter
+    def tokenizer(self, tok):
+        self._tokenizer = tok
+
+    def get_num_layers(self):
+        return self.lm.cfg.num_hidden_layers
+
+
+class EmuModel:
+    def __init__(self, vision_cfg: CLIPVisionCfg = CLIPVisionCfg(), text_decoder_cfg: TextDecoderCfg = TextDecoderCfg(),
+                 *, llama_cfg: Optional[LlamaCfg] = None, device="cuda", tp_rank: int = 0, tp_size: int = 1,
+                 ctx: Optional[EmuHipContext] = None):
+        from .vit import VitEngine
+        self.vision_cfg, self.text_decoder_cfg = vision_cfg, text_decoder_cfg
+        if llama_cfg is None:
+            llama_cfg = LlamaCfg.from_json(text_decoder_cfg.llama_config_path)
+        self.llama_cfg = llama_cfg
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.ctx = ctx or EmuHipContext(dev, tp_rank, tp_size)
+        self.vocab = VOCAB_EMU2_CHAT if text_decoder_cfg.instruct else VOCAB_EMU2
+        self.visual = VitEngine(vision_cfg, self.ctx)
+        self.decoder = _Decoder(LlamaEngine(llama_cfg, self.vocab, self.ctx), text_decoder_cfg)
+        self.project_up: Optional[torch.Tensor] = None       # [hidden, width]   EVA -> LM   (emu.py:53)
+        self.project_down: Optional[torch.Tensor] = None     # [width, hidden]   LM -> EVA   (emu.py:55)
+        self.n_query = vision_cfg.n_query
+        self.v_query = vision_cfg.v_query
+        self.image_placeholder = DEFAULT_IMG_TOKEN + DEFAULT_IMAGE_TOKEN * self.n_query + DEFAULT_IMG_END_TOKEN
+        self.video_placeholder = DEFAULT_IMG_TOKEN + DEFAULT_gIMG_TOKEN * self.v_query + DEFAULT_IMG_END_TOKEN
+        self.use_graph = False
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def device(self, module=None):
+        return self.ctx.device
+
+    def dtype(self, module=None):
+        return BF16
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        return self.load_weights(state_dict.items(), strict=strict)
+
+    def load_weights(self, items: Iterable[Tuple[str, torch.Tensor]], strict: bool = True):
+        """Streaming loader (reference key names); tensors may live on CPU or GPU, any float dtype."""
+        unexpected = []
+        for name, t in items:
+            if name.startswith("visual."):
+                used = self.visual.load_tensor(name[len("visual."):], t)
+            elif name.startswith("decoder.lm."):
+                used = self.decoder.lm.load_tensor(name[len("decoder.lm."):], t)
+            elif name == "project_up.weight":
+                self.project_up, used = t.to(self.ctx.device, BF16).contiguous(), True
+            elif name == "project_down.weight":
+                self.project_down, used = t.to(self.ctx.device, BF16).contiguous(), True
+            else:
+                used = False
+            if not used and not name.endswith("rotary_emb.inv_freq"):
+                unexpected.append(name)
+        missing = []
+        if not self.visual.ready:
+            missing.append("visual.*")
+        if not self.decoder.lm.ready:
+            missing.append("decoder.lm.*")
+        if self.project_up is None:
+            missing.append("project_up.weight")
+        if self.project_down is None:
+            missing.append("project_down.weight")
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for EmuModel: missing {missing}, unexpected {unexpected}")
+        return missing, unexpected
+
+    # ------------------------------------------------------------------ encode_image (emu.py:77-90)
+    @torch.no_grad()
+    def encode_image(self, image: torch.Tensor, *, n_query=None):
+        n_query = n_query if n_query is not None else self.n_query
+        tokens = self.visual(image)                                   # [B, 1+g*g, C]
+        g = self.vision_cfg.grid
+        stride = int(g // (n_query ** 0.5))
+        return ops.avgpool_tokens(tokens, g, stride)                  # [B, n_query, C]
+
+    def _project(self, x2d: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        return ops.linear(x2d.contiguous(), w)
+
+    def _prompt_embeds(self, input_ids: torch.Tensor, image: Optional[torch.Tensor], n_query: Optional[int],
+                       token_id: int = IMAGE_TOKEN_ID, embeds: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """embed_tokens + masked overwrite of the <image> rows with project_up(encode_image) (emu.py:193-203)."""
+        lm = self.decoder.lm
+        B, S = input_ids.shape
+        x = lm.embed_tokens(input_ids).view(B * S, -1) if embeds is None else embeds
+        if image is not None:
+            e = self.encode_image(image, n_query=n_query)
+            e = self._project(e.view(-1, e.shape[-1]), self.project_up)
+            rows = torch.nonzero(input_ids.reshape(-1).to(self.ctx.device) == token_id).reshape(-1).to(torch.int32)
+            if rows.numel() != e.shape[0]:
+                raise ValueError(f"shape mismatch: {rows.numel()} image slots in the prompt cannot take "
+                                 f"{e.shape[0]} image embedding rows")
+            ops.scatter_rows(e, rows.contiguous(), x)
+        return x
+
+    # ------------------------------------------------------------------ generate (emu.py:155-235)
+    @torch.no_grad()
+    def generate_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, image: Optional[torch.Tensor] = None,
+                     video: Optional[torch.Tensor] = None, max_new_tokens: int = 10, min_len: int = 1,
+                     stop_on_eos: bool = True) -> torch.Tensor:
+        """Greedy ``generate`` at the token-id level: returns the NEW ids [B, n] (what HF returns for inputs_embeds)."""
+        B, S = input_ids.shape
+        x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
+        if video is not None:
+            x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
+        return self.decoder.lm.greedy_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len,
+                                               eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID, use_graph=self.use_graph,
+                                               stop_on_eos=stop_on_eos)
+
+    @torch.no_grad()
+    def generate(self, text: List[str], image: Optional[torch.Tensor] = None, video: Optional[torch.Tensor] = None,
+                 image_placeholder: str = DEFAULT_IMG_PLACEHOLDER, video_placeholder: str = DEFAULT_VID_PLACEHOLDER,
+                 num_beams=5, max_new_tokens=10, min_len=1, do_sample=False, penalty_alpha=None, top_p=None,
+                 top_k=None, temperature=None, length_penalty=-1, repetition_penalty=1.0, synced_gpus=False,
+                 skip_special_tokens=True, **kwargs):
+        if do_sample or penalty_alpha is not None or repetition_penalty != 1.0:
+            raise NotImplementedError("sampling / contrastive search / repetition penalty are not built yet "
+                                      "(SURVEY 8f row 3); use do_sample=False, repetition_penalty=1.0")
+        if num_beams != 1:
+            raise NotImplementedError("beam search is SURVEY 8f row 3 (next); call generate(..., num_beams=1)")
+        tok = self.decoder.tokenizer
+        text = [t.replace(image_placeholder, self.image_placeholder).replace(video_placeholder, self.video_placeholder)
+                for t in text]
+        inputs = tok(text, padding="longest", return_tensors="pt")
+        ids = self.generate_ids(inputs.input_ids, inputs.attention_mask, image, video, max_new_tokens, min_len)
+        return tok.batch_decode(ids.cpu(), skip_special_tokens=skip_special_tokens)
+
+    # ------------------------------------------------------------------ generate_image (emu.py:92-153)
+    @torch.no_grad()
+    def generate_image_ids(self, prompt_ids: torch.Tensor, image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Visual-embedding regression at the token-id level for rows of equal length (no padding):
+        prompt + [IMG] prefill, then n_query-1 cached steps with input project_up(project_down(h_prev))."""
+        lm = self.decoder.lm
+        B, S0 = prompt_ids.shape
+        ids = torch.cat((prompt_ids.to(torch.int64), torch.full((B, 1), IMG_TOKEN_ID, dtype=torch.int64)), dim=1)
+        S = S0 + 1
+        if S + self.n_query > lm.cfg.max_position_embeddings:
+            raise ValueError("prompt too long for generate_image")
+        x = self._prompt_embeds(ids, image, self.n_query, IMAGE_TOKEN_ID)
+        mask = torch.ones(B, S, dtype=torch.int64)
+        hidden, kstart, _ = lm.prefill(x.view(B, S, -1), mask, hf_generate_positions=False)
+        h = lm.final_norm_rows(hidden[:, -1, :].contiguous())
+        outs = [self._project(h, self.project_down)]                               # [B, width]
+        pos = torch.full((B,), S, device=self.ctx.device, dtype=torch.int32)
+        for j in range(self.n_query - 1):
+            xin = self._project(outs[-1], self.project_up)                        # [B, hidden]
+            hj = lm.decode_embeds(xin, pos, S + j, kstart)
+            pos = pos + 1
+            outs.append(self._project(lm.final_norm_rows(hj), self.project_down))
+        return torch.stack(outs, dim=1)                                            # [B, n_query, width]
+
+    @torch.no_grad()
+    def generate_image(self, text: List[str], image: Optional[torch.Tensor] = None,
+                       placeholder: str = DEFAULT_IMG_PLACEHOLDER):
+        tok = self.decoder.tokenizer
+        text = [t.replace(placeholder, self.image_placeholder) for t in text]
+        inputs = tok(text, padding="longest", return_tensors="pt")
+        if not bool(inputs.attention_mask.all()):
+            # the reference re-pads every iteration and calls lm.model without position_ids;
+            # rows of different length are therefore run one by one, which is what un-padded rows compute.
+            outs = []
+            for i, t in enumerate(text):
+                one = tok([t], return_tensors="pt").input_ids
+                img = None
+                if image is not None:
+                    n_img = [x.count(self.image_placeholder) for x in text]
+                    a = sum(n_img[:i])
+                    img = image[a:a + n_img[i]]
+                outs.append(self.generate_image_ids(one, img))
+            return torch.cat(outs, dim=0)
+        return self.generate_image_ids(inputs.input_ids, image)

@@ -1,0 +1,342 @@
+"""LLaMA decoder engine: host side of the ``emu_llama_*`` C ABI.
+
+Plays the role of ``transformers.LlamaForCausalLM`` inside the reference's ``EmuForClsAndRegression``
+(Emu2/emu/lm.py:30-40) for the calls the hot path makes: ``lm.model.embed_tokens`` (emu.py:119,193),
+``lm.model(inputs_embeds=...)`` (emu.py:133-138) and greedy ``lm.generate`` (emu.py:213-229).
+All arithmetic runs in libemu_hip.so; torch only owns the memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import LlamaCfgC, check, lib
+from .conf.emu_conf import LlamaCfg
+from .tp import ShardPlan
+
+BF16 = torch.bfloat16
+_LAYER_KEYS = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+               "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight",
+               "input_layernorm.weight", "post_attention_layernorm.weight")
+
+
+def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [max_pos, D] bf16 exactly as transformers' LlamaRotaryEmbedding builds them (fp32 math, cast)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(BF16).to(device).contiguous(), emb.sin().to(BF16).to(device).contiguous()
+
+
+class EmuHipContext:
+    """One per (process, device): owns the emu_ctx handle and, for tp_size > 1, the RCCL communicator."""
+
+    def __init__(self, device: torch.device, tp_rank: int = 0, tp_size: int = 1):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("emu_amd needs a GPU device (no CPU path)")
+        self.tp_rank, self.tp_size = tp_rank, tp_size
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        check(lib().emu_ctx_create(idx, tp_rank, tp_size, C.byref(h)), "emu_ctx_create")
+        self.handle = h
+
+    def init_tp(self, broadcast_bytes) -> None:
+        """Create the RCCL communicator.  ``broadcast_bytes(b: bytes|None) -> bytes`` must return rank 0's
+        128-byte unique id on every rank (e.g. via the torch.distributed store)."""
+        if self.tp_size == 1:
+            return
+        buf = (C.c_char * 128)()
+        if self.tp_rank == 0:
+            check(lib().emu_tp_unique_id(buf), "emu_tp_unique_id")
+            uid = broadcast_bytes(bytes(buf))
+        else:
+            uid = broadcast_bytes(None)
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        with torch.cuda.device(self.device):
+            check(lib().emu_tp_init(self.handle, buf), "emu_tp_init", self.handle)
+
+    def allreduce(self, t: torch.Tensor) -> torch.Tensor:
+        check(lib().emu_allreduce_bf16(self.handle, t.data_ptr(), t.numel(), ops.stream()), "emu_allreduce_bf16", self.handle)
+        return t
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().emu_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class LlamaEngine:
+    def __init__(self, cfg: LlamaCfg, vocab: int, ctx: EmuHipContext):
+        self.cfg, self.vocab, self.ctx = cfg, vocab, ctx
+        self.device = ctx.device
+        self.plan = ShardPlan(cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.intermediate_size,
+                              ctx.tp_size, ctx.tp_rank)
+        c = LlamaCfgC(cfg.hidden_size, self.plan.heads_local, cfg.head_dim, self.plan.ffn_local,
+                      cfg.num_hidden_layers, vocab, cfg.max_position_embeddings, cfg.rms_norm_eps)
+        h = C.c_void_p()
+        check(lib().emu_llama_create(ctx.handle, C.byref(c), C.byref(h)), "emu_llama_create", ctx.handle)
+        self.handle = h
+        self._keep: Dict[str, torch.Tensor] = {}          # packed weights (owned here, pointers held by the lib)
+        self._pending: Dict[int, Dict[str, torch.Tensor]] = {}
+        self.layers_loaded = 0
+        self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, self.device)
+        self.embed = self.final_norm = self.lm_head = None
+        self.kcache = self.vcache = None
+        self.kv_batch = self.s_max = 0
+        self._ws = None
+
+    # ------------------------------------------------------------------ weights
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(device=self.device, dtype=BF16).contiguous()
+
+    def load_tensor(self, name: str, t: torch.Tensor) -> bool:
+        """Consume one reference-named tensor (``model.layers.N...`` / ``model.embed_tokens.weight`` /
+        ``model.norm.weight`` / ``lm_head.weight``, i.e. keys relative to ``decoder.lm.``). Returns True if used."""
+        if name == "model.embed_tokens.weight":
+            self.embed = self._dev(t)
+        elif name == "model.norm.weight":
+            self.final_norm = self._dev(t)
+        elif name == "lm_head.weight":
+            self.lm_head = self._dev(t)
+        elif name.startswith("model.layers."):
+            rest = name[len("model.layers."):]
+            idx, key = rest.split(".", 1)
+            if key not in _LAYER_KEYS:
+                return False                                   # e.g. rotary_emb.inv_freq buffers of old checkpoints
+            d = self._pending.setdefault(int(idx), {})
+            d[key] = t
+            if len(d) == len(_LAYER_KEYS):
+                self._pack_layer(int(idx), self._pending.pop(int(idx)))
+        else:
+            return False
+        if self.embed is not None and self.final_norm is not None and self.lm_head is not None:
+            check(lib().emu_llama_set_head(self.handle, self.final_norm.data_ptr(), self.lm_head.data_ptr(),
+                                           self.embed.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()),
+                  "emu_llama_set_head")
+        return True
+
+    def _pack_layer(self, i: int, d: Dict[str, torch.Tensor]) -> None:
+        g = lambda k: d[k].to(device=self.device, dtype=BF16)
+        p = self.plan.pack_layer(g("self_attn.q_proj.weight"), g("self_attn.k_proj.weight"),
+                                 g("self_attn.v_proj.weight"), g("self_attn.o_proj.weight"),
+                                 g("mlp.gate_proj.weight"), g("mlp.up_proj.weight"), g("mlp.down_proj.weight"))
+        p["ln1"] = self._dev(d["input_layernorm.weight"])
+        p["ln2"] = self._dev(d["post_attention_layernorm.weight"])
+        for k, v in p.items():
+            self._keep[f"{i}.{k}"] = v
+        check(lib().emu_llama_set_layer(self.handle, i, p["wqkv"].data_ptr(), p["wo"].data_ptr(), p["wgu"].data_ptr(),
+                                        p["wdown"].data_ptr(), p["ln1"].data_ptr(), p["ln2"].data_ptr()),
+              "emu_llama_set_layer")
+        self.layers_loaded += 1
+
+    def load_weights(self, items: Iterable[Tuple[str, torch.Tensor]], prefix: str = "decoder.lm.") -> None:
+        for name, t in items:
+            if name.startswith(prefix):
+                self.load_tensor(name[len(prefix):], t)
+
+    @property
+    def ready(self) -> bool:
+        return (self.layers_loaded == self.cfg.num_hidden_layers and self.embed is not None
+                and self.final_norm is not None and self.lm_head is not None)
+
+    def weight_bytes_per_token(self) -> int:
+        """Algorithmic bytes one decode step of THIS shard must stream (all packed matrices once + lm_head)."""
+        per = sum(v.numel() * 2 for k, v in self._keep.items() if k.split(".")[1] in ("wqkv", "wo", "wgu", "wdown"))
+        return per + (self.lm_head.numel() * 2 if self.lm_head is not None else 0)
+
+    # ------------------------------------------------------------------ KV cache / workspace
+    def alloc_kv(self, batch: int, s_max: int) -> None:
+        if batch == self.kv_batch and s_max == self.s_max and self.kcache is not None:
+            return
+        L, Hl, D = self.cfg.num_hidden_layers, self.plan.heads_local, self.cfg.head_dim
+        self.kcache = torch.zeros(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
+        self.vcache = torch.zeros(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
+        self.kv_batch, self.s_max = batch, s_max
+        check(lib().emu_llama_set_kv(self.handle, self.kcache.data_ptr(), self.vcache.data_ptr(), batch, s_max),
+              "emu_llama_set_kv")
+        self._ws = None
+
+    def _workspace(self, B: int, T: int) -> torch.Tensor:
+        need = lib().emu_llama_workspace_bytes(self.handle, B, T)
+        need = max(need, B * T * self.cfg.hidden_size * 2)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        return self._ws
+
+    # ------------------------------------------------------------------ forward
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        """lm.model.embed_tokens (emu.py:119,193): ids [..] -> [.., hidden] bf16."""
+        flat = ids.reshape(-1).to(device=self.device, dtype=torch.int32).contiguous()
+        return ops.embed_gather(flat, self.embed).view(*ids.shape, self.cfg.hidden_size)
+
+    def forward(self, hidden: torch.Tensor, B: int, T: int, pos: torch.Tensor, slot: torch.Tensor,
+                kstart: Optional[torch.Tensor], ctx: int, ctx_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """All decoder layers in place on the residual stream ``hidden`` [B*T, hidden] (not final-normed)."""
+        assert hidden.is_contiguous() and hidden.dtype == BF16 and hidden.shape == (B * T, self.cfg.hidden_size)
+        ws = self._workspace(B, T)
+        check(lib().emu_llama_forward(self.handle, hidden.data_ptr(), B, T, pos.data_ptr(), slot.data_ptr(),
+                                      ops._p(kstart), ops._p(ctx_dev), ctx, ws.data_ptr(), ws.numel(), ops.stream()),
+              "emu_llama_forward", self.ctx.handle)
+        return hidden
+
+    def final_norm_rows(self, hidden: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(hidden)
+        check(lib().emu_llama_final_norm(self.handle, hidden.data_ptr(), out.data_ptr(), hidden.shape[0], ops.stream()),
+              "emu_llama_final_norm")
+        return out
+
+    def logits(self, hidden_rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """final RMSNorm + lm_head on rows [M, hidden] -> [M, vocab] bf16."""
+        M = hidden_rows.shape[0]
+        if out is None:
+            out = torch.empty(M, self.vocab, device=self.device, dtype=BF16)
+        ws = self._workspace(max(M, 1), 1)
+        check(lib().emu_llama_logits(self.handle, hidden_rows.data_ptr(), hidden_rows.stride(0), M, out.data_ptr(),
+                                     out.stride(0), ws.data_ptr(), ws.numel(), ops.stream()),
+              "emu_llama_logits", self.ctx.handle)
+        return out
+
+    # ------------------------------------------------------------------ model-level calls
+    def prefill(self, embeds: torch.Tensor, attention_mask: torch.Tensor, s_max: Optional[int] = None,
+                hf_generate_positions: bool = True):
+        """Run S prompt slots through all layers and fill the KV cache.
+
+        ``embeds`` [B,S,hidden] bf16, ``attention_mask`` [B,S] (1 = real token, left padded).
+        ``hf_generate_positions``: position_ids = cumsum(mask)-1 as ``lm.generate`` does; False = arange(S) as the
+        bare ``lm.model(...)`` call of generate_image does (emu.py:133-138).
+        Returns (hidden [B,S,hidden] residual stream, kstart [B] int32, next_pos [B] int32)."""
+        B, S, H = embeds.shape
+        am = attention_mask.to(device=self.device, dtype=torch.int64)
+        n_real = am.sum(dim=1)
+        self.alloc_kv(B, s_max or self.cfg.max_position_embeddings)
+        if S > self.s_max:
+            raise ValueError(f"prompt length {S} exceeds KV capacity {self.s_max}")
+        if hf_generate_positions:
+            pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+            next_pos = n_real
+        else:
+            pos = torch.arange(S, device=self.device)[None].expand(B, -1)
+            next_pos = torch.full((B,), S, device=self.device)
+        slot = torch.arange(S, device=self.device)[None].expand(B, -1)
+        kstart = (S - n_real).to(torch.int32).contiguous()
+        hidden = embeds.to(device=self.device, dtype=BF16).reshape(B * S, H).contiguous().clone()
+        self.forward(hidden, B, S, pos.reshape(-1).to(torch.int32).contiguous(),
+                     slot.reshape(-1).to(torch.int32).contiguous(), kstart, ctx=S)
+        return hidden.view(B, S, H), kstart, next_pos.to(torch.int32).contiguous()
+
+    def decode_embeds(self, x: torch.Tensor, pos: torch.Tensor, slot_idx: int, kstart: torch.Tensor) -> torch.Tensor:
+        """One cached step on explicit input embeddings x [B, hidden] (used by generate_image)."""
+        B = x.shape[0]
+        hidden = x.to(BF16).contiguous().clone()
+        slot = torch.full((B,), slot_idx, device=self.device, dtype=torch.int32)
+        self.forward(hidden, B, 1, pos, slot, kstart, ctx=slot_idx + 1)
+        return hidden
+
+    @torch.no_grad()
+    def greedy_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int,
+                        min_len: int = 1, eos_id: int = 2, pad_id: int = 32000, use_graph: bool = False,
+                        stop_on_eos: bool = True) -> torch.Tensor:
+        """``lm.generate(inputs_embeds=..., num_beams=1, do_sample=False)`` (emu.py:213-229): returns only the
+        new ids [B, n].  The whole token loop stays on the device (embed -> layers -> logits -> argmax ->
+        state advance per step, optionally replayed from one hipGraph); EOS/PAD bookkeeping of finished rows is
+        applied afterwards on the host, which is equivalent because rows never interact."""
+        B, S, H = embeds.shape
+        s_max = self.cfg.max_position_embeddings
+        if S + max_new_tokens > s_max:
+            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
+        last = hidden[:, -1, :]
+        logits = torch.empty(B, self.vocab, device=self.device, dtype=BF16)
+        self.logits(last, out=logits)
+        cur = ops.argmax(logits, suppress_id=eos_id if min_len >= 1 else -1)
+        out_ids = torch.full((max_new_tokens, B), pad_id, device=self.device, dtype=torch.int32)
+        out_ids[0] = cur
+        if max_new_tokens > 1:
+            st = GreedyState(self, B, cur, next_pos, S, kstart, out_ids)
+            n_eager = max(0, min_len - 1)
+            steps = max_new_tokens - 1
+            for i in range(steps):
+                suppress = eos_id if i < n_eager else -1
+                if suppress >= 0:
+                    st.step_eager_suppress(suppress)
+                elif use_graph:
+                    st.step_graph()
+                else:
+                    st.step()
+        ids = out_ids.t().to(torch.int64)                       # [B, max_new]
+        if not stop_on_eos:
+            return ids
+        return apply_eos_padding(ids, eos_id, pad_id)
+
+
+def apply_eos_padding(ids: torch.Tensor, eos_id: int, pad_id: int) -> torch.Tensor:
+    """HF greedy bookkeeping: after a row emits EOS it emits PAD; generation stops once every row is finished."""
+    ids = ids.clone()
+    B, n = ids.shape
+    is_eos = ids == eos_id
+    first = torch.where(is_eos.any(dim=1), is_eos.float().argmax(dim=1), torch.full((B,), n, device=ids.device))
+    ar = torch.arange(n, device=ids.device)[None]
+    ids[ar > first[:, None]] = pad_id
+    keep = int(min(n, int(first.max().item()) + 1))
+    return ids[:, :keep]
+
+
+class GreedyState:
+    """Device-resident state of the greedy token loop (see emu_llama_greedy_step)."""
+
+    def __init__(self, eng: LlamaEngine, B: int, first_ids: torch.Tensor, next_pos: torch.Tensor, S: int,
+                 kstart: torch.Tensor, out_ids: torch.Tensor):
+        self.eng, self.B = eng, B
+        dev = eng.device
+        self.cur = first_ids.to(torch.int32).clone()
+        self.pos = next_pos.to(torch.int32).clone()
+        self.slot = torch.full((B,), S, device=dev, dtype=torch.int32)
+        self.ctx = torch.tensor([S + 1], device=dev, dtype=torch.int32)
+        self.step_idx = torch.tensor([1], device=dev, dtype=torch.int32)   # out_ids[0] already holds first_ids
+        self.kstart = kstart
+        self.out_ids = out_ids
+        self.hidden = torch.empty(B, eng.cfg.hidden_size, device=dev, dtype=BF16)
+        self.logits = torch.empty(B, eng.vocab, device=dev, dtype=BF16)
+        self.ws = eng._workspace(B, 1)
+        self.graph = None
+
+    def step(self) -> None:
+        e = self.eng
+        check(lib().emu_llama_greedy_step(e.handle, self.B, self.cur.data_ptr(), self.pos.data_ptr(),
+                                          self.slot.data_ptr(), self.kstart.data_ptr(), self.ctx.data_ptr(),
+                                          self.step_idx.data_ptr(), self.out_ids.data_ptr(), e.s_max,
+                                          self.hidden.data_ptr(), self.logits.data_ptr(), self.logits.stride(0),
+                                          self.ws.data_ptr(), self.ws.numel(), ops.stream()),
+              "emu_llama_greedy_step", e.ctx.handle)
+
+    def step_graph(self) -> None:
+        """Replay the step from a hipGraph captured on first use (launch-bound at TP>1: ~550 launches/token)."""
+        if self.graph is None:
+            self.step()                                   # warm-up outside capture (lazy module loads)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self.graph = g
+            return                                        # capture does not execute: state advanced once by warm-up...
+        self.graph.replay()
+
+    def step_eager_suppress(self, suppress: int) -> None:
+        """A step with a suppressed id (min_length > 1): same as step() but argmax masks ``suppress``."""
+        e = self.eng
+        ops.embed_gather(self.cur, e.embed, out=self.hidden)
+        e.forward(self.hidden, self.B, 1, self.pos, self.slot, self.kstart, ctx=e.s_max, ctx_dev=self.ctx)
+        e.logits(self.hidden, out=self.logits)
+        ops.argmax(self.logits, suppress_id=suppress, out=self.cur)
+        st = int(self.step_idx.item())
+        self.out_ids[st] = self.cur
+        self.pos += 1
+        self.slot += 1
+        self.ctx += 1
+        self.step_idx += 1

@@ -1,0 +1,157 @@
+"""Tensor-level wrappers of the primitive C-ABI operators (include/emu_hip.h).
+
+PyTorch is only the allocator/stream provider here: every function hands raw device pointers of bf16 CUDA
+(ROCm) tensors to libemu_hip.so on torch's current stream.  No function has a torch fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import check, lib
+
+EPI_NONE, EPI_RESID, EPI_SWIGLU, EPI_SILU, EPI_GELU, EPI_GEGLU = range(6)
+BF16 = torch.bfloat16
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str, dtype=BF16):
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor (emu_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name} must be contiguous in its last dimension")
+
+
+def linear(x, w, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = EPI_NONE, out=None):
+    """out[m, n] = epi(sum_k x[m, k] w[n, k] + bias[n]); see emu_linear_bf16."""
+    _req(x, "x"); _req(w, "w")
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], (x.shape, w.shape)
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epi in (EPI_SWIGLU, EPI_GEGLU) else N
+    if out is None:
+        out = torch.empty(M, n_out, device=x.device, dtype=BF16)
+    _req(out, "out")
+    if res is not None:
+        _req(res, "res")
+    check(lib().emu_linear_bf16(_p(x), _p(w), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K,
+                                x.stride(0), w.stride(0), res.stride(0) if res is not None else 0,
+                                out.stride(0), float(eps), int(epi), stream()), "emu_linear_bf16")
+    return out
+
+
+def rmsnorm(x, w, eps: float, out=None):
+    _req(x, "x"); _req(w, "w")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().emu_rmsnorm_bf16(_p(x), _p(w), _p(out), rows, cols, x.stride(0), out.stride(0), float(eps), stream()),
+          "emu_rmsnorm_bf16")
+    return out
+
+
+def layernorm(x, w, b, eps: float, res=None, out=None):
+    _req(x, "x")
+    assert x.is_contiguous()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().emu_layernorm_bf16(_p(x), _p(w), _p(b), _p(res), _p(out), rows, cols, float(eps), stream()),
+          "emu_layernorm_bf16")
+    return out
+
+
+def embed_gather(ids, table, out=None):
+    _req(ids, "ids", torch.int32); _req(table, "table")
+    n = ids.numel()
+    if out is None:
+        out = torch.empty(n, table.shape[1], device=table.device, dtype=BF16)
+    check(lib().emu_embed_gather_bf16(_p(ids), _p(table), _p(out), n, table.shape[1], table.shape[0], stream()),
+          "emu_embed_gather_bf16")
+    return out
+
+
+def scatter_rows(src, dst_rows, out):
+    _req(src, "src"); _req(dst_rows, "dst_rows", torch.int32); _req(out, "out")
+    assert src.is_contiguous() and out.is_contiguous() and src.shape[0] == dst_rows.numel()
+    check(lib().emu_scatter_rows_bf16(_p(src), _p(dst_rows), _p(out), src.shape[0], src.shape[1], stream()),
+          "emu_scatter_rows_bf16")
+    return out
+
+
+def argmax(logits, vocab: Optional[int] = None, suppress_id: int = -1, out=None):
+    _req(logits, "logits")
+    rows = logits.shape[0]
+    vocab = logits.shape[1] if vocab is None else vocab
+    if out is None:
+        out = torch.empty(rows, device=logits.device, dtype=torch.int32)
+    check(lib().emu_argmax_bf16(_p(logits), logits.stride(0), rows, vocab, suppress_id, _p(out), stream()),
+          "emu_argmax_bf16")
+    return out
+
+
+def avgpool_tokens(x, grid: int, stride: int):
+    """x [B, 1+grid*grid, C] -> [B, (grid/stride)^2, C] (cls dropped)."""
+    _req(x, "x")
+    assert x.is_contiguous()
+    B, _, Cc = x.shape
+    go = grid // stride
+    out = torch.empty(B, go * go, Cc, device=x.device, dtype=BF16)
+    check(lib().emu_avgpool_tokens_bf16(_p(x), _p(out), B, grid, Cc, stride, stream()), "emu_avgpool_tokens_bf16")
+    return out
+
+
+def rope_kv_append(qkv, cos, sin, pos, slot, kcache, vcache, B: int, T: int, H: int, D: int):
+    _req(qkv, "qkv"); _req(kcache, "kcache"); _req(vcache, "vcache")
+    _req(pos, "pos", torch.int32); _req(slot, "slot", torch.int32)
+    assert qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
+    S_max = kcache.shape[-2]
+    check(lib().emu_rope_kv_append_bf16(_p(qkv), _p(cos), _p(sin), _p(pos), _p(slot), _p(kcache), _p(vcache),
+                                        B, T, H, D, S_max, stream()), "emu_rope_kv_append_bf16")
+
+
+def transpose_v(v, B: int, H: int, S: int, D: int, sb: int, sh: int, ss: int, S_pad: Optional[int] = None):
+    _req(v, "v")
+    S_pad = (S + 63) // 64 * 64 if S_pad is None else S_pad
+    vt = torch.empty(B, H, D, S_pad, device=v.device, dtype=BF16)
+    check(lib().emu_transpose_v_bf16(_p(v), sb, sh, ss, _p(vt), B, H, S, D, S_pad, stream()), "emu_transpose_v_bf16")
+    return vt
+
+
+def flash_attn(q, k, v, causal: bool, scale: float, kstart=None):
+    """q [B,Sq,H,D], k/v [B,Sk,H,D] (any strides with D contiguous) -> o [B,Sq,H,D]."""
+    _req(q, "q"); _req(k, "k"); _req(v, "v")
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    vt = transpose_v(v, B, H, Sk, D, v.stride(0), v.stride(2), v.stride(1))
+    o = torch.empty(B, Sq, H, D, device=q.device, dtype=BF16)
+    check(lib().emu_flash_attn_bf16(_p(q), q.stride(0), q.stride(2), q.stride(1),
+                                    _p(k), k.stride(0), k.stride(2), k.stride(1), _p(vt),
+                                    _p(o), o.stride(0), o.stride(2), o.stride(1), _p(kstart),
+                                    B, H, Sq, Sk, vt.shape[-1], D, int(causal), float(scale), stream()),
+          "emu_flash_attn_bf16")
+    return o
+
+
+def decode_attn(q, kcache, vcache, ctx: int, scale: float, kstart=None, ctx_dev=None, ctx_max: int = 0):
+    """q [B,H,D]; caches [B,H,S_max,D] -> o [B,H,D]."""
+    _req(q, "q"); _req(kcache, "kcache"); _req(vcache, "vcache")
+    B, H, D = q.shape
+    S_max = kcache.shape[-2]
+    ws = torch.empty(lib().emu_decode_attn_ws_bytes(B, H, D, max(ctx, ctx_max)) // 4, device=q.device,
+                     dtype=torch.float32)
+    o = torch.empty(B, H, D, device=q.device, dtype=BF16)
+    check(lib().emu_decode_attn_bf16(_p(q), q.stride(0), q.stride(1), _p(kcache), _p(vcache), _p(o), o.stride(0),
+                                     o.stride(1), _p(kstart), _p(ctx_dev), ctx, ctx_max, _p(ws), B, H, D, S_max,
+                                     float(scale), stream()), "emu_decode_attn_bf16")
+    return o

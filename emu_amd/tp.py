@@ -1,0 +1,80 @@
+"""Tensor-parallel shard plan of the LLaMA decoder (one process per GPU, RCCL all-reduce over xGMI).
+
+New design: the reference's only multi-GPU scheme is whole-layer placement (Emu2/emu/chat.py:235-283,
+Emu2/emu/mixin.py:14-85), which keeps one GPU busy at a time.  Here q/k/v and gate/up are column-sharded,
+o_proj and down_proj row-sharded, and the two partial sums per layer are all-reduced.
+
+LLaMA-33B has 52 heads, which 8 does not divide: heads are padded to ``heads_pad = ceil(H / tp) * tp``
+(56 for tp=8); the extra heads have all-zero q/k/v rows and all-zero o_proj columns, so they contribute
+exactly 0 to the output.  ffn (17920 = 8 * 2240) must divide evenly.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    hidden: int
+    heads: int
+    head_dim: int
+    ffn: int
+    tp_size: int
+    tp_rank: int
+
+    def __post_init__(self):
+        if not (0 <= self.tp_rank < self.tp_size):
+            raise ValueError("tp_rank out of range")
+        if self.ffn % self.tp_size or (self.ffn // self.tp_size) % 8:
+            raise ValueError(f"intermediate size {self.ffn} cannot be split into {self.tp_size} shards of a multiple of 8")
+
+    @property
+    def heads_pad(self) -> int:
+        return -(-self.heads // self.tp_size) * self.tp_size
+
+    @property
+    def heads_local(self) -> int:
+        return self.heads_pad // self.tp_size
+
+    @property
+    def ffn_local(self) -> int:
+        return self.ffn // self.tp_size
+
+    @property
+    def head_range(self):
+        """Global head indices [h0, h1) owned by this rank (indices >= heads are zero padding)."""
+        h0 = self.tp_rank * self.heads_local
+        return h0, h0 + self.heads_local
+
+    @property
+    def ffn_range(self):
+        f0 = self.tp_rank * self.ffn_local
+        return f0, f0 + self.ffn_local
+
+    # ---- packing ------------------------------------------------------------------------------------
+    def _head_rows(self, w: torch.Tensor) -> torch.Tensor:
+        """Rows of a [H*D, hidden] projection that belong to this rank's heads, zero rows for padding."""
+        D = self.head_dim
+        h0, h1 = self.head_range
+        real = max(0, min(h1, self.heads) - h0)
+        out = w.new_zeros(self.heads_local * D, w.shape[1])
+        if real > 0:
+            out[: real * D] = w[h0 * D:(h0 + real) * D]
+        return out
+
+    def pack_layer(self, q, k, v, o, gate, up, down) -> Dict[str, torch.Tensor]:
+        """Reference tensors (transformers LlamaDecoderLayer names) -> packed shard tensors of emu_hip.h."""
+        D = self.head_dim
+        wqkv = torch.cat([self._head_rows(q), self._head_rows(k), self._head_rows(v)], dim=0).contiguous()
+        h0, h1 = self.head_range
+        real = max(0, min(h1, self.heads) - h0)
+        wo = o.new_zeros(o.shape[0], self.heads_local * D)
+        if real > 0:
+            wo[:, : real * D] = o[:, h0 * D:(h0 + real) * D]
+        f0, f1 = self.ffn_range
+        wgu = torch.stack([gate[f0:f1], up[f0:f1]], dim=1).reshape(2 * self.ffn_local, gate.shape[1]).contiguous()
+        wdown = down[:, f0:f1].contiguous()
+        return {"wqkv": wqkv, "wo": wo.contiguous(), "wgu": wgu, "wdown": wdown}

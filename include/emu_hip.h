@@ -1,0 +1,166 @@
+/* emu_hip.h -- C ABI of libemu_hip.so, the MI355X (gfx950) compute library behind emu_amd.
+ *
+ * The reference (baaivision/Emu, Emu2/) has no FFI layer: its hot path is Python calling torch /
+ * transformers / diffusers ops.  This header is the operator interface those call sites bind to when the
+ * arithmetic is replaced by hand-written HIP kernels; every entry cites the reference lines it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *  - plain C symbols, raw device pointers + sizes, no torch types; bf16 tensors are `uint16_t` bit patterns,
+ *    row-major, innermost dimension contiguous; all "ld*"/stride arguments are in ELEMENTS.
+ *  - every launch takes an explicit HIP stream (`emu_stream_t` = hipStream_t) and is asynchronous;
+ *    nothing here allocates, frees or synchronises device memory (hipGraph / stream-capture safe).
+ *  - return value: 0 = OK, negative = -errno style (-22 = EINVAL: unsupported shape/alignment),
+ *    positive = hipError_t / ncclResult_t (offset by 1000) of the failing runtime call.
+ *  - one context per (process, device); thread-compatible, not thread-safe per context.
+ *  - the caller owns all tensors (e.g. torch allocator); the library owns only its small host-side tables.
+ */
+#ifndef EMU_HIP_H
+#define EMU_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* emu_stream_t;
+typedef struct emu_ctx emu_ctx;
+typedef struct emu_llama emu_llama;
+typedef struct emu_vit emu_vit;
+
+enum { EMU_EPI_NONE = 0, EMU_EPI_RESID = 1, EMU_EPI_SWIGLU = 2, EMU_EPI_SILU = 3, EMU_EPI_GELU = 4, EMU_EPI_GEGLU = 5 };
+
+/* ---- context / tensor-parallel communicator ------------------------------------------------------------
+ * Replaces the reference's layer-placement "model parallel" (Emu2/emu/mixin.py:14-85, chat.py:235-283): the
+ * decoder is tensor-parallel, one process per GPU, partial sums exchanged with RCCL all-reduce over xGMI. */
+int emu_version(void);
+int emu_ctx_create(int device, int tp_rank, int tp_size, emu_ctx** out);
+void emu_ctx_destroy(emu_ctx* ctx);
+const char* emu_last_error(const emu_ctx* ctx);
+int emu_tp_unique_id(void* out128);                      /* rank 0: 128-byte RCCL unique id           */
+int emu_tp_init(emu_ctx* ctx, const void* id128);        /* all ranks: ncclCommInitRank               */
+int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);   /* in-place sum          */
+
+/* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while
+ * enabled (eager launches only, not inside stream capture).  read: sum of launch durations (ms), algorithmic
+ * weight bytes (2*N*K per launch) and launch count since the last enable. */
+int emu_profile_gemv(int enable);
+int emu_profile_gemv_read(double* total_ms, double* weight_bytes, long* launches);
+
+/* ---- primitive operators -------------------------------------------------------------------------------*/
+/* torch.nn.functional.linear on the hot path (eva_vit.py:106,112,198,250; LlamaAttention/LlamaMLP linears
+ * reached from emu.py:133-138,213-229; project_up/down emu.py:53,55,131,147,201).
+ * C[m,n] = epi(sum_k A[m,k] W[n,k] (+bias[n])).  M <= 8 streams W once (HBM-bound GEMV, optional fused
+ * LLaMA RMSNorm of A via norm_w/eps); M > 8 runs the MFMA GEMM (norm_w must be NULL).
+ * EPI_RESID: C = bf16(res + bf16(.)).  EPI_SWIGLU/GEGLU: W rows interleaved (2j, 2j+1), C has N/2 columns. */
+int emu_linear_bf16(const void* A, const void* W, const void* bias, const void* res, const void* norm_w,
+                    void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi,
+                    emu_stream_t s);
+/* LlamaRMSNorm (transformers; emu.py:133-138): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) */
+int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, int ldx, int ldy, float eps,
+                     emu_stream_t s);
+/* nn.LayerNorm + post-norm residual (eva_vit.py:298-300): y = (res ? res + : ) bf16(LN(x) * w + b) */
+int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* res, void* y, int rows,
+                       int cols, float eps, emu_stream_t s);
+/* embed_tokens (emu.py:119,193) and the masked row overwrite text_embeds[ids == IMAGE] = ... (emu.py:202-203) */
+int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab,
+                          emu_stream_t s);
+int emu_scatter_rows_bf16(const void* src, const int32_t* dst_rows, void* out, int n_rows, int hidden,
+                          emu_stream_t s);
+/* greedy next-token selection of lm.generate(num_beams=1, do_sample=False) (emu.py:213-229); suppress_id =
+ * EOS while fewer than min_length tokens exist, else -1.  First index wins ties. */
+int emu_argmax_bf16(const void* logits, int ld, int rows, int vocab, int suppress_id, int32_t* out,
+                    emu_stream_t s);
+/* PatchEmbed conv as im2col (eva_vit.py:327-335): image NCHW (fp32 or bf16) -> [B*g*g, Kpad] bf16 */
+int emu_patchify(const void* image, int image_is_f32, void* out, int B, int C, int HW, int patch, int Kpad,
+                 emu_stream_t s);
+/* cat(cls, patches) + pos_embed (eva_vit.py:406-409) */
+int emu_vit_assemble_bf16(const void* patches, const void* cls, const void* pos, void* x, int B, int T, int C,
+                          emu_stream_t s);
+/* encode_image pooling (emu.py:82-89): tokens [B, 1+g*g, C] -> [B, (g/s)^2, C] */
+int emu_avgpool_tokens_bf16(const void* x, void* out, int B, int g, int C, int stride, emu_stream_t s);
+/* apply_rotary_pos_emb on q,k in place + KV-cache append (transformers LlamaAttention; emu.py:213-229).
+ * qkv rows [B*T, 3*H*D] (q | k | v); cos/sin tables [max_pos, D] bf16; caches [B, H, S_max, D]. */
+int emu_rope_kv_append_bf16(void* qkv, const void* cos, const void* sin, const int32_t* pos,
+                            const int32_t* slot, void* kcache, void* vcache, int B, int T, int H, int D,
+                            int S_max, emu_stream_t s);
+/* Vt[b,h,d,s] = V[b,h,s,d], zero padded to S_pad (multiple of 64) */
+int emu_transpose_v_bf16(const void* v, long v_sb, long v_sh, long v_ss, void* vt, int B, int H, int S, int D,
+                         int S_pad, emu_stream_t s);
+/* softmax(Q K^T * scale + causal/left-pad mask) V, fused (LlamaAttention prefill; eva_vit.py:227-248;
+ * diffusers attention).  D in {64, 128}.  kstart[b]: keys < kstart[b] masked (left padding), may be NULL. */
+int emu_flash_attn_bf16(const void* q, long q_sb, long q_sh, long q_ss, const void* k, long k_sb, long k_sh,
+                        long k_ss, const void* vt, void* o, long o_sb, long o_sh, long o_ss,
+                        const int32_t* kstart, int B, int H, int Sq, int Sk, int Sk_pad, int D, int causal,
+                        float scale, emu_stream_t s);
+/* one-query attention over the KV cache (decode step).  ctx_dev (device int32, may be NULL) overrides ctx so a
+ * captured graph can be replayed while the context grows; ctx_max sizes the launch. */
+size_t emu_decode_attn_ws_bytes(int B, int H, int D, int ctx_max);
+int emu_decode_attn_bf16(const void* q, long q_sb, long q_sh, const void* kcache, const void* vcache, void* o,
+                         long o_sb, long o_sh, const int32_t* kstart, const int32_t* ctx_dev, int ctx,
+                         int ctx_max, void* ws, int B, int H, int D, int S_max, float scale, emu_stream_t s);
+
+/* ---- LLaMA decoder engine ------------------------------------------------------------------------------
+ * transformers LlamaModel / LlamaForCausalLM as used by EmuModel.generate / generate_image
+ * (emu.py:133-138, 213-229).  Weights are passed as raw pointers to PACKED tensors (see emu_amd/llama.py):
+ *   wqkv  [3*Hl*D, hidden]   rows = q heads | k heads | v heads of this TP shard
+ *   wo    [hidden, Hl*D]
+ *   wgu   [2*Fl, hidden]     gate/up interleaved: row 2j = gate_j, row 2j+1 = up_j
+ *   wdown [hidden, Fl]
+ * KV cache: [layers, B, Hl, S_max, D] for K and V. */
+typedef struct {
+    int hidden, heads_local, head_dim, ffn_local, layers, vocab, max_pos;
+    float rms_eps;
+} emu_llama_cfg;
+int emu_llama_create(emu_ctx* ctx, const emu_llama_cfg* cfg, emu_llama** out);
+void emu_llama_destroy(emu_llama* m);
+int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* wo, const void* wgu,
+                        const void* wdown, const void* ln1, const void* ln2);
+int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed,
+                       const void* rope_cos, const void* rope_sin);
+int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max);
+size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
+/* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
+ * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).
+ * pos/slot: device int32 [B*T] (RoPE position / cache slot per row); kstart: device int32 [B] or NULL;
+ * ctx_dev: device int32 [1] = number of valid cache slots AFTER this call (decode only, may be NULL);
+ * ctx: the same value on the host (exact for prefill; upper bound used when ctx_dev is given). */
+int emu_llama_forward(emu_llama* m, void* hidden, int B, int T, const int32_t* pos, const int32_t* slot,
+                      const int32_t* kstart, const int32_t* ctx_dev, int ctx, void* workspace, size_t ws_bytes,
+                      emu_stream_t s);
+/* final RMSNorm (+ lm_head): rows [M, hidden] -> normed [M, hidden] / logits [M, ld] */
+int emu_llama_final_norm(emu_llama* m, const void* hidden, void* out, int rows, emu_stream_t s);
+int emu_llama_logits(emu_llama* m, const void* hidden, int ldh, int M, void* logits, int ld, void* workspace,
+                     size_t ws_bytes, emu_stream_t s);
+/* one greedy decode step entirely on the device (graph-capturable): embed(cur_ids) -> layers -> logits ->
+ * argmax -> out_ids[step_dev[0], :] = cur_ids = next; pos/slot/ctx/step advance by one.
+ * state: device int32 arrays cur_ids[B], pos[B], slot[B], ctx[1], step[1]; out_ids [max_new, B]. */
+int emu_llama_greedy_step(emu_llama* m, int B, int32_t* cur_ids, int32_t* pos, int32_t* slot,
+                          const int32_t* kstart, int32_t* ctx_dev, int32_t* step_dev, int32_t* out_ids,
+                          int ctx_upper, void* hidden, void* logits, int ld_logits, void* workspace,
+                          size_t ws_bytes, emu_stream_t s);
+
+/* ---- EVA-CLIP ViT engine -------------------------------------------------------------------------------
+ * EVAVisionTransformer.forward_features (eva_vit.py:402-431), post-norm blocks (:296-300), naive attention
+ * (:182-252) with heads zero-padded from head_width to 128 at pack time (see emu_amd/vit.py):
+ *   wqkv [3*Hh*128, C] (+ bqkv [3*Hh*128] = q_bias | 0 | v_bias), wproj [C, Hh*128], fc1 [F, C], fc2 [C, F]. */
+typedef struct {
+    int image_size, patch_size, width, layers, heads, head_width, mlp_hidden, kpad;
+    float ln_eps;
+} emu_vit_cfg;
+int emu_vit_create(emu_ctx* ctx, const emu_vit_cfg* cfg, emu_vit** out);
+void emu_vit_destroy(emu_vit* m);
+int emu_vit_set_stem(emu_vit* m, const void* wpatch, const void* bpatch, const void* cls, const void* pos);
+int emu_vit_set_block(emu_vit* m, int layer, const void* wqkv, const void* bqkv, const void* wproj,
+                      const void* bproj, const void* ln1w, const void* ln1b, const void* fc1w, const void* fc1b,
+                      const void* fc2w, const void* fc2b, const void* ln2w, const void* ln2b);
+size_t emu_vit_workspace_bytes(const emu_vit* m, int B);
+/* image NCHW (fp32 or bf16) -> tokens [B, 1+g*g, C] bf16 (raw block output incl. cls, eva_vit.py:433-445) */
+int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int B, void* out_tokens, void* workspace,
+                    size_t ws_bytes, emu_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMU_HIP_H */

@@ -1,0 +1,145 @@
+"""GPU parity tests of the engines (ViT, LLaMA prefill/decode, EmuModel.generate / generate_image) against the
+CPU oracle and the golden fixtures frozen from the real reference.  Run on an MI355X with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from tests import tiny
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-12))
+
+
+@pytest.fixture(scope="module")
+def tiny_model(golden_dir):
+    """emu_amd.EmuModel (HIP) + oracle weights (fp32 tensors holding the same bf16 values)."""
+    from emu_amd import EmuModel, TextDecoderCfg
+    from oracle import emu2_ref as R
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    m = EmuModel(v, TextDecoderCfg(instruct=True), llama_cfg=l, device="cuda")
+    m.load_state_dict(W, strict=True)
+    return m, R.bf16_round(W), tiny.oracle_cfg(v, l, vocab)
+
+
+def test_vit_and_encode_image(tiny_model, golden_dir):
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "vit_tiny.npz")
+    image = _t(z["image"]).to(BF16)
+    feats = m.visual(image.cuda())
+    want = R.vit_forward(image.float(), W, cfg.vit)
+    assert rel_err(feats, want) < 2e-2, rel_err(feats, want)
+    # and against the real reference's fp32 output (different weights rounding: looser)
+    assert rel_err(feats, _t(z["feats"])) < 3e-2
+    for nq in (4, 1):
+        enc = m.encode_image(image.cuda(), n_query=nq)
+        assert rel_err(enc, R.encode_image(image.float(), W, cfg, n_query=nq)) < 2e-2
+
+
+def test_llama_prefill_hidden_and_logits(tiny_model, golden_dir):
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "llama_tiny.npz")
+    embeds, mask = _t(z["embeds"]).to(BF16), _t(z["mask"])
+    lm = m.decoder.lm
+    hidden, kstart, _ = lm.prefill(embeds.cuda(), mask, hf_generate_positions=False)
+    got = lm.final_norm_rows(hidden.reshape(-1, hidden.shape[-1]).contiguous()).view_as(hidden)
+    want = R.llama_model(embeds.float(), mask, W, cfg.llama)
+    valid = mask.bool()
+    assert rel_err(got.cpu()[valid], want[valid]) < 2e-2
+    assert rel_err(got.cpu()[valid], _t(z["hidden"])[valid]) < 3e-2           # real reference, fp32 weights
+    logits = lm.logits(hidden[:, -1, :])
+    wl = torch.nn.functional.linear(want[:, -1], W["decoder.lm.lm_head.weight"])
+    assert rel_err(logits, wl) < 2e-2
+
+
+def test_decode_matches_prefill(tiny_model):
+    """KV-cache property: prefill(S) then one cached step == last row of prefill(S+1)."""
+    m, W, cfg = tiny_model
+    lm = m.decoder.lm
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(2, 40, cfg.llama.hidden, generator=g) * 0.5).to(BF16).cuda()
+    mask = torch.ones(2, 40, dtype=torch.long)
+    full, _, _ = lm.prefill(x, mask)
+    full_last = full[:, -1, :].clone()
+    part, kstart, pos = lm.prefill(x[:, :39].contiguous(), mask[:, :39])
+    step = lm.decode_embeds(x[:, 39, :].contiguous(), pos, 39, kstart)
+    assert rel_err(step, full_last) < 1.5e-2
+
+
+def test_generate_greedy_token_exact(tiny_model, golden_dir):
+    """north_star: token ids bit-exact for greedy text.  Compared with the REAL reference's ids (golden), B=1 with
+    an image and B=2 ragged (left-padded) text-only; the fixtures have top-2 logit margins > 0.05."""
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    new1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), _t(z["image"]).cuda(), max_new_tokens=8)
+    assert new1.cpu().tolist() == z["new1"].tolist()
+    new2 = m.generate_ids(_t(z["ids2"]), _t(z["mask2"]), None, max_new_tokens=6)
+    assert new2.cpu().tolist() == z["new2"].tolist()
+
+
+def test_generate_graph_replay_equals_eager(tiny_model, golden_dir):
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    m.use_graph = True
+    try:
+        new1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), _t(z["image"]).cuda(), max_new_tokens=8)
+    finally:
+        m.use_graph = False
+    assert new1.cpu().tolist() == z["new1"].tolist()
+
+
+def test_generate_image_matches_reference(tiny_model, golden_dir):
+    """Stated fp tolerance on the regressed visual embeddings: relative L2 error < 3e-2 vs the oracle's uncached
+    loop (the reference algorithm) and vs the real reference output."""
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_image_tiny.npz")
+    out = m.generate_image_ids(_t(z["prompt_text"]), None)
+    want = R.emu_generate_image_uncached(_t(z["prompt_text"]), None, W, cfg)
+    assert out.shape == want.shape
+    assert rel_err(out, want) < 3e-2, rel_err(out, want)
+    assert rel_err(out, _t(z["out_text"])) < 4e-2
+    img = _t(z["image"]).to(BF16)
+    out = m.generate_image_ids(_t(z["prompt_img"]), img.cuda())
+    want = R.emu_generate_image_uncached(_t(z["prompt_img"]), img.float(), W, cfg)
+    assert rel_err(out, want) < 3e-2, rel_err(out, want)
+
+
+def test_true_width_single_layer_decode_and_prefill():
+    """One LLaMA-33B-shaped layer (hidden 6656, 52 heads, ffn 17920) against the CPU oracle: prefill S=96 and a
+    cached decode step -- exercises the real GEMV/GEMM/attention shapes of the bench."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import LlamaCfg
+    from emu_amd.llama import EmuHipContext, LlamaEngine
+    from oracle import emu2_ref as R
+    l = LlamaCfg(num_hidden_layers=1)
+    vocab = 1024                                      # small head: the lm_head GEMV shape is covered by test_gemv
+    shapes = {k: s for k, s in synth.llama_param_shapes(l, vocab).items()}
+    W = synth.synth_state_dict(shapes, seed=3)
+    eng = LlamaEngine(l, vocab, EmuHipContext(torch.device("cuda", 0)))
+    eng.load_weights(W.items())
+    assert eng.ready
+    Wr = R.bf16_round(W)
+    cfg = R.LlamaCfg(layers=1, vocab=vocab)
+    g = torch.Generator().manual_seed(9)
+    S = 96
+    x = (torch.randn(1, S + 1, l.hidden_size, generator=g)).to(BF16)
+    mask = torch.ones(1, S, dtype=torch.long)
+    hidden, kstart, pos = eng.prefill(x[:, :S].cuda(), mask, s_max=256)
+    cache = R.KVCache(1)
+    want = R.llama_model(x[:, :S].float(), mask, Wr, cfg, cache=cache, final_norm=False)
+    assert rel_err(hidden, want) < 2e-2, rel_err(hidden, want)
+    step = eng.decode_embeds(x[:, S].cuda(), pos, S, kstart)
+    want1 = R.llama_model(x[:, S:].float(), torch.ones(1, S + 1, dtype=torch.long), Wr, cfg, cache=cache, final_norm=False)
+    assert rel_err(step, want1[:, 0]) < 2e-2, rel_err(step, want1[:, 0])

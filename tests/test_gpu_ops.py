@@ -1,0 +1,254 @@
+"""GPU parity tests of the primitive C-ABI operators (through emu_amd.ops -> libemu_hip.so) against CPU fp32
+references that keep the reference's bf16 rounding points.  Run on an MI355X with `-m gpu`."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _ops():
+    from emu_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF16)
+
+
+def bfr(t):
+    return t.to(BF16).float()
+
+
+def ref_linear(x, w, bias=None, res=None, norm_w=None, eps=0.0, epi=0):
+    """CPU fp32 math on bf16-valued inputs with the reference's rounding points."""
+    x, w = x.float(), w.float()
+    if norm_w is not None:
+        x = bfr(norm_w.float() * bfr(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)))
+    y = x @ w.t()
+    if bias is not None:
+        y = y + bias.float()
+    y = bfr(y)
+    if epi == 1:
+        y = bfr(y + res.float())
+    elif epi == 2:
+        y = bfr(bfr(F.silu(y[:, 0::2])) * y[:, 1::2])
+    elif epi == 3:
+        y = bfr(F.silu(y))
+    elif epi == 4:
+        y = bfr(F.gelu(y))
+    elif epi == 5:
+        y = bfr(y[:, 0::2] * bfr(F.gelu(y[:, 1::2])))
+    return y
+
+
+def close(got, want, rtol=2e-2, atol=None, what=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    if atol is None:
+        atol = 1e-2 * float(want.abs().max().clamp_min(1e-6))
+    bad = (got - want).abs() > atol + rtol * want.abs()
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max abs err "
+                                 f"{float((got - want).abs().max())}, ref max {float(want.abs().max())}")
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("N,K", [(64, 256), (1002, 896), (520, 6656), (96, 17920)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemv(M, N, K, epi):
+    ops = _ops()
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias = rnd(N, seed=3) if epi in (0, 3) else None
+    res = rnd(M, N, seed=4) if epi == 1 else None
+    got = ops.linear(x.cuda(), w.cuda(), bias=None if bias is None else bias.cuda(),
+                     res=None if res is None else res.cuda(), epi=epi)
+    close(got, ref_linear(x, w, bias, res, epi=epi), what=f"gemv M{M} N{N} K{K} epi{epi}")
+
+
+@pytest.mark.parametrize("M", [1, 4])
+@pytest.mark.parametrize("epi", [0, 2])
+def test_gemv_fused_rmsnorm(M, epi):
+    ops = _ops()
+    K, N = 6656, 264
+    x, w, g = rnd(M, K, seed=1, scale=3.0), rnd(N, K, seed=2, scale=0.05), (1 + 0.1 * rnd(K, seed=5).float()).to(BF16)
+    got = ops.linear(x.cuda(), w.cuda(), norm_w=g.cuda(), eps=1e-6, epi=epi)
+    close(got, ref_linear(x, w, norm_w=g, eps=1e-6, epi=epi), what="gemv+rmsnorm")
+
+
+def test_gemv_strided_rows():
+    ops = _ops()
+    big = rnd(4, 3 * 512, seed=7).cuda()
+    x = big[:, 512:1024]                       # ldx = 1536, K = 512
+    w = rnd(40, 512, seed=8, scale=0.05)
+    close(ops.linear(x, w.cuda()), ref_linear(x.cpu(), w), what="gemv strided")
+
+
+@pytest.mark.parametrize("M,N,K", [(9, 128, 64), (128, 128, 128), (300, 320, 640), (770, 384, 1792), (257, 1000, 200),
+                                   (130, 6656, 6656)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5])
+def test_gemm(M, N, K, epi):
+    ops = _ops()
+    if N * K > 4e6 and epi not in (0, 2):
+        pytest.skip("large shape: two epilogues are enough")
+    x, w = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.05)
+    bias = rnd(N, seed=13) if epi in (0, 1, 4) else None
+    res = rnd(M, N, seed=14) if epi == 1 else None
+    got = ops.linear(x.cuda(), w.cuda(), bias=None if bias is None else bias.cuda(),
+                     res=None if res is None else res.cuda(), epi=epi)
+    close(got, ref_linear(x, w, bias, res, epi=epi), what=f"gemm M{M} N{N} K{K} epi{epi}")
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches any row/col swap in the MFMA fragment maps exactly."""
+    ops = _ops()
+    K = 256
+    x = torch.eye(K).to(BF16)
+    w = (torch.arange(192 * K).reshape(192, K) % 251 - 125).float().to(BF16)      # exactly representable
+    got = ops.linear(x.cuda(), w.cuda())
+    assert torch.equal(got.float().cpu(), w.float().t().contiguous())
+
+
+def test_gemm_matches_gemv_rows():
+    """Same weights through both kernels: the M<=8 GEMV and the MFMA GEMM agree to accumulation-order noise."""
+    ops = _ops()
+    x, w = rnd(16, 6656, seed=21).cuda(), rnd(512, 6656, seed=22, scale=0.05).cuda()
+    a = ops.linear(x, w)                       # GEMM (M = 16)
+    b = torch.cat([ops.linear(x[:8], w), ops.linear(x[8:], w)])
+    close(a, b.float().cpu(), rtol=1e-2, what="gemm vs gemv")
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 6656), (5, 256), (300, 1792)])
+def test_rmsnorm_layernorm(rows, cols):
+    ops = _ops()
+    x = rnd(rows, cols, seed=31, scale=2.0)
+    w = (1 + 0.1 * rnd(cols, seed=32).float()).to(BF16)
+    b = rnd(cols, seed=33, scale=0.1)
+    res = rnd(rows, cols, seed=34)
+    xf = x.float()
+    want = bfr(w.float() * bfr(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)))
+    close(ops.rmsnorm(x.cuda(), w.cuda(), 1e-6), want, what="rmsnorm")
+    ln = bfr(F.layer_norm(xf, (cols,), w.float(), b.float(), 1e-6))
+    close(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6), ln, what="layernorm")
+    close(ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6, res=res.cuda()), bfr(res.float() + ln), what="layernorm+res")
+    # in-place residual form used by the ViT engine (y aliases res)
+    r = res.cuda().clone()
+    ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6, res=r, out=r)
+    close(r, bfr(res.float() + ln), what="layernorm in place")
+
+
+def test_embed_scatter_argmax_avgpool():
+    ops = _ops()
+    table = rnd(1000, 256, seed=41)
+    ids = torch.tensor([0, 999, 5, 5, 123], dtype=torch.int32)
+    e = ops.embed_gather(ids.cuda(), table.cuda())
+    assert torch.equal(e.cpu(), table[ids.long()])
+    src = rnd(2, 256, seed=42)
+    ops.scatter_rows(src.cuda(), torch.tensor([3, 1], dtype=torch.int32).cuda(), e)
+    want = table[ids.long()].clone(); want[3] = src[0]; want[1] = src[1]
+    assert torch.equal(e.cpu(), want)
+    logits = rnd(3, 32274, seed=43)
+    logits[0, 777] = 50.0; logits[0, 30000] = 50.0          # tie -> first index
+    logits[1, 2] = 60.0                                      # suppressed
+    got = ops.argmax(logits.cuda(), suppress_id=2).cpu()
+    lf = logits.float().clone(); lf[:, 2] = -float("inf")
+    assert got.tolist() == lf.argmax(-1).tolist() and got[0] == 777
+    x = rnd(2, 17, 224, seed=44)
+    for s in (1, 2, 4):
+        ref = F.avg_pool2d(x[:, 1:].float().permute(0, 2, 1).reshape(2, 224, 4, 4), s, s).reshape(2, 224, -1).permute(0, 2, 1)
+        close(ops.avgpool_tokens(x.cuda(), 4, s), bfr(ref), what=f"avgpool s{s}")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_rope_kv_append(D):
+    from oracle import emu2_ref as R
+    ops = _ops()
+    B, T, H, S_max = 2, 5, 3, 16
+    from emu_amd.llama import rope_tables
+    cos, sin = rope_tables(D, 64, 10000.0, "cuda")
+    qkv = rnd(B * T, 3 * H * D, seed=51)
+    pos = torch.tensor([[3, 4, 5, 6, 7], [0, 1, 2, 3, 4]], dtype=torch.int32)
+    slot = torch.tensor([[2, 3, 4, 5, 6], [2, 3, 4, 5, 6]], dtype=torch.int32)
+    kc = torch.zeros(B, H, S_max, D, dtype=BF16, device="cuda"); vc = torch.zeros_like(kc)
+    dq = qkv.cuda().clone()
+    ops.rope_kv_append(dq, cos, sin, pos.reshape(-1).cuda(), slot.reshape(-1).cuda(), kc, vc, B, T, H, D)
+    q = qkv.view(B, T, 3, H, D)
+    c, s = R.rope_cos_sin(pos.long(), D, 10000.0, BF16)
+    qr, kr = R.apply_rope(q[:, :, 0].transpose(1, 2), q[:, :, 1].transpose(1, 2), c, s)     # bf16 ops, [B,H,T,D]
+    got = dq.view(B, T, 3, H, D).cpu()
+    assert torch.equal(got[:, :, 0].transpose(1, 2), qr)
+    assert torch.equal(got[:, :, 1].transpose(1, 2), kr)
+    assert torch.equal(got[:, :, 2], q[:, :, 2])
+    assert torch.equal(kc[:, :, 2:7].cpu(), kr) and torch.equal(vc[:, :, 2:7].cpu(), q[:, :, 2].transpose(1, 2))
+    assert float(kc[:, :, :2].abs().max()) == 0 and float(kc[:, :, 7:].abs().max()) == 0
+
+
+def ref_attention(q, k, v, causal, scale, kstart=None):
+    """q [B,Sq,H,D], k/v [B,Sk,H,D] fp32 softmax reference."""
+    q, k, v = (t.float().transpose(1, 2) for t in (q, k, v))
+    Sq, Sk = q.shape[2], k.shape[2]
+    s = q @ k.transpose(-1, -2) * scale
+    allowed = torch.ones(q.shape[0], 1, Sq, Sk, dtype=torch.bool)
+    if causal:
+        allowed &= (torch.arange(Sk)[None, :] <= torch.arange(Sq)[:, None] + (Sk - Sq))[None, None]
+    if kstart is not None:
+        allowed &= (torch.arange(Sk)[None, :] >= kstart[:, None])[:, None, None, :]
+    s = s.masked_fill(~allowed, -float("inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return (p @ v).transpose(1, 2)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("Sq,Sk,causal", [(17, 17, False), (200, 200, True), (130, 333, True), (64, 64, True),
+                                           (1025, 1025, False), (5, 77, False)])
+def test_flash_attn(D, Sq, Sk, causal):
+    ops = _ops()
+    B, H = 2, 3
+    q, k, v = rnd(B, Sq, H, D, seed=61), rnd(B, Sk, H, D, seed=62), rnd(B, Sk, H, D, seed=63)
+    scale = D ** -0.5
+    got = ops.flash_attn(q.cuda(), k.cuda(), v.cuda(), causal, scale)
+    close(got, ref_attention(q, k, v, causal, scale), atol=2e-2, what=f"flash D{D} {Sq}x{Sk} causal{causal}")
+
+
+def test_flash_attn_left_padding_and_strided_qkv():
+    ops = _ops()
+    B, S, H, D = 2, 150, 2, 128
+    qkv = rnd(B, S, 3, H, D, seed=64).cuda()                  # packed projection output, like the engines use
+    kstart = torch.tensor([0, 37], dtype=torch.int32)
+    got = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], True, D ** -0.5, kstart=kstart.cuda())
+    want = ref_attention(qkv[:, :, 0].cpu(), qkv[:, :, 1].cpu(), qkv[:, :, 2].cpu(), True, D ** -0.5, kstart.long())
+    ok_rows = torch.ones(B, S, dtype=torch.bool); ok_rows[1, :37] = False     # padded query rows are don't-care
+    close(got.cpu()[ok_rows], want[ok_rows], atol=2e-2, what="flash left pad")
+    assert bool(torch.isfinite(got.float()).all())
+
+
+def test_flash_attn_spiked_scores():
+    """Force the online-softmax rescale path: one key dominates late in the sequence."""
+    ops = _ops()
+    B, S, H, D = 1, 300, 1, 128
+    q, k, v = rnd(B, S, H, D, seed=65), rnd(B, S, H, D, seed=66), rnd(B, S, H, D, seed=67)
+    k[0, 250, 0] = q[0, 280, 0] * 4
+    got = ops.flash_attn(q.cuda(), k.cuda(), v.cuda(), True, D ** -0.5)
+    close(got, ref_attention(q, k, v, True, D ** -0.5), atol=2e-2, what="flash spike")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("ctx", [1, 255, 256, 257, 700])
+def test_decode_attn(D, ctx):
+    ops = _ops()
+    B, H, S_max = 2, 3, 1024
+    q = rnd(B, H, D, seed=71)
+    kc, vc = rnd(B, H, S_max, D, seed=72), rnd(B, H, S_max, D, seed=73)
+    kstart = torch.tensor([0, min(5, ctx - 1)], dtype=torch.int32)
+    want = ref_attention(q[:, None], kc[:, :, :ctx].transpose(1, 2), vc[:, :, :ctx].transpose(1, 2), False, D ** -0.5,
+                         kstart.long())[:, 0]
+    got = ops.decode_attn(q.cuda(), kc.cuda(), vc.cuda(), ctx, D ** -0.5, kstart=kstart.cuda())
+    close(got, want, atol=2e-2, what=f"decode attn ctx{ctx}")
+    # graph-replay form: live context read from device memory, launch sized for S_max
+    ctx_dev = torch.tensor([ctx], dtype=torch.int32, device="cuda")
+    got2 = ops.decode_attn(q.cuda(), kc.cuda(), vc.cuda(), S_max, D ** -0.5, kstart=kstart.cuda(), ctx_dev=ctx_dev,
+                           ctx_max=S_max)
+    assert torch.equal(got.cpu(), got2.cpu())

@@ -1,0 +1,95 @@
+"""CPU tests of the host logic: TP shard plan, EOS bookkeeping, synthetic weights, config mirrors."""
+import pytest
+import torch
+
+from emu_amd import synth
+from emu_amd.conf.emu_conf import CLIPVisionCfg, LlamaCfg
+from emu_amd.tp import ShardPlan
+from oracle import emu2_ref as R
+from tests.tp_ref import sharded_layer_partial
+
+
+def _layer_weights(l: LlamaCfg, seed=1):
+    shapes = {k: s for k, s in synth.llama_param_shapes(l, 64).items() if ".layers.0." in k}
+    return synth.synth_state_dict(shapes, seed=seed)
+
+
+@pytest.mark.parametrize("heads,tp", [(4, 1), (4, 2), (4, 4), (5, 2), (13, 8), (52, 8)])
+def test_shard_plan_sum_of_shards_equals_unsharded_layer(heads, tp):
+    D = 16
+    l = LlamaCfg(hidden_size=heads * D, intermediate_size=64 * tp, num_attention_heads=heads, num_hidden_layers=1)
+    W = _layer_weights(l)
+    pre = "decoder.lm.model.layers.0."
+    cfg = R.LlamaCfg(hidden=l.hidden_size, heads=heads, layers=1, ffn=l.intermediate_size, vocab=64)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 7, l.hidden_size, generator=g)
+    pos = torch.arange(7)[None].expand(2, -1)
+    cos, sin = R.rope_cos_sin(pos, D, 10000.0, torch.float32)
+    amask = torch.ones(2, 7, dtype=torch.long)
+    mask = R.build_mask(amask, 7, torch.float32)
+    want = R.llama_layer(x, W, 0, cfg, cos, sin, mask, None)
+    plans = [ShardPlan(l.hidden_size, heads, D, l.intermediate_size, tp, r) for r in range(tp)]
+    assert plans[0].heads_pad % tp == 0 and plans[0].heads_pad >= heads
+    packed = [p.pack_layer(*(W[pre + k] for k in ("self_attn.q_proj.weight", "self_attn.k_proj.weight",
+                                                   "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                                                   "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                                                   "mlp.down_proj.weight"))) for p in plans]
+    # lock-step simulation of the tp ranks with an in-process all-reduce
+    ln1, ln2 = W[pre + "input_layernorm.weight"], W[pre + "post_attention_layernorm.weight"]
+    import threading
+    barrier = threading.Barrier(tp)
+    box, outs = [None] * tp, [None] * tp
+
+    def run(r):
+        def allreduce(t):
+            box[r] = t
+            barrier.wait()
+            s = sum(box)
+            barrier.wait()
+            return s
+        outs[r] = sharded_layer_partial(x, packed[r], ln1, ln2, plans[r], cfg, cos, sin, mask, allreduce)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(tp)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r in range(tp):
+        torch.testing.assert_close(outs[r], want, rtol=1e-4, atol=1e-5)
+
+
+def test_shard_plan_33b_shapes():
+    for tp in (1, 2, 4, 8):
+        p = ShardPlan(6656, 52, 128, 17920, tp, tp - 1)
+        assert p.ffn_local * tp == 17920 and p.heads_local * tp >= 52
+    p = ShardPlan(6656, 52, 128, 17920, 8, 7)
+    assert p.heads_pad == 56 and p.heads_local == 7 and p.head_range == (49, 56)     # 3 real + 4 zero heads
+    with pytest.raises(ValueError):
+        ShardPlan(6656, 52, 128, 17920, 3, 0)
+
+
+def test_apply_eos_padding_matches_hf_bookkeeping():
+    from emu_amd.llama import apply_eos_padding
+    ids = torch.tensor([[5, 2, 9, 9, 9], [7, 8, 2, 4, 4]])
+    out = apply_eos_padding(ids, eos_id=2, pad_id=32000)
+    assert out.tolist() == [[5, 2, 32000], [7, 8, 2]]
+    ids = torch.tensor([[5, 6, 7], [7, 8, 2]])
+    assert apply_eos_padding(ids, 2, 32000).tolist() == ids.tolist()
+
+
+def test_synth_is_deterministic_and_per_tensor():
+    v = CLIPVisionCfg(image_size=28, width=32, layers=1, head_width=16, mlp_ratio=2.0)
+    l = LlamaCfg(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_hidden_layers=1)
+    shapes = synth.emu_param_shapes(v, l, 100)
+    a = synth.synth_state_dict(shapes, seed=3)
+    b = dict(synth.iter_synth(shapes, seed=3))
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    one = synth.synth_tensor("project_up.weight", shapes["project_up.weight"], seed=3)
+    assert torch.equal(one, a["project_up.weight"])
+    assert abs(float(a["decoder.lm.model.norm.weight"].mean()) - 1.0) < 0.1
+    assert set(k.split(".")[0] for k in a) == {"visual", "decoder", "project_up", "project_down"}
+
+
+def test_config_mirrors_reference_defaults():
+    v = CLIPVisionCfg()
+    assert (v.width, v.layers, v.head_width, v.heads, v.mlp_hidden, v.tokens, v.n_query) == (1792, 64, 112, 16, 15360, 1025, 64)
+    l = LlamaCfg.from_json(__import__("os").path.join(__import__("os").path.dirname(synth.__file__), "conf", "llama_config"))
+    assert (l.hidden_size, l.num_attention_heads, l.num_hidden_layers, l.intermediate_size, l.head_dim) == (6656, 52, 60, 17920, 128)
