@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--prompt-tokens", type=int, default=512)
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
 
@@ -50,48 +50,73 @@ def log(*a):
 
 def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
     """CPU oracle (port of the reference algorithm, oracle/emu2_ref.py) on the host cores: ONE true-shape
-    LLaMA-33B decoder layer, cached decode step at ctx_len, bf16 like the reference runs it; tokens/s is
-    extrapolated as 1 / (60 * t_layer + t_lm_head).  Bounded to ~`seconds` of CPU work."""
+    LLaMA-33B decoder layer, cached decode step at ctx_len; tokens/s is extrapolated as
+    1 / (60 * t_layer + t_lm_head).  The (dtype, thread-count) pair is the fastest of a short calibration
+    (torch CPU bf16 mat-vec can be far slower than fp32, and 256 threads slower than 32); `cores` reports the
+    threads actually used.  Bounded to roughly `seconds` of measurement after calibration."""
     from emu_amd import synth
     from emu_amd.conf.emu_conf import LlamaCfg
     from oracle import emu2_ref as R
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     l = LlamaCfg(num_hidden_layers=1)
     shapes = {k: s for k, s in synth.llama_param_shapes(l, vocab).items() if "embed_tokens" not in k}
-    W = {k: synth.synth_tensor(k, s, seed=0).to(torch.bfloat16) for k, s in shapes.items()}
+    W32 = {k: synth.synth_tensor(k, s, seed=0) for k, s in shapes.items()}
     cfg = R.LlamaCfg(layers=1, vocab=vocab)
-    cache = R.KVCache(1)
     g = torch.Generator().manual_seed(0)
-    cache.k[0] = torch.randn(1, cfg.heads, ctx_len, cfg.head_dim, generator=g).to(torch.bfloat16)
-    cache.v[0] = torch.randn(1, cfg.heads, ctx_len, cfg.head_dim, generator=g).to(torch.bfloat16)
-    x = torch.randn(1, 1, cfg.hidden, generator=g).to(torch.bfloat16)
+    k0 = torch.randn(1, cfg.heads, ctx_len, cfg.head_dim, generator=g)
+    v0 = torch.randn(1, cfg.heads, ctx_len, cfg.head_dim, generator=g)
+    x0 = torch.randn(1, 1, cfg.hidden, generator=g)
     pos = torch.tensor([[ctx_len]])
+    mask = torch.ones(1, ctx_len + 1, dtype=torch.long)
 
-    def one_layer():
-        c = R.KVCache(1)
-        c.k[0], c.v[0] = cache.k[0], cache.v[0]
-        mask = torch.ones(1, ctx_len + 1, dtype=torch.long)
-        return R.llama_model(x, mask, W, cfg, position_ids=pos, cache=c, final_norm=False)
+    def make(dtype):
+        W = W32 if dtype == torch.float32 else {k: t.to(dtype) for k, t in W32.items()}
+        kk, vv, x = k0.to(dtype), v0.to(dtype), x0.to(dtype)
 
-    def head():
-        h = R.rms_norm(x, W["decoder.lm.model.norm.weight"], cfg.rms_eps)
-        return torch.nn.functional.linear(h, W["decoder.lm.lm_head.weight"])
+        def one_layer():
+            c = R.KVCache(1)
+            c.k[0], c.v[0] = kk, vv
+            return R.llama_model(x, mask, W, cfg, position_ids=pos, cache=c, final_norm=False)
 
+        def head():
+            h = R.rms_norm(x, W["decoder.lm.model.norm.weight"], cfg.rms_eps)
+            return torch.nn.functional.linear(h, W["decoder.lm.lm_head.weight"])
+        return one_layer, head
+
+    cands = []
+    for dtype in (torch.float32, torch.bfloat16):
+        for th in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+            cands.append((dtype, th))
+    best = None
+    t_cal = time.perf_counter()
     with torch.no_grad():
+        for dtype, th in cands:
+            if time.perf_counter() - t_cal > seconds:            # calibration budget
+                break
+            torch.set_num_threads(th)
+            one_layer, head = make(dtype)
+            one_layer()
+            t0 = time.perf_counter(); one_layer(); dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, dtype, th)
+        _, dtype, th = best
+        torch.set_num_threads(th)
+        one_layer, head = make(dtype)
         one_layer(); head()
         t0 = time.perf_counter(); n = 0
-        while time.perf_counter() - t0 < seconds * 0.8:
+        while time.perf_counter() - t0 < seconds * 0.8 or n < 2:
             one_layer(); n += 1
         t_layer = (time.perf_counter() - t0) / n
         t0 = time.perf_counter(); m = 0
-        while time.perf_counter() - t0 < seconds * 0.2:
+        while time.perf_counter() - t0 < seconds * 0.2 or m < 2:
             head(); m += 1
         t_head = (time.perf_counter() - t0) / m
     tok_s = 1.0 / (60 * t_layer + t_head)
-    return {"value": tok_s, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 true-shape LLaMA-33B decoder layer x{n} + lm_head x{m} (bf16, ctx {ctx_len}, batch 1) "
-                      f"on {cores} threads; tokens/s = 1/(60*{t_layer * 1e3:.1f} ms + {t_head * 1e3:.1f} ms)"}
+    dn = "fp32" if dtype == torch.float32 else "bf16"
+    return {"value": tok_s, "unit": "tokens/s", "cores": th, "kind": "port",
+            "sample": f"1 true-shape LLaMA-33B decoder layer x{n} + lm_head x{m} ({dn}, ctx {ctx_len}, batch 1) on {th} of "
+                      f"{ncpu} host threads (fastest of a dtype/thread calibration); tokens/s = 1/(60*{t_layer * 1e3:.1f} ms "
+                      f"+ {t_head * 1e3:.1f} ms)"}
 
 
 def main():
