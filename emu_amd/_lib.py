@@ -33,6 +33,12 @@ class VitCfgC(C.Structure):
                 ("head_width", i32), ("mlp_hidden", i32), ("kpad", i32), ("ln_eps", f32)]
 
 
+class UNetCfgC(C.Structure):
+    _fields_ = [("in_ch", i32), ("out_ch", i32), ("ch", i32 * 3), ("layers_per_block", i32), ("depth", i32 * 3),
+                ("heads", i32 * 3), ("attn", i32 * 3), ("cross_dim", i32), ("groups", i32), ("gn_eps", f32),
+                ("temb_dim", i32), ("kpad_in", i32)]
+
+
 _PROTOS = {
     "emu_version": (i32, []),
     "emu_profile_gemv": (i32, [i32]),
@@ -74,6 +80,19 @@ _PROTOS = {
     "emu_vit_set_block": (i32, [vp, i32] + [vp] * 12),
     "emu_vit_workspace_bytes": (sz, [vp, i32]),
     "emu_vit_forward": (i32, [vp, vp, i32, i32, vp, vp, sz, vp]),
+    "emu_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
+    "emu_groupnorm_nhwc_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "emu_conv3x3_nhwc_bf16": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "emu_unet_create": (i32, [vp, C.POINTER(UNetCfgC), C.POINTER(vp)]),
+    "emu_unet_destroy": (None, [vp]),
+    "emu_unet_set_weight": (i32, [vp, C.c_char_p, vp]),
+    "emu_unet_finalize": (i32, [vp]),
+    "emu_unet_temb_total": (i32, [vp]),
+    "emu_unet_workspace_bytes": (sz, [vp, i32, i32]),
+    "emu_unet_context_bytes": (sz, [vp, i32]),
+    "emu_unet_set_context": (i32, [vp, vp, i32, vp, i32, vp, sz, vp, sz, vp]),
+    "emu_unet_step": (i32, [vp, vp, i32, i32, vp, vp, vp, f32, vp, sz, vp]),
+    "emu_unet_forward": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
 }
 
 

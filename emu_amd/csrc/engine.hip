@@ -56,10 +56,12 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
         return st;
     }
     if (norm_w) return -22;
-    GemmArgs g{A, W, bias, res, C, M, N, K, lda, ldw, ldres, ldc, epi};
+    GemmArgs g{A, W, bias, res, C, M, N, K, lda, ldw, ldres, ldc, epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
     return launch_gemm(g, s);
 }
 }  // namespace
+
+int emu_ctx_fail(emu_ctx* c, int code, const char* what) { return fail(c, code, what); }
 
 extern "C" {
 

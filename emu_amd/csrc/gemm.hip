@@ -24,7 +24,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {       // 128-byte r
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int EPI>
+template <int EPI, bool CONV>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][W | A]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     const bf16_t* gW[4];
     const bf16_t* gA[4];
     int soff[4], kc[4];
+    int pb[4], py[4], px[4];                     // CONV: output pixel of each staged row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = tid + 256 * i, row = q >> 3, c = q & 7;
@@ -51,17 +52,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
         gA[i] = a.A + (size_t)gm * a.lda + c * 8;
         soff[i] = lds_off(row, c);
         kc[i] = c * 8;
+        if constexpr (CONV) {
+            const int hw = a.conv.Hout * a.conv.Wout;
+            pb[i] = gm / hw;
+            const int r = gm - pb[i] * hw;
+            py[i] = r / a.conv.Wout;
+            px[i] = r - py[i] * a.conv.Wout;
+        }
     }
     const int nk = (a.K + BK - 1) / BK;
     u32x4 rw[4], ra[4];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if constexpr (CONV) {
+            // a 64-wide k tile lies inside one filter tap because Cin % 64 == 0
+            const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = (k0 + kc[i]) < a.K;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            rw[i] = ok ? ld16(gW[i] + k0) : z;
-            ra[i] = ok ? ld16(gA[i] + k0) : z;
+            for (int i = 0; i < 4; ++i) {
+                rw[i] = ld16(gW[i] + k0);
+                int yi, xi;
+                bool ok;
+                if (a.conv.mode == CONV_3X3_S2) {
+                    yi = 2 * py[i] + ky - 1; xi = 2 * px[i] + kx - 1;
+                    ok = yi >= 0 && yi < a.conv.Hin && xi >= 0 && xi < a.conv.Win;
+                } else if (a.conv.mode == CONV_3X3_UP2) {       // nearest x2 upsample fused into the gather
+                    const int yu = py[i] + ky - 1, xu = px[i] + kx - 1;
+                    ok = yu >= 0 && yu < 2 * a.conv.Hin && xu >= 0 && xu < 2 * a.conv.Win;
+                    yi = yu >> 1; xi = xu >> 1;
+                } else {
+                    yi = py[i] + ky - 1; xi = px[i] + kx - 1;
+                    ok = yi >= 0 && yi < a.conv.Hin && xi >= 0 && xi < a.conv.Win;
+                }
+                const size_t off = (((size_t)pb[i] * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin + ci0 + kc[i];
+                ra[i] = ok ? ld16(a.A + off) : z;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (k0 + kc[i]) < a.K;
+                rw[i] = ok ? ld16(gW[i] + k0) : z;
+                ra[i] = ok ? ld16(gA[i] + k0) : z;
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -137,6 +170,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = bfround(v[e]);
+                if (a.bias2) {
+                    const bf16_t* b2 = a.bias2 + (size_t)(m / a.rows_per_batch) * a.ld_bias2 + nb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (full || nb + e < a.N) v[e] = bfround(v[e] + bf2f(b2[e]));
+                }
                 if constexpr (pair) {
                     // interleaved rows (2j, 2j+1): SwiGLU = (gate, up) -> bf16(bf16(silu(gate)) * up)
                     //                               GEGLU  = (hidden, gate) -> bf16(hidden * bf16(gelu(gate)))
@@ -192,18 +230,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
 }  // namespace
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
-    if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.lda & 7) || (a.ldw & 7) || (a.ldc & 3)) return -22;
+    if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7) || (a.ldc & 3)) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && (a.N & 1)) return -22;
     if (a.epi == EPI_RESID && (a.ldres & 3)) return -22;
+    if (a.bias2 && a.rows_per_batch < 1) return -22;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
+    if (a.conv.mode != CONV_NONE) {
+        const ConvGeom& g = a.conv;
+        if ((g.Cin & 63) || a.K != 9 * g.Cin || a.M % (g.Hout * g.Wout)) return -22;
+        if (g.mode == CONV_3X3 && (g.Hout != g.Hin || g.Wout != g.Win)) return -22;
+        if (g.mode == CONV_3X3_S2 && (g.Hout != (g.Hin + 1) / 2 || g.Wout != (g.Win + 1) / 2)) return -22;
+        if (g.mode == CONV_3X3_UP2 && (g.Hout != 2 * g.Hin || g.Wout != 2 * g.Win)) return -22;
+        switch (a.epi) {
+            case EPI_NONE:  hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, true>), grid, block, 0, s, a); break;
+            case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<EPI_RESID, true>), grid, block, 0, s, a); break;
+            default: return -22;
+        }
+        EMU_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a.lda & 7) return -22;
     switch (a.epi) {
-        case EPI_NONE:   hipLaunchKernelGGL(gemm_nt_kernel<EPI_NONE>, grid, block, 0, s, a); break;
-        case EPI_RESID:  hipLaunchKernelGGL(gemm_nt_kernel<EPI_RESID>, grid, block, 0, s, a); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL(gemm_nt_kernel<EPI_SWIGLU>, grid, block, 0, s, a); break;
-        case EPI_SILU:   hipLaunchKernelGGL(gemm_nt_kernel<EPI_SILU>, grid, block, 0, s, a); break;
-        case EPI_GELU:   hipLaunchKernelGGL(gemm_nt_kernel<EPI_GELU>, grid, block, 0, s, a); break;
-        case EPI_GEGLU:  hipLaunchKernelGGL(gemm_nt_kernel<EPI_GEGLU>, grid, block, 0, s, a); break;
+        case EPI_NONE:   hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, false>), grid, block, 0, s, a); break;
+        case EPI_RESID:  hipLaunchKernelGGL((gemm_nt_kernel<EPI_RESID, false>), grid, block, 0, s, a); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm_nt_kernel<EPI_SWIGLU, false>), grid, block, 0, s, a); break;
+        case EPI_SILU:   hipLaunchKernelGGL((gemm_nt_kernel<EPI_SILU, false>), grid, block, 0, s, a); break;
+        case EPI_GELU:   hipLaunchKernelGGL((gemm_nt_kernel<EPI_GELU, false>), grid, block, 0, s, a); break;
+        case EPI_GEGLU:  hipLaunchKernelGGL((gemm_nt_kernel<EPI_GEGLU, false>), grid, block, 0, s, a); break;
         default: return -22;
     }
     EMU_CHECK_LAUNCH();

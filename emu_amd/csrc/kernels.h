@@ -22,8 +22,13 @@ struct GemvArgs {
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
 
+// Implicit-GEMM 3x3 convolution over an NHWC activation: A is [B, Hin, Win, Cin], the GEMM row m is the output
+// pixel (b, yo, xo), K = 9*Cin ordered (ky, kx, ci) -- weights repacked to [Cout, 3, 3, Cin].  Cin % 64 == 0.
+enum EmuConvMode { CONV_NONE = 0, CONV_3X3 = 1, CONV_3X3_S2 = 2, CONV_3X3_UP2 = 3 };
+struct ConvGeom { int mode, Hin, Win, Hout, Wout, Cin; };
+
 struct GemmArgs {
-    const bf16_t* A;        // [M, lda]  activations (K contiguous)
+    const bf16_t* A;        // [M, lda]  activations (K contiguous)   (conv: NHWC input)
     const bf16_t* W;        // [N, ldw]  weights     (K contiguous)
     const bf16_t* bias;     // [N] or null
     const bf16_t* res;      // [M, ldres] (EPI_RESID)
@@ -31,6 +36,10 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldw, ldres, ldc;
     int epi;
+    ConvGeom conv;          // mode 0 = plain GEMM
+    const bf16_t* bias2;    // [M / rows_per_batch, ld_bias2] or null: per-batch bias added after the first rounding
+    int rows_per_batch;     //   (ResnetBlock2D: conv1(x) + time_emb_proj(silu(temb))[:, :, None, None])
+    int ld_bias2;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -100,3 +109,24 @@ int decode_attn_nsplit(int ctx);
 int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, int32_t* ctx, int32_t* step,
                           int32_t* out_ids, int B, hipStream_t s);
 int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
+
+// ---- UNet denoise helpers (unet.hip); activations are NHWC: [B, H*W, C] bf16
+// GroupNorm(groups, eps) (+ optional SiLU) over x [B, HW, C]: three launches (partial sums, finalize to per-(b, c)
+// scale/shift, apply).  ws must hold gn_ws_floats(B, C, HW) floats.
+size_t gn_ws_floats(int B, int C, int HW);
+int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, float* ws, int B, int HW, int C,
+                     int groups, float eps, int silu, hipStream_t s);
+// out[m, :C1] = a[m, :], out[m, C1:] = b[m, :]
+int launch_concat_channels(const bf16_t* a, const bf16_t* b, bf16_t* out, int rows, int C1, int C2, hipStream_t s);
+// latents NCHW [1, C, H, W] -> conv_in im2col matrix [2*H*W, Kpad] (both CFG halves identical), scaled by
+// 1/sqrt(sigma[step]^2 + 1) (EulerDiscreteScheduler.scale_model_input); k = (ky*3 + kx)*C + c, zero padded
+int launch_unet_prep_input(const bf16_t* latents, const float* sigmas, const int32_t* step, bf16_t* out, int C, int H, int W,
+                           int Kpad, hipStream_t s);
+// classifier-free guidance (cond first) + Euler step on NCHW latents, then step++ :
+//   eps = u + g*(c - u); x += eps * (sigma[step+1] - sigma[step])   with the bf16 rounding points of the reference ops
+int launch_cfg_euler_step(const bf16_t* eps_nhwc, bf16_t* latents, const float* sigmas, int32_t* step, float guidance, int C,
+                          int HW, hipStream_t s);
+// out[r, :] = bf16(silu(bf16(a[r, :] + b[r, :])))   (silu(emb + aug_emb) feeding every time_emb_proj)
+int launch_add_silu(const bf16_t* a, const bf16_t* b, bf16_t* sum_out, bf16_t* silu_out, int n, hipStream_t s);
+// out[r, :] = table[step[0], :] for r < rows
+int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out, int rows, int cols, hipStream_t s);

@@ -155,3 +155,31 @@ def decode_attn(q, kcache, vcache, ctx: int, scale: float, kstart=None, ctx_dev=
                                      o.stride(1), _p(kstart), _p(ctx_dev), ctx, ctx_max, _p(ws), B, H, D, S_max,
                                      float(scale), stream()), "emu_decode_attn_bf16")
     return o
+
+
+CONV_3X3, CONV_3X3_S2, CONV_3X3_UP2 = 1, 2, 3
+
+
+def groupnorm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool = False):
+    """x [B, HW, C] (NHWC) -> GroupNorm(groups)(+SiLU), same shape."""
+    _req(x, "x")
+    assert x.is_contiguous() and x.dim() == 3
+    B, HW, Cc = x.shape
+    ws = torch.empty(lib().emu_groupnorm_ws_bytes(B, HW, Cc), device=x.device, dtype=torch.uint8)
+    y = torch.empty_like(x)
+    check(lib().emu_groupnorm_nhwc_bf16(_p(x), _p(gamma), _p(beta), _p(y), _p(ws), B, HW, Cc, groups, float(eps), int(silu),
+                                        stream()), "emu_groupnorm_nhwc_bf16")
+    return y
+
+
+def conv3x3_nhwc(x, w, bias=None, bias2=None, res=None, mode: int = CONV_3X3):
+    """x [B, H, W, Cin] NHWC, w [Cout, 3, 3, Cin] -> [B, Ho, Wo, Cout]."""
+    _req(x, "x"); _req(w, "w")
+    assert x.is_contiguous() and w.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H, W) if mode == CONV_3X3 else (((H + 1) // 2, (W + 1) // 2) if mode == CONV_3X3_S2 else (2 * H, 2 * W))
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=BF16)
+    check(lib().emu_conv3x3_nhwc_bf16(_p(x), _p(w), _p(bias), _p(bias2), bias2.stride(0) if bias2 is not None else 0, _p(res),
+                                      _p(y), B, H, W, Cin, Cout, mode, stream()), "emu_conv3x3_nhwc_bf16")
+    return y

@@ -1,0 +1,359 @@
+"""SDXL-style UNet denoiser + Euler scheduler: host side of the ``emu_unet_*`` C ABI.
+
+Plays the role of diffusers' ``UNet2DConditionModel`` + ``EulerDiscreteScheduler`` inside the reference's
+``EmuVisualGeneration`` (Emu2/emu/diffusion.py:30-166; configs conf/diffusion_config/{unet,scheduler}/*.json).
+Weights keep diffusers' state-dict names (what the reference checkpoint stores under ``unet.``) and are re-packed once:
+
+  * conv kernels  [Cout, Cin, 3, 3] -> [Cout, (ky, kx, ci)]   (implicit-GEMM order for NHWC activations)
+  * attn1 to_q/to_k/to_v -> one [3C, C] matrix; attn2 to_k/to_v -> one [2C, 1792] matrix (K/V of the fixed prompt are
+    computed once per generation, not per step)
+  * GEGLU proj [8C, C] -> rows interleaved (hidden_j, gate_j) so ``hidden * gelu(gate)`` is a lane-local GEMM epilogue
+  * every resnet's time_emb_proj concatenated into one [sum(Cout), 1280] matrix (one GEMV per step)
+
+PARITY UNPINNED: diffusers is not available to run (see oracle/unet_ref.py); tests compare against that restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import UNetCfgC, check, lib
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class UNetCfg:
+    """Fields of conf/diffusion_config/unet/config.json that the forward pass uses."""
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, int, int] = (320, 640, 1280)
+    layers_per_block: int = 2
+    transformer_layers_per_block: Tuple[int, int, int] = (1, 2, 10)
+    num_heads: Tuple[int, int, int] = (5, 10, 20)            # json "attention_head_dim" (diffusers naming quirk)
+    down_attention: Tuple[bool, bool, bool] = (False, True, True)
+    cross_attention_dim: int = 1792
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 3328
+
+    @property
+    def temb_dim(self) -> int:
+        return self.block_out_channels[0] * 4
+
+
+def _resnet_shapes(s, p, cin, cout, temb):
+    s[p + "norm1.weight"] = (cin,); s[p + "norm1.bias"] = (cin,)
+    s[p + "conv1.weight"] = (cout, cin, 3, 3); s[p + "conv1.bias"] = (cout,)
+    s[p + "time_emb_proj.weight"] = (cout, temb); s[p + "time_emb_proj.bias"] = (cout,)
+    s[p + "norm2.weight"] = (cout,); s[p + "norm2.bias"] = (cout,)
+    s[p + "conv2.weight"] = (cout, cout, 3, 3); s[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        s[p + "conv_shortcut.weight"] = (cout, cin, 1, 1); s[p + "conv_shortcut.bias"] = (cout,)
+
+
+def _transformer_shapes(s, p, c, depth, cross):
+    s[p + "norm.weight"] = (c,); s[p + "norm.bias"] = (c,)
+    s[p + "proj_in.weight"] = (c, c); s[p + "proj_in.bias"] = (c,)
+    for k in range(depth):
+        b = p + f"transformer_blocks.{k}."
+        for n in ("norm1", "norm2", "norm3"):
+            s[b + n + ".weight"] = (c,); s[b + n + ".bias"] = (c,)
+        for a, kd in (("attn1", c), ("attn2", cross)):
+            s[b + a + ".to_q.weight"] = (c, c)
+            s[b + a + ".to_k.weight"] = (c, kd)
+            s[b + a + ".to_v.weight"] = (c, kd)
+            s[b + a + ".to_out.0.weight"] = (c, c); s[b + a + ".to_out.0.bias"] = (c,)
+        s[b + "ff.net.0.proj.weight"] = (8 * c, c); s[b + "ff.net.0.proj.bias"] = (8 * c,)
+        s[b + "ff.net.2.weight"] = (c, 4 * c); s[b + "ff.net.2.bias"] = (c,)
+    s[p + "proj_out.weight"] = (c, c); s[p + "proj_out.bias"] = (c,)
+
+
+def structure(cfg: UNetCfg):
+    """Resnets and transformers in traversal order (down i,j ; mid ; up i,j) with their channel bookkeeping --
+    the same walk as emu_unet_finalize in csrc/unet_engine.hip."""
+    ch = cfg.block_out_channels
+    resnets, transformers, samplers = [], [], []
+    cin = ch[0]
+    for i in range(3):
+        for j in range(cfg.layers_per_block):
+            resnets.append((f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else ch[i], ch[i]))
+            if cfg.down_attention[i]:
+                transformers.append((f"down_blocks.{i}.attentions.{j}.", ch[i], cfg.transformer_layers_per_block[i]))
+        if i < 2:
+            samplers.append((f"down_blocks.{i}.downsamplers.0.conv", ch[i]))
+        cin = ch[i]
+    resnets.append(("mid_block.resnets.0.", ch[2], ch[2]))
+    transformers.append(("mid_block.attentions.0.", ch[2], cfg.transformer_layers_per_block[2]))
+    resnets.append(("mid_block.resnets.1.", ch[2], ch[2]))
+    out = ch[2]
+    for i in range(3):
+        lvl = 2 - i
+        prev, out = out, ch[lvl]
+        inp = ch[max(lvl - 1, 0)]
+        for j in range(cfg.layers_per_block + 1):
+            skip = inp if j == cfg.layers_per_block else out
+            first = prev if j == 0 else out
+            resnets.append((f"up_blocks.{i}.resnets.{j}.", first + skip, out))
+            if cfg.down_attention[lvl]:
+                transformers.append((f"up_blocks.{i}.attentions.{j}.", out, cfg.transformer_layers_per_block[lvl]))
+        if i < 2:
+            samplers.append((f"up_blocks.{i}.upsamplers.0.conv", out))
+    return resnets, transformers, samplers
+
+
+def unet_param_shapes(cfg: UNetCfg = UNetCfg()) -> "OrderedDict[str, Tuple[int, ...]]":
+    """diffusers UNet2DConditionModel state-dict keys and shapes for this config (2.53 B parameters at defaults)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    ch, T = cfg.block_out_channels, cfg.temb_dim
+    s["conv_in.weight"] = (ch[0], cfg.in_channels, 3, 3); s["conv_in.bias"] = (ch[0],)
+    s["time_embedding.linear_1.weight"] = (T, ch[0]); s["time_embedding.linear_1.bias"] = (T,)
+    s["time_embedding.linear_2.weight"] = (T, T); s["time_embedding.linear_2.bias"] = (T,)
+    s["add_embedding.linear_1.weight"] = (T, cfg.projection_class_embeddings_input_dim)
+    s["add_embedding.linear_1.bias"] = (T,)
+    s["add_embedding.linear_2.weight"] = (T, T); s["add_embedding.linear_2.bias"] = (T,)
+    resnets, transformers, samplers = structure(cfg)
+    for p, cin, cout in resnets:
+        _resnet_shapes(s, p, cin, cout, T)
+    for p, c, depth in transformers:
+        _transformer_shapes(s, p, c, depth, cfg.cross_attention_dim)
+    for p, c in samplers:
+        s[p + ".weight"] = (c, c, 3, 3); s[p + ".bias"] = (c,)
+    s["conv_norm_out.weight"] = (ch[0],); s["conv_norm_out.bias"] = (ch[0],)
+    s["conv_out.weight"] = (cfg.out_channels, ch[0], 3, 3); s["conv_out.bias"] = (cfg.out_channels,)
+    return s
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): fp32 [N, dim] = [cos | sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    e = t.to(torch.float32)[:, None] * freqs[None, :]
+    return torch.cat([torch.cos(e), torch.sin(e)], dim=-1)
+
+
+class EulerDiscreteSchedule:
+    """Host-side tables of diffusers' EulerDiscreteScheduler as configured by scheduler_config.json
+    (scaled_linear betas, 'leading' spacing, steps_offset 1, linear sigma interpolation, epsilon prediction)."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0)
+        self._train_sigmas = (((1 - ac) / ac) ** 0.5).numpy()
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+        self.timesteps = self.sigmas = None
+
+    def set_timesteps(self, n: int):
+        ratio = self.num_train_timesteps // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.float32) + self.steps_offset
+        sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)
+        self.timesteps = torch.from_numpy(ts)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        return self
+
+    @property
+    def init_noise_sigma(self) -> float:
+        return float((self.sigmas.max() ** 2 + 1) ** 0.5)
+
+
+class UNetEngine:
+    def __init__(self, cfg: UNetCfg, ctx):
+        self.cfg, self.ctx, self.device = cfg, ctx, ctx.device
+        self.kpad_in = (9 * cfg.in_channels + 63) // 64 * 64
+        c = UNetCfgC(cfg.in_channels, cfg.out_channels, (C.c_int * 3)(*cfg.block_out_channels), cfg.layers_per_block,
+                     (C.c_int * 3)(*cfg.transformer_layers_per_block), (C.c_int * 3)(*cfg.num_heads),
+                     (C.c_int * 3)(*[int(a) for a in cfg.down_attention]), cfg.cross_attention_dim, cfg.norm_num_groups,
+                     cfg.norm_eps, cfg.temb_dim, self.kpad_in)
+        h = C.c_void_p()
+        check(lib().emu_unet_create(ctx.handle, C.byref(c), C.byref(h)), "emu_unet_create", ctx.handle)
+        self.handle = h
+        self._keep: Dict[str, torch.Tensor] = {}
+        self.ready = False
+        self._ws = self._cache = None
+        self.schedule: Optional[EulerDiscreteSchedule] = None
+        self._graph = None
+
+    # ------------------------------------------------------------------ weights
+    def _reg(self, name: str, t: torch.Tensor):
+        t = t.to(device=self.device, dtype=BF16).contiguous()
+        self._keep[name] = t
+        check(lib().emu_unet_set_weight(self.handle, name.encode(), t.data_ptr()), "emu_unet_set_weight")
+
+    @staticmethod
+    def _conv(w: torch.Tensor) -> torch.Tensor:
+        return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)             # [Cout, (ky, kx, ci)]
+
+    def load_state_dict(self, sd, prefix: str = "", strict: bool = True):
+        """``sd``: mapping (or iterable of pairs) with diffusers UNet2DConditionModel names, optionally prefixed
+        (the reference pipeline checkpoint uses ``unet.``).  Streaming: tensors are packed as soon as their group is
+        complete and the originals can be dropped by the caller."""
+        cfg = self.cfg
+        items = sd.items() if hasattr(sd, "items") else sd
+        pend: Dict[str, torch.Tensor] = {}
+        want = set(unet_param_shapes(cfg).keys())
+        seen = set()
+        resnets, transformers, samplers = structure(cfg)
+        temb_w: Dict[str, torch.Tensor] = {}
+        temb_b: Dict[str, torch.Tensor] = {}
+        dev = lambda t: t.to(self.device, BF16)
+
+        def flush_block(b: str, c: int):
+            g = lambda k: dev(pend.pop(b + k))
+            self._reg(b + "attn1.qkv.w", torch.cat([g("attn1.to_q.weight"), g("attn1.to_k.weight"), g("attn1.to_v.weight")]))
+            self._reg(b + "attn1.out.w", g("attn1.to_out.0.weight")); self._reg(b + "attn1.out.b", g("attn1.to_out.0.bias"))
+            self._reg(b + "attn2.q.w", g("attn2.to_q.weight"))
+            self._reg(b + "attn2.kv.w", torch.cat([g("attn2.to_k.weight"), g("attn2.to_v.weight")]))
+            self._reg(b + "attn2.out.w", g("attn2.to_out.0.weight")); self._reg(b + "attn2.out.b", g("attn2.to_out.0.bias"))
+            w, bb = g("ff.net.0.proj.weight"), g("ff.net.0.proj.bias")
+            self._reg(b + "ff.geglu.w", torch.stack([w[:4 * c], w[4 * c:]], dim=1).reshape(8 * c, c))
+            self._reg(b + "ff.geglu.b", torch.stack([bb[:4 * c], bb[4 * c:]], dim=1).reshape(8 * c))
+            self._reg(b + "ff.out.w", g("ff.net.2.weight")); self._reg(b + "ff.out.b", g("ff.net.2.bias"))
+            for n in ("norm1", "norm2", "norm3"):
+                self._reg(b + n + ".g", g(n + ".weight")); self._reg(b + n + ".b", g(n + ".bias"))
+
+        block_keys = {}
+        for p, c, depth in transformers:
+            for k in range(depth):
+                b = p + f"transformer_blocks.{k}."
+                ks = [kk[len(b):] for kk in want if kk.startswith(b)]
+                block_keys[b] = (set(ks), c)
+
+        for name, t in items:
+            if prefix:
+                if not name.startswith(prefix):
+                    continue
+                name = name[len(prefix):]
+            if name not in want:
+                if strict:
+                    raise RuntimeError(f"unexpected UNet tensor {name!r}")
+                continue
+            seen.add(name)
+            if ".transformer_blocks." in name:
+                b = name[: name.index(".transformer_blocks.") + len(".transformer_blocks.")]
+                b = b + name[len(b):].split(".", 1)[0] + "."
+                pend[name] = t
+                ks, c = block_keys[b]
+                if all((b + k) in pend for k in ks):
+                    flush_block(b, c)
+            elif name.endswith("time_emb_proj.weight"):
+                temb_w[name[: -len("time_emb_proj.weight")]] = dev(t)
+            elif name.endswith("time_emb_proj.bias"):
+                temb_b[name[: -len("time_emb_proj.bias")]] = dev(t)
+            elif name == "conv_in.weight":
+                w = self._conv(dev(t))
+                wp = torch.zeros(w.shape[0], self.kpad_in, device=self.device, dtype=BF16)
+                wp[:, : w.shape[1]] = w
+                self._reg("conv_in.w", wp)
+            elif name.endswith("conv_shortcut.weight"):
+                self._reg(name[: -len("conv_shortcut.weight")] + "shortcut.w", dev(t).reshape(t.shape[0], t.shape[1]))
+            elif name.endswith("conv_shortcut.bias"):
+                self._reg(name[: -len("conv_shortcut.bias")] + "shortcut.b", t)
+            elif t.dim() == 4:
+                self._reg(name[: -len("weight")] + "w", self._conv(dev(t)))
+            elif name.endswith(".weight"):
+                suffix = "g" if (".norm" in name or name.startswith("conv_norm_out")) and t.dim() == 1 else "w"
+                self._reg(name[: -len("weight")] + suffix, t)
+            elif name.endswith(".bias"):
+                self._reg(name[: -len("bias")] + "b", t)
+        missing = sorted(want - seen)
+        if missing:
+            if strict:
+                raise RuntimeError(f"missing UNet tensors: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+            return missing
+        order = [p for p, _, _ in resnets]
+        self._reg("temb_proj_all.w", torch.cat([temb_w[p] for p in order], dim=0))
+        self._reg("temb_proj_all.b", torch.cat([temb_b[p] for p in order], dim=0))
+        check(lib().emu_unet_finalize(self.handle), "emu_unet_finalize", self.ctx.handle)
+        assert lib().emu_unet_temb_total(self.handle) == sum(c for _, _, c in resnets)
+        self.ready = True
+        return []
+
+    # ------------------------------------------------------------------ per-generation state
+    def _workspace(self, H: int, W: int) -> torch.Tensor:
+        need = lib().emu_unet_workspace_bytes(self.handle, H, W)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+            self._graph = None
+        return self._ws
+
+    def set_timesteps(self, n: int):
+        self.schedule = EulerDiscreteSchedule().set_timesteps(n)
+        self.temb_table = timestep_embedding(self.schedule.timesteps, self.cfg.block_out_channels[0]).to(BF16).to(self.device)
+        self.sigmas = self.schedule.sigmas.to(self.device)
+        self.step_dev = torch.zeros(1, device=self.device, dtype=torch.int32)
+        self._graph = None
+        return self.schedule
+
+    def set_context(self, prompt_embeds: torch.Tensor, height: int, width: int, original_size=(1024, 1024), crop=(0, 0)):
+        """prompt_embeds [2, n, 1792] (cond FIRST, then the negative prompt; diffusion.py:202,210).  Builds
+        text_embeds = mean over tokens (:113) and the 12 time_ids (:108-110), runs the once-per-prompt GEMMs."""
+        assert self.ready and prompt_embeds.dim() == 3 and prompt_embeds.shape[0] == 2
+        pe = prompt_embeds.to(self.device, BF16).contiguous()
+        n = pe.shape[1]
+        text_embeds = pe.mean(dim=1)                                              # bf16 mean, like torch.mean on bf16
+        time_ids = torch.tensor(list(original_size) + list(crop) + [height, width] , dtype=torch.float32)
+        tid = timestep_embedding(torch.cat([time_ids, time_ids]), self.cfg.addition_time_embed_dim).reshape(2, -1)
+        add_in = torch.cat([text_embeds, tid.to(BF16).to(self.device)], dim=-1).contiguous()
+        assert add_in.shape[1] == self.cfg.projection_class_embeddings_input_dim, add_in.shape
+        need = lib().emu_unet_context_bytes(self.handle, n)
+        if self._cache is None or self._cache.numel() < need:
+            self._cache = torch.empty(need, device=self.device, dtype=torch.uint8)
+            self._graph = None
+        ws = self._workspace(8, 8)
+        check(lib().emu_unet_set_context(self.handle, pe.data_ptr(), n, add_in.data_ptr(), add_in.shape[1],
+                                         self._cache.data_ptr(), self._cache.numel(), ws.data_ptr(), ws.numel(), ops.stream()),
+              "emu_unet_set_context", self.ctx.handle)
+
+    # ------------------------------------------------------------------ compute
+    def forward(self, sample: torch.Tensor, step_index: int) -> torch.Tensor:
+        """Bare UNet on ONE latent [1,4,H,W] duplicated for (cond, uncond) and scaled by 1/sqrt(sigma_i^2+1):
+        returns the noise prediction [2,4,H,W] bf16 (parity-test entry)."""
+        _, Cc, H, W = sample.shape
+        x = sample.to(self.device, BF16).contiguous()
+        ws = self._workspace(H, W)
+        eps = torch.empty(2 * H * W, Cc, device=self.device, dtype=BF16)
+        st = torch.tensor([step_index], device=self.device, dtype=torch.int32)
+        check(lib().emu_unet_forward(self.handle, x.data_ptr(), H, W, self.temb_table.data_ptr(), self.sigmas.data_ptr(),
+                                     st.data_ptr(), eps.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream()),
+              "emu_unet_forward", self.ctx.handle)
+        return eps.view(2, H, W, Cc).permute(0, 3, 1, 2).contiguous()
+
+    def step(self, latents: torch.Tensor, guidance: float):
+        """One denoise step in place on latents [1,4,H,W] bf16 (advances the device-side step counter)."""
+        _, _, H, W = latents.shape
+        ws = self._workspace(H, W)
+        check(lib().emu_unet_step(self.handle, latents.data_ptr(), H, W, self.temb_table.data_ptr(), self.sigmas.data_ptr(),
+                                  self.step_dev.data_ptr(), float(guidance), ws.data_ptr(), ws.numel(), ops.stream()),
+              "emu_unet_step", self.ctx.handle)
+
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, guidance: float = 3.0, use_graph: bool = True, steps: Optional[int] = None):
+        """The loop of diffusion.py:130-149 on latents [1,4,H,W] (already multiplied by init_noise_sigma), in place.
+        With ``use_graph`` the ~900-launch step is captured once into a hipGraph and replayed."""
+        assert latents.is_cuda and latents.dtype == BF16 and latents.is_contiguous() and latents.shape[0] == 1
+        n = len(self.schedule.timesteps) if steps is None else steps
+        self._workspace(latents.shape[2], latents.shape[3])
+        i = 0
+        if use_graph and n > 1:
+            key = (latents.data_ptr(), float(guidance), tuple(latents.shape))
+            if self._graph is None or self._graph[0] != key:
+                self.step(latents, guidance); i += 1                      # warm-up outside capture
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.step(latents, guidance)
+                self._graph = (key, g)
+            g = self._graph[1]
+            for _ in range(i, n):
+                g.replay()
+        else:
+            for _ in range(n):
+                self.step(latents, guidance)
+        return latents

@@ -160,6 +160,52 @@ size_t emu_vit_workspace_bytes(const emu_vit* m, int B);
 int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int B, void* out_tokens, void* workspace,
                     size_t ws_bytes, emu_stream_t s);
 
+/* ---- SDXL-style UNet denoise engine ---------------------------------------------------------------------
+ * One call = one iteration of EmuVisualGeneration's denoising loop (Emu2/emu/diffusion.py:130-149):
+ * cat([latents]*2) -> scheduler.scale_model_input -> UNet2DConditionModel (conf/diffusion_config/unet/config.json)
+ * -> chunk(cond, uncond) -> guidance -> EulerDiscreteScheduler.step (conf/.../scheduler_config.json).
+ * Weights are registered by PACKED name (see emu_amd/unet.py: conv weights [Cout, 3,3,Cin], fused attn1 qkv / attn2 kv,
+ * interleaved GEGLU rows, all time_emb_proj concatenated into temb_proj_all).  Parity of this path is UNPINNED
+ * (diffusers is not available to run; see oracle/unet_ref.py). */
+/* GroupNorm(groups, eps)(+SiLU) over an NHWC activation [B, HW, C] (diffusers ResnetBlock2D / Transformer2DModel norms) */
+size_t emu_groupnorm_ws_bytes(int B, int HW, int C);
+int emu_groupnorm_nhwc_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int B, int HW, int C,
+                            int groups, float eps, int silu, emu_stream_t s);
+/* 3x3 convolution, padding 1, as an implicit GEMM over NHWC input [B,Hin,Win,Cin] (Cin % 64 == 0), weights
+ * [Cout, 3, 3, Cin].  mode 1: stride 1; 2: stride 2 (Downsample2D); 3: nearest x2 upsample fused (Upsample2D).
+ * y = bf16(res + bf16(bf16(conv + bias) + bias2[b]))  (bias2: per-batch rows, e.g. the time embedding projection) */
+int emu_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, const void* bias2, int ld_bias2, const void* res,
+                          void* y, int B, int Hin, int Win, int Cin, int Cout, int mode, emu_stream_t s);
+
+typedef struct emu_unet emu_unet;
+typedef struct {
+    int in_ch, out_ch;
+    int ch[3];
+    int layers_per_block;
+    int depth[3], heads[3], attn[3];
+    int cross_dim, groups;
+    float gn_eps;
+    int temb_dim, kpad_in;
+} emu_unet_cfg;
+int emu_unet_create(emu_ctx* ctx, const emu_unet_cfg* cfg, emu_unet** out);
+void emu_unet_destroy(emu_unet* u);
+int emu_unet_set_weight(emu_unet* u, const char* name, const void* ptr);
+int emu_unet_finalize(emu_unet* u);                       /* -2 + emu_last_error: first missing tensor        */
+int emu_unet_temb_total(const emu_unet* u);               /* rows of temb_proj_all (sum of resnet out channels) */
+size_t emu_unet_workspace_bytes(const emu_unet* u, int H, int W);
+size_t emu_unet_context_bytes(const emu_unet* u, int n_ctx);
+/* once per prompt: cross-attention K / V^T of every block from ctx_tokens [2, n_ctx, cross] (cond FIRST,
+ * diffusion.py:202,210) and the text_time embedding from add_in [2, add_dim] = cat(mean(prompt), Timesteps(time_ids)) */
+int emu_unet_set_context(emu_unet* u, const void* ctx_tokens, int n_ctx, const void* add_in, int add_dim, void* cache,
+                         size_t cache_bytes, void* workspace, size_t ws_bytes, emu_stream_t s);
+/* one denoise step in place on latents NCHW [1, 4, H, W] bf16.  temb_table [steps, ch0] bf16 = Timesteps(t_i);
+ * sigmas [steps+1] fp32; step_dev: device int32 step index, incremented by the call (graph replay advances it). */
+int emu_unet_step(emu_unet* u, void* latents, int H, int W, const void* temb_table, const void* sigmas, int32_t* step_dev,
+                  float guidance, void* workspace, size_t ws_bytes, emu_stream_t s);
+/* bare UNet forward (parity tests): eps_out NHWC [2*H*W, 4] for cat([latents]*2) / sqrt(sigmas[step]^2 + 1) */
+int emu_unet_forward(emu_unet* u, const void* latents, int H, int W, const void* temb_table, const void* sigmas,
+                     const int32_t* step_dev, void* eps_out, void* workspace, size_t ws_bytes, emu_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
