@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--prompt-tokens", type=int, default=512)
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-denoise", action="store_true", help="skip the UNet denoise leg")
+    p.add_argument("--denoise-steps", type=int, default=50)
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
@@ -117,6 +119,53 @@ def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
             "sample": f"1 true-shape LLaMA-33B decoder layer x{n} + lm_head x{m} ({dn}, ctx {ctx_len}, batch 1) on {th} of "
                       f"{ncpu} host threads (fastest of a dtype/thread calibration); tokens/s = 1/(60*{t_layer * 1e3:.1f} ms "
                       f"+ {t_head * 1e3:.1f} ms)"}
+
+
+UNET_FLOPS_PER_STEP = 13.48e12      # one denoise step (CFG batch 2) at 128x128 latents, 64 ctx tokens
+
+
+def denoise_leg(ctx, dev, steps, world, dist):
+    """prompt_embeds randn(2,64,1792) seed 3, latents randn(1,4,128,128) seed 4, 50 Euler steps,
+    CFG 3.0, 1024x1024; synthetic UNet weights (2.53 B params) generated on the GPU.  The timed region is exactly the
+    `steps`-iteration loop (scale_model_input -> UNet -> CFG -> Euler step per iteration), hipGraph replayed.
+    Across GPUs this path does not shard: every rank runs an independent replica; aggregate = sum."""
+    from emu_amd import synth
+    from emu_amd.unet import UNetCfg, UNetEngine, unet_param_shapes
+    cfg = UNetCfg()
+    eng = UNetEngine(cfg, ctx)
+    eng.load_state_dict(synth.iter_synth(unet_param_shapes(cfg), seed=0, device=dev, dtype=torch.bfloat16))
+    g = torch.Generator().manual_seed(3)
+    prompt = torch.randn(2, 64, 1792, generator=g).to(torch.bfloat16).to(dev)
+    sch = eng.set_timesteps(steps)
+    eng.set_context(prompt, 1024, 1024)
+    g = torch.Generator().manual_seed(4)
+    lat0 = (torch.randn(1, 4, 128, 128, generator=g) * sch.init_noise_sigma).to(torch.bfloat16).to(dev)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lat = lat0.clone()
+    with torch.no_grad():
+        eng.denoise(lat, 3.0, use_graph=True, steps=3)                  # warm-up: eager step + graph capture + replay
+        eng.set_timesteps(steps)
+        lat.copy_(lat0)
+        sync(); t = time.perf_counter()
+        eng.denoise(lat, 3.0, use_graph=True, steps=steps)
+        sync(); dt = time.perf_counter() - t
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    per_gpu = steps / dt
+    finite = bool(torch.isfinite(lat.float()).all())
+    return {"metric": "diffusion denoise steps/sec (UNet fwd CFG batch 2 + guidance + Euler step, 1024x1024, 64 ctx tokens)",
+            "value": per_gpu * world, "unit": "steps/s", "per_gpu": per_gpu, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "scaling": "replicas only (independent images per GPU)", "launch": "hipGraph replay", "finite_output": finite,
+            "roofline": {"bound": "mfma", "achieved": UNET_FLOPS_PER_STEP * per_gpu / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": UNET_FLOPS_PER_STEP * per_gpu / MFMA_BF16_PEAK,
+                         "flops_per_step": UNET_FLOPS_PER_STEP}}
 
 
 def main():
@@ -243,6 +292,11 @@ def main():
     kv_bytes = 2 * lcfg.num_hidden_layers * (lm.plan.heads_local * lcfg.head_dim) * 2 * ctx_mid
     ids_host = out_ids[: a.warmup + a.steps + 1, 0].tolist()
 
+    # ---- second half of the metric: SDXL-style UNet denoise (BASELINE.json configs[3]), replicas only across GPUs
+    denoise = None
+    if not a.no_denoise:
+        denoise = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None)
+
     if rank == 0:
         prefill_flops = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
                                                    + 2 * S * S * lcfg.hidden_size)
@@ -269,6 +323,8 @@ def main():
                       "weight_bytes_per_token_per_gpu": lm.weight_bytes_per_token(), "kv_bytes_per_token_per_gpu": kv_bytes,
                       "first_tokens": ids_host[:8]},
         }
+        if denoise is not None:
+            res["denoise"] = denoise
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_seconds, S, VOCAB_EMU2_CHAT)

@@ -229,7 +229,7 @@ LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
     w.act = (bf16_t*)take(M * (size_t)c.ffn_local * 2);
     const size_t spad = (size_t)((m->s_max + 63) / 64) * 64;
     w.vt = (bf16_t*)take(T > 1 ? (size_t)Bn * HD * spad * 2 : 0);
-    w.dec = (float*)take(emu_decode_attn_ws_bytes(Bn, c.heads_local, c.head_dim, m->s_max > 0 ? m->s_max : 1));
+    w.dec = (float*)take(decode_fused_ws_floats(Bn, c.heads_local, c.head_dim, m->s_max > 0 ? m->s_max : 1) * sizeof(float));
     w.total = off;
     return w;
 }
@@ -303,13 +303,14 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
             TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s));
         }
-        { RopeKvArgs r{w.qkv, m->cos, m->sin, pos, slot, kc, vc, Bn, T, Hl, D, m->s_max};
-          TRY(cx, launch_rope_kv(r, s)); }
         if (T == 1) {
-            DecodeAttnArgs a{w.qkv, (long)3 * HD, (long)D, kc, vc, w.attn, (long)HD, (long)D, kstart, ctx_dev, w.dec,
-                             Bn, Hl, D, m->s_max, ctx, ctx, scale};
-            TRY(cx, launch_decode_attn(a, s));
+            // RoPE + KV append + attention in one launch; context = slot + 1 is read on the device (graph replay)
+            DecodeFusedArgs a{w.qkv, m->cos, m->sin, pos, slot, kc, vc, w.attn, (long)HD, (long)D, kstart, w.dec,
+                              Bn, Hl, D, m->s_max, ctx, scale};
+            TRY(cx, launch_decode_fused(a, s));
         } else {
+            { RopeKvArgs r{w.qkv, m->cos, m->sin, pos, slot, kc, vc, Bn, T, Hl, D, m->s_max};
+              TRY(cx, launch_rope_kv(r, s)); }
             TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, w.vt, Bn, Hl, ctx, D, spad};
             TRY(cx, launch_transpose_v(tv, s));
             FlashArgs f{w.qkv, (long)T * 3 * HD, (long)D, (long)3 * HD,

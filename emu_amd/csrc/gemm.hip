@@ -12,6 +12,8 @@
 // Replaces the torch Linear calls on the reference hot path: Emu2/emu/eva_vit.py:106,112,198,250 (ViT),
 // transformers LlamaAttention/LlamaMLP reached from Emu2/emu/emu.py:133-138,213-229 (prefill),
 // project_up/down emu.py:201,147.  Algorithmic FLOPs = 2*M*N*K.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -22,6 +24,83 @@ constexpr int TILE_BYTES = 128 * BK * 2;     // 16 KiB per operand tile
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {       // 128-byte rows, 8 slots of 16 B
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+
+// Epilogue for one accumulator quad: lane-local 4 consecutive output columns nb..nb+3 of row m.
+template <int EPI>
+__device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, float (&v)[4]) {
+    const bool full = (nb + 3) < a.N;
+    if (full) {
+        if (a.bias) {
+            const u32x2 bv = *reinterpret_cast<const u32x2*>(a.bias + nb);
+            v[0] += bflo(bv.x); v[1] += bfhi(bv.x); v[2] += bflo(bv.y); v[3] += bfhi(bv.y);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bfround(v[e]);
+        if (a.bias2) {
+            const u32x2 bv = *reinterpret_cast<const u32x2*>(a.bias2 + (size_t)(m / a.rows_per_batch) * a.ld_bias2 + nb);
+            v[0] = bfround(v[0] + bflo(bv.x)); v[1] = bfround(v[1] + bfhi(bv.x));
+            v[2] = bfround(v[2] + bflo(bv.y)); v[3] = bfround(v[3] + bfhi(bv.y));
+        }
+        if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) {
+            // interleaved rows (2j, 2j+1): SwiGLU = (gate, up) -> bf16(bf16(silu(gate)) * up)
+            //                               GEGLU  = (hidden, gate) -> bf16(hidden * bf16(gelu(gate)))
+            float o0, o1;
+            if constexpr (EPI == EPI_SWIGLU) {
+                o0 = bfround(silu(v[0])) * v[1];
+                o1 = bfround(silu(v[2])) * v[3];
+            } else {
+                o0 = v[0] * bfround(gelu_erf(v[1]));
+                o1 = v[2] * bfround(gelu_erf(v[3]));
+            }
+            *reinterpret_cast<uint32_t*>(a.C + (size_t)m * a.ldc + (nb >> 1)) = packbf(o0, o1);
+        } else {
+            if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bfround(silu(v[e]));
+            }
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bfround(gelu_erf(v[e]));
+            }
+            if constexpr (EPI == EPI_RESID) {
+                const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (size_t)m * a.ldres + nb);
+                v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
+            }
+            u32x2 ov;
+            ov.x = packbf(v[0], v[1]);
+            ov.y = packbf(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + nb) = ov;
+        }
+        return;
+    }
+    // ragged last columns (N % 4 != 0): scalar path
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (nb + e < a.N) {
+            if (a.bias) v[e] += bf2f(a.bias[nb + e]);
+            v[e] = bfround(v[e]);
+            if (a.bias2) v[e] = bfround(v[e] + bf2f(a.bias2[(size_t)(m / a.rows_per_batch) * a.ld_bias2 + nb + e]));
+        }
+    }
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) {
+        if (nb + 1 < a.N) {
+            const float o0 = (EPI == EPI_SWIGLU) ? bfround(silu(v[0])) * v[1] : v[0] * bfround(gelu_erf(v[1]));
+            a.C[(size_t)m * a.ldc + (nb >> 1)] = f2bf(o0);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (nb + e < a.N) {
+                float t = v[e];
+                if constexpr (EPI == EPI_SILU) t = bfround(silu(t));
+                if constexpr (EPI == EPI_GELU) t = bfround(gelu_erf(t));
+                if constexpr (EPI == EPI_RESID) t += bf2f(a.res[(size_t)m * a.ldres + nb + e]);
+                a.C[(size_t)m * a.ldc + nb + e] = f2bf(t);
+            }
+        }
+    }
 }
 
 template <int EPI, bool CONV>
@@ -149,13 +228,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     }
 
     // epilogue: lane holds, per accumulator, column m and rows n = nb + (r & 3), nb = .. + 8*(r>>2) + 4*hi
-    const bool pair = (EPI == EPI_SWIGLU || EPI == EPI_GEGLU);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + wm * 64 + j * 32 + l31;
         if (m >= a.M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nb = n0 + wn * 64 + i * 32 + 8 * g + 4 * hi;
@@ -163,69 +241,217 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                const bool full = (nb + 3) < a.N;
-                if (a.bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (full || nb + e < a.N) v[e] += bf2f(a.bias[nb + e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = bfround(v[e]);
-                if (a.bias2) {
-                    const bf16_t* b2 = a.bias2 + (size_t)(m / a.rows_per_batch) * a.ld_bias2 + nb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (full || nb + e < a.N) v[e] = bfround(v[e] + bf2f(b2[e]));
-                }
-                if constexpr (pair) {
-                    // interleaved rows (2j, 2j+1): SwiGLU = (gate, up) -> bf16(bf16(silu(gate)) * up)
-                    //                               GEGLU  = (hidden, gate) -> bf16(hidden * bf16(gelu(gate)))
-                    float o0, o1;
-                    if constexpr (EPI == EPI_SWIGLU) {
-                        o0 = bfround(silu(v[0])) * v[1];
-                        o1 = bfround(silu(v[2])) * v[3];
-                    } else {
-                        o0 = v[0] * bfround(gelu_erf(v[1]));
-                        o1 = v[2] * bfround(gelu_erf(v[3]));
-                    }
-                    bf16_t* dst = a.C + (size_t)m * a.ldc + (nb >> 1);
-                    if (full) {
-                        *reinterpret_cast<uint32_t*>(dst) = packbf(o0, o1);
-                    } else {
-                        if (nb + 1 < a.N) dst[0] = f2bf(o0);
-                    }
-                } else {
-                    if constexpr (EPI == EPI_SILU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = bfround(silu(v[e]));
-                    }
-                    if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = bfround(gelu_erf(v[e]));
-                    }
-                    bf16_t* dst = a.C + (size_t)m * a.ldc + nb;
-                    if (full) {
-                        if constexpr (EPI == EPI_RESID) {
-                            const u32x2 rv = *reinterpret_cast<const u32x2*>(a.res + (size_t)m * a.ldres + nb);
-                            v[0] += bflo(rv.x); v[1] += bfhi(rv.x); v[2] += bflo(rv.y); v[3] += bfhi(rv.y);
-                        }
-                        u32x2 ov;
-                        ov.x = packbf(v[0], v[1]);
-                        ov.y = packbf(v[2], v[3]);
-                        *reinterpret_cast<u32x2*>(dst) = ov;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (nb + e < a.N) {
-                                float t = v[e];
-                                if constexpr (EPI == EPI_RESID) t += bf2f(a.res[(size_t)m * a.ldres + nb + e]);
-                                dst[e] = f2bf(t);
-                            }
-                        }
-                    }
-                }
+                store_quad<EPI>(a, m, nb, v);
             }
-        }
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------ v2 pipeline
+// Same tile math as gemm_nt_kernel, different memory pipeline: operands go global -> LDS directly with
+// global_load_lds (16 B per lane, no VGPR staging, no ds_write pass) into a 4-stage LDS ring, and the loads of tiles
+// t+1, t+2 stay in flight ACROSS the per-tile barrier (counted s_waitcnt vmcnt(N), raw s_barrier), so HBM/L2 latency
+// (~2-3k cycles under load) is covered by three tiles of MFMA work instead of one.  An LDS-DMA instruction writes
+// lane-linear (wave base + lane*16), so the bank-conflict swizzle is applied to the per-lane SOURCE address and undone
+// by the same XOR on the ds_read side.  MF = 32-row m-fragments per wave: 2 -> 128x128 tile, 1 -> 128(n) x 64(m) tile
+// for problems with too few 128x128 tiles to fill 256 CUs.  Implicit-GEMM conv taps that fall outside the image read a
+// 16-byte zero buffer instead of the activation.
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Tile configuration: WN x WM waves, each owning NF x MF 32x32 accumulators; NSTG-deep LDS ring of 64-wide k tiles.
+template <int WN_, int WM_, int NF_, int MF_, int NSTG_>
+struct TileCfg {
+    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_;
+    static constexpr int THREADS = WN * WM * 64;
+    static constexpr int BNv = WN * NF * 32, BMv = WM * MF * 32;
+    static constexpr int W_BYTES = BNv * 128, A_BYTES = BMv * 128, ST_BYTES = W_BYTES + A_BYTES;
+    static constexpr int NLW = (BNv * 8) / THREADS, NLA = (BMv * 8) / THREADS, LPT = NLW + NLA;   // LDS-DMA per thread per tile
+    static_assert((BNv * 8) % THREADS == 0 && (BMv * 8) % THREADS == 0, "tile rows must split evenly over the waves");
+    static_assert(NSTG * ST_BYTES <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    static_assert((NSTG - 2) * LPT <= 63, "vmcnt field is 6 bits");
+};
+
+template <int EPI, bool CONV, class T>
+__global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
+    constexpr int NW = T::WN * T::WM;                   // waves per workgroup
+    __shared__ __attribute__((aligned(16))) char smem[T::NSTG * T::ST_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / T::WM, wm = wave % T::WM;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int xcd = b & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int tiles_m = (a.M + T::BMv - 1) / T::BMv;
+    const int n0 = (wg / tiles_m) * T::BNv, m0 = (wg % tiles_m) * T::BMv;
+
+    // per-lane source of every LDS-DMA instruction: LDS row r = (i*NW + wave)*8 + lane/8, slot p = lane%8 receives global
+    // chunk c = p ^ ((r >> 1) & 7)
+    const bf16_t* gW[T::NLW];
+    const bf16_t* gA[T::NLA];
+    int pb[T::NLA], py[T::NLA], px[T::NLA], ac[T::NLA];
+#pragma unroll
+    for (int i = 0; i < T::NLW; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        int gn = n0 + r; gn = gn < a.N ? gn : a.N - 1;
+        gW[i] = a.W + (size_t)gn * a.ldw + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < T::NLA; ++i) {
+        const int r = (i * NW + wave) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
+        gA[i] = a.A + (size_t)gm * a.lda + c * 8;
+        ac[i] = c * 8;
+        if constexpr (CONV) {
+            const int hw = a.conv.Hout * a.conv.Wout;
+            pb[i] = gm / hw;
+            const int rr = gm - pb[i] * hw;
+            py[i] = rr / a.conv.Wout;
+            px[i] = rr - py[i] * a.conv.Wout;
+        }
+    }
+    const int nk = a.K / BK;
+    auto issue = [&](int kt, int stage) {
+        kt = kt < nk ? kt : nk - 1;                    // past-the-end tiles re-load the last one (keeps vmcnt counts uniform)
+        const int k0 = kt * BK;
+        char* base = smem + stage * T::ST_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
+        if constexpr (CONV) {
+            const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < T::NLA; ++i) {
+                int yi, xi;
+                bool ok;
+                if (a.conv.mode == CONV_3X3_S2) {
+                    yi = 2 * py[i] + ky - 1; xi = 2 * px[i] + kx - 1;
+                    ok = yi >= 0 && yi < a.conv.Hin && xi >= 0 && xi < a.conv.Win;
+                } else if (a.conv.mode == CONV_3X3_UP2) {
+                    const int yu = py[i] + ky - 1, xu = px[i] + kx - 1;
+                    ok = yu >= 0 && yu < 2 * a.conv.Hin && xu >= 0 && xu < 2 * a.conv.Win;
+                    yi = yu >> 1; xi = xu >> 1;
+                } else {
+                    yi = py[i] + ky - 1; xi = px[i] + kx - 1;
+                    ok = yi >= 0 && yi < a.conv.Hin && xi >= 0 && xi < a.conv.Win;
+                }
+                const size_t off = (((size_t)pb[i] * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin + ci0 + ac[i];
+                const bf16_t* src = ok ? a.A + off : reinterpret_cast<const bf16_t*>(g_zero16);
+                glds16(src, base + T::W_BYTES + i * NW * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T::NLA; ++i) glds16(gA[i] + k0, base + T::W_BYTES + i * NW * 1024);
+        }
+    };
+
+    f32x16_t acc[T::NF][T::MF];
+#pragma unroll
+    for (int i = 0; i < T::NF; ++i)
+#pragma unroll
+        for (int j = 0; j < T::MF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int t = 0; t < T::NSTG - 1; ++t) issue(t, t);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<(T::NSTG - 2) * T::LPT>();          // this wave's share of tile kt has landed
+        __builtin_amdgcn_s_barrier();                  // ... and everyone's; everyone is also done reading tile kt-1
+        issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
+        const char* sW = smem + (kt % T::NSTG) * T::ST_BYTES;
+        const char* sA = sW + T::W_BYTES;
+        // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are in flight under the MFMAs of kk
+        bf16x8_t wf[2][T::NF], af[2][T::MF];
+        auto frags = [&](int kk, int buf) {
+            const int ch = kk * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < T::NF; ++i)
+                wf[buf][i] = *reinterpret_cast<const bf16x8_t*>(sW + lds_off((wn * T::NF + i) * 32 + l31, ch));
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j)
+                af[buf][j] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off((wm * T::MF + j) * 32 + l31, ch));
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk < 3) frags(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);         // keep the next k-step's ds_reads ABOVE this k-step's MFMAs
+#pragma unroll
+            for (int i = 0; i < T::NF; ++i)
+#pragma unroll
+                for (int j = 0; j < T::MF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], af[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
+
+#pragma unroll
+    for (int j = 0; j < T::MF; ++j) {
+        const int m = m0 + (wm * T::MF + j) * 32 + l31;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < T::NF; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi;
+                if (nb >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                store_quad<EPI>(a, m, nb, v);
+            }
+    }
+}
+
+using CfgA = TileCfg<2, 2, 2, 2, 4>;     // 128 x 128, 4 waves, 4-stage ring (128 KiB)
+using CfgB = TileCfg<2, 2, 2, 2, 2>;     // 128 x 128, 4 waves, 2 stages (64 KiB, 2 workgroups per CU)
+using CfgC = TileCfg<4, 2, 2, 2, 3>;     // 256(n) x 128(m), 8 waves, 3 stages (144 KiB)
+using CfgD = TileCfg<4, 2, 2, 4, 2>;     // 256 x 256, 8 waves of 64(n) x 128(m), 2 stages (128 KiB)
+using CfgE = TileCfg<2, 2, 2, 1, 4>;     // 128(n) x 64(m), 4 waves, 4 stages (96 KiB): few-tile problems
+using CfgF = TileCfg<2, 4, 2, 2, 3>;     // 128(n) x 256(m), 8 waves, 3 stages (144 KiB)
+using CfgG = TileCfg<2, 2, 1, 1, 3>;     // 64 x 64, 4 waves, 3 stages (48 KiB, 3 workgroups per CU): latency-bound small GEMMs
+using CfgH = TileCfg<2, 2, 2, 1, 3>;     // 128(n) x 64(m), 4 waves, 3 stages (72 KiB, 2 workgroups per CU)
+
+template <int EPI, bool CONV, class T>
+void launch_cfg(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ((a.M + T::BMv - 1) / T::BMv) * ((a.N + T::BNv - 1) / T::BNv);
+    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(tiles), dim3(T::THREADS), 0, s, a);
+}
+
+inline int tiles_of(const GemmArgs& a, int bn, int bm) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); }
+
+template <int EPI, bool CONV>
+void launch_v2(const GemmArgs& a, hipStream_t s) {
+    static const char* force = getenv("EMU_GEMM_CFG");      // A/B runs: force one configuration
+    char cfg = force ? force[0] : 0;
+    if (!cfg) {
+        // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so large problems take the
+        // 256(n) x 128(m) tile; mid-size ones 128x128 with two workgroups per CU; problems with few tiles (UNet 32x32
+        // level, skinny ViT fc2) take 128 x 64 tiles, 3-stage ring, two workgroups per CU (measured: tools/kbench.py).
+        if (tiles_of(a, 256, 128) >= 512) cfg = 'C';
+        else if (tiles_of(a, 128, 128) >= 320) cfg = 'B';
+        else cfg = 'H';
+    }
+    switch (cfg) {
+        case 'C': launch_cfg<EPI, CONV, CfgC>(a, s); break;
+        case 'D': launch_cfg<EPI, CONV, CfgD>(a, s); break;
+        case 'H': launch_cfg<EPI, CONV, CfgH>(a, s); break;
+        default:  launch_cfg<EPI, CONV, CfgB>(a, s); break;
+    }
+}
+
 
 }  // namespace
 
@@ -236,12 +462,23 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.bias2 && a.rows_per_batch < 1) return -22;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const dim3 grid(tiles), block(256);
+    static const bool force_v1 = getenv("EMU_GEMM_V1") != nullptr;
+    const bool v2 = !force_v1 && (a.K % BK) == 0;
     if (a.conv.mode != CONV_NONE) {
         const ConvGeom& g = a.conv;
         if ((g.Cin & 63) || a.K != 9 * g.Cin || a.M % (g.Hout * g.Wout)) return -22;
         if (g.mode == CONV_3X3 && (g.Hout != g.Hin || g.Wout != g.Win)) return -22;
         if (g.mode == CONV_3X3_S2 && (g.Hout != (g.Hin + 1) / 2 || g.Wout != (g.Win + 1) / 2)) return -22;
         if (g.mode == CONV_3X3_UP2 && (g.Hout != 2 * g.Hin || g.Wout != 2 * g.Win)) return -22;
+        if (v2) {
+            switch (a.epi) {
+                case EPI_NONE:  launch_v2<EPI_NONE, true>(a, s); break;
+                case EPI_RESID: launch_v2<EPI_RESID, true>(a, s); break;
+                default: return -22;
+            }
+            EMU_CHECK_LAUNCH();
+            return 0;
+        }
         switch (a.epi) {
             case EPI_NONE:  hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, true>), grid, block, 0, s, a); break;
             case EPI_RESID: hipLaunchKernelGGL((gemm_nt_kernel<EPI_RESID, true>), grid, block, 0, s, a); break;
@@ -251,6 +488,19 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         return 0;
     }
     if (a.lda & 7) return -22;
+    if (v2) {
+        switch (a.epi) {
+            case EPI_NONE:   launch_v2<EPI_NONE, false>(a, s); break;
+            case EPI_RESID:  launch_v2<EPI_RESID, false>(a, s); break;
+            case EPI_SWIGLU: launch_v2<EPI_SWIGLU, false>(a, s); break;
+            case EPI_SILU:   launch_v2<EPI_SILU, false>(a, s); break;
+            case EPI_GELU:   launch_v2<EPI_GELU, false>(a, s); break;
+            case EPI_GEGLU:  launch_v2<EPI_GEGLU, false>(a, s); break;
+            default: return -22;
+        }
+        EMU_CHECK_LAUNCH();
+        return 0;
+    }
     switch (a.epi) {
         case EPI_NONE:   hipLaunchKernelGGL((gemm_nt_kernel<EPI_NONE, false>), grid, block, 0, s, a); break;
         case EPI_RESID:  hipLaunchKernelGGL((gemm_nt_kernel<EPI_RESID, false>), grid, block, 0, s, a); break;

@@ -110,6 +110,23 @@ int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, i
                           int32_t* out_ids, int B, hipStream_t s);
 int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
 
+// Decode step, fused: RoPE of q and of the new k, KV-cache append of the new token, and single-query attention over
+// the cache, in one launch (+ the split combine).  Context length of row b = slot[b] + 1, read on the device.
+struct DecodeFusedArgs {
+    const bf16_t* qkv;                         // [B, 3*H*D] projection rows (q | k | v), not yet rotated
+    const bf16_t* cos; const bf16_t* sin;      // [max_pos, D]
+    const int32_t* pos;                        // [B] RoPE position of the new token
+    const int32_t* slot;                       // [B] cache slot of the new token
+    bf16_t* kcache; bf16_t* vcache;            // [B, H, S_max, D]
+    bf16_t* o; long o_sb, o_sh;
+    const int32_t* kstart;                     // [B] or null
+    float* ws;                                 // decode_fused_ws_floats(B, H, D, ctx_max)
+    int B, H, D, S_max, ctx_max;               // ctx_max sizes the launch (>= max slot + 1)
+    float scale;
+};
+size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max);
+int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s);
+
 // ---- UNet denoise helpers (unet.hip); activations are NHWC: [B, H*W, C] bf16
 // GroupNorm(groups, eps) (+ optional SiLU) over x [B, HW, C]: three launches (partial sums, finalize to per-(b, c)
 // scale/shift, apply).  ws must hold gn_ws_floats(B, C, HW) floats.

@@ -285,11 +285,19 @@ class UNetEngine:
         return self._ws
 
     def set_timesteps(self, n: int):
+        """(Re)build the per-step device tables.  Same ``n`` as before: tables are refreshed IN PLACE and the step counter
+        rewound, so a captured hipGraph stays valid across generations."""
         self.schedule = EulerDiscreteSchedule().set_timesteps(n)
-        self.temb_table = timestep_embedding(self.schedule.timesteps, self.cfg.block_out_channels[0]).to(BF16).to(self.device)
-        self.sigmas = self.schedule.sigmas.to(self.device)
-        self.step_dev = torch.zeros(1, device=self.device, dtype=torch.int32)
-        self._graph = None
+        temb = timestep_embedding(self.schedule.timesteps, self.cfg.block_out_channels[0]).to(BF16)
+        if getattr(self, "temb_table", None) is not None and self.temb_table.shape == temb.shape:
+            self.temb_table.copy_(temb)
+            self.sigmas.copy_(self.schedule.sigmas)
+            self.step_dev.zero_()
+        else:
+            self.temb_table = temb.to(self.device)
+            self.sigmas = self.schedule.sigmas.to(self.device)
+            self.step_dev = torch.zeros(1, device=self.device, dtype=torch.int32)
+            self._graph = None
         return self.schedule
 
     def set_context(self, prompt_embeds: torch.Tensor, height: int, width: int, original_size=(1024, 1024), crop=(0, 0)):
