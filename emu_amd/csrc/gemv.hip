@@ -9,12 +9,16 @@
 //
 // Replaces (reference call sites): LlamaDecoderLayer linears + RMSNorm reached from Emu2/emu/emu.py:133-138
 // and :213-229 at S=1, project_up/project_down emu.py:131,147.  Algorithmic bytes per call = 2*N*K.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-template <int R, int MB, bool NORM, int EPI>
+// PRE > 0: all (<= PRE) 16-byte weight chunks of this thread are requested BEFORE the RMSNorm prologue, so the HBM
+// stream is already in flight while the block computes mean(x^2); requires K/8 <= 256*PRE.  PRE == 0: generic loop.
+template <int R, int MB, bool NORM, int EPI, int PRE>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     __shared__ float red[4][R * MB];
     __shared__ float fin[R * MB];
@@ -24,6 +28,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     const int KV = a.K >> 3;                       // 16-byte vectors per row
     const int n0 = blockIdx.x * R;
 
+    const bf16_t* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;                 // tail rows: clamp loads, mask stores
+        wrow[r] = a.W + (size_t)n * a.ldw;
+    }
+    // PRE path (MB == 1): x first (L2 hits, returned first because loads complete in order), then the whole weight
+    // slice of this thread, so HBM is streaming while the RMSNorm statistics are reduced.
+    u32x4 pre[PRE > 0 ? PRE : 1][R];
+    u32x4 xr[PRE > 0 ? PRE : 1];
+    if constexpr (PRE > 0) {
+        static_assert(PRE == 0 || MB == 1, "preload form is for the single-row decode case");
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int vi = tid + 256 * c;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            xr[c] = vi < KV ? ld16(a.x + vi * 8) : z;
+        }
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int vi = tid + 256 * c;
+            const int vc = vi < KV ? vi : KV - 1;  // clamped: x is zero there, so the product vanishes
+#pragma unroll
+            for (int r = 0; r < R; ++r) pre[c][r] = ld_stream(reinterpret_cast<const u32x4*>(wrow[r] + vc * 8));
+        }
+    }
+
     float rinv[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) rinv[m] = 1.f;
@@ -31,6 +63,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         float ss[MB];
 #pragma unroll
         for (int m = 0; m < MB; ++m) ss[m] = 0.f;
+        if constexpr (PRE > 0) {
+#pragma unroll
+            for (int c = 0; c < PRE; ++c) {
+                float f[8];
+                unpack8(xr[c], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss[0] += f[j] * f[j];
+            }
+        } else
         for (int vi = tid; vi < KV; vi += 256) {
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
@@ -44,7 +85,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            float t = block_sum<4>(ss[m], scratch);
+            const float t = block_sum<4>(ss[m], scratch);
             rinv[m] = rsqrtf(t / (float)a.K + a.eps);
         }
     }
@@ -55,26 +96,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
 
-    const bf16_t* wrow[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int n = n0 + r;
-        n = n < a.N ? n : a.N - 1;                 // tail rows: clamp loads, mask stores
-        wrow[r] = a.W + (size_t)n * a.ldw;
-    }
-
-#pragma unroll 2
-    for (int vi = tid; vi < KV; vi += 256) {
-        u32x4 wv[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) wv[r] = ld_stream(reinterpret_cast<const u32x4*>(wrow[r] + vi * 8));
+    auto consume = [&](int vi, const u32x4 (&wv)[R], const u32x4* xpre) {
         float g[8];
         if constexpr (NORM) unpack8(ld16(a.norm_w + vi * 8), g);
         float xf[MB][8];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m < a.M) {
-                unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), xf[m]);
+                if (xpre) unpack8(*xpre, xf[m]);
+                else unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), xf[m]);
                 if constexpr (NORM) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xf[m][j] = bfround(g[j] * bfround(xf[m][j] * rinv[m]));
@@ -93,13 +123,29 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
         }
+    };
+
+    if constexpr (PRE > 0) {
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) {
+            const int vi = tid + 256 * c;
+            if (vi < KV) consume(vi, pre[c], &xr[c]);
+        }
+    } else {
+#pragma unroll 2
+        for (int vi = tid; vi < KV; vi += 256) {
+            u32x4 wv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) wv[r] = ld_stream(reinterpret_cast<const u32x4*>(wrow[r] + vi * 8));
+            consume(vi, wv, nullptr);
+        }
     }
 
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            float v = wave_sum(acc[r][m]);
+            const float v = wave_sum(acc[r][m]);
             if (lane == 0) red[wave][r * MB + m] = v;
         }
     __syncthreads();
@@ -135,15 +181,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
 }
 
-template <int R, int MB, bool NORM>
+template <int R, int MB, bool NORM, int PRE>
 int launch_epi(const GemvArgs& a, hipStream_t s) {
     const dim3 grid((a.N + R - 1) / R), block(256);
     switch (a.epi) {
-        case EPI_NONE:   hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_NONE>), grid, block, 0, s, a); break;
-        case EPI_RESID:  hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_RESID>), grid, block, 0, s, a); break;
-        case EPI_SWIGLU: hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_SWIGLU>), grid, block, 0, s, a); break;
-        case EPI_SILU:   hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_SILU>), grid, block, 0, s, a); break;
-        case EPI_GELU:   hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_GELU>), grid, block, 0, s, a); break;
+        case EPI_NONE:   hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_NONE, PRE>), grid, block, 0, s, a); break;
+        case EPI_RESID:  hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_RESID, PRE>), grid, block, 0, s, a); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_SWIGLU, PRE>), grid, block, 0, s, a); break;
+        case EPI_SILU:   hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_SILU, PRE>), grid, block, 0, s, a); break;
+        case EPI_GELU:   hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI_GELU, PRE>), grid, block, 0, s, a); break;
         default: return -22;
     }
     EMU_CHECK_LAUNCH();
@@ -152,7 +198,14 @@ int launch_epi(const GemvArgs& a, hipStream_t s) {
 
 template <int R, int MB>
 int launch_norm(const GemvArgs& a, hipStream_t s) {
-    return a.norm_w ? launch_epi<R, MB, true>(a, s) : launch_epi<R, MB, false>(a, s);
+    // the preload-everything form only for the single-row decode case (register budget: PRE*R*4 VGPRs)
+    static const bool no_pre = getenv("EMU_GEMV_NOPRE") != nullptr;
+    // measured: the preload form wins only for plain streams (o_proj); with the RMSNorm prologue it loses 20 %
+    // (clamped tail chunks + lower occupancy), so those keep the rolling loop.
+    if constexpr (MB == 1 && R <= 4) {
+        if (!no_pre && !a.norm_w && (a.K >> 3) <= 1024) return launch_epi<R, MB, false, 4>(a, s);
+    }
+    return a.norm_w ? launch_epi<R, MB, true, 0>(a, s) : launch_epi<R, MB, false, 0>(a, s);
 }
 
 template <int R>
@@ -165,18 +218,22 @@ int launch_mb(const GemvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int emu_gemv_rows_per_block(int N, int K) {
-    // K=6656-class rows are short: take 8 rows per workgroup so each lane keeps >= 8 loads in flight;
-    // long rows (down_proj K=17920) use 4.  Small N (TP shards) drops to 2 to keep >= 2 blocks per CU.
-    int R = K >= 12288 ? 4 : 8;
-    while (R > 2 && (N + R - 1) / R < 1024) R >>= 1;
+int emu_gemv_rows_per_block(int N, int K, bool norm) {
+    // measured (tools/kbench.py, profiles/): kernels with the fused RMSNorm prologue want 8 rows per workgroup so the
+    // prologue is amortised; plain streams are fastest with 2 rows per workgroup (more, smaller workgroups balance the
+    // 256 CUs better).
+    (void)K;
+    int R = norm ? 8 : 2;
+    while (R > 2 && (N + R - 1) / R < 512) R >>= 1;
     return R;
 }
 
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.M < 1 || a.M > 8 || (a.K & 7) || a.N < 1) return -22;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return -22;
-    int R = a.rows_per_block > 0 ? a.rows_per_block : emu_gemv_rows_per_block(a.N, a.K);
+    static const char* force_r = getenv("EMU_GEMV_R");     // A/B runs
+    int R = a.rows_per_block > 0 ? a.rows_per_block
+                                 : (force_r ? atoi(force_r) : emu_gemv_rows_per_block(a.N, a.K, a.norm_w != nullptr));
     if (a.M > 4 && R > 4) R = 4;                   // bound the accumulator register file
     switch (R) {
         case 2: return launch_mb<2>(a, s);

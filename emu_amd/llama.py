@@ -44,10 +44,11 @@ class EmuHipContext:
         check(lib().emu_ctx_create(idx, tp_rank, tp_size, C.byref(h)), "emu_ctx_create")
         self.handle = h
 
-    def init_tp(self, broadcast_bytes) -> None:
+    def init_tp(self, broadcast_bytes, force: bool = False) -> None:
         """Create the RCCL communicator.  ``broadcast_bytes(b: bytes|None) -> bytes`` must return rank 0's
-        128-byte unique id on every rank (e.g. via the torch.distributed store)."""
-        if self.tp_size == 1:
+        128-byte unique id on every rank (e.g. via the torch.distributed store).  ``force`` creates a communicator
+        even for tp_size 1 (a 1-rank RCCL all-reduce: used to exercise the RCCL + hipGraph path on a single GPU)."""
+        if self.tp_size == 1 and not force:
             return
         buf = (C.c_char * 128)()
         if self.tp_rank == 0:

@@ -143,3 +143,25 @@ def test_true_width_single_layer_decode_and_prefill():
     step = eng.decode_embeds(x[:, S].cuda(), pos, S, kstart)
     want1 = R.llama_model(x[:, S:].float(), torch.ones(1, S + 1, dtype=torch.long), Wr, cfg, cache=cache, final_norm=False)
     assert rel_err(step, want1[:, 0]) < 2e-2, rel_err(step, want1[:, 0])
+
+
+def test_rccl_single_rank_path_eager_and_graph(golden_dir):
+    """The tensor-parallel code path (ncclAllReduce on the launch stream after o_proj / down_proj, also inside hipGraph
+    capture) with a 1-rank RCCL communicator: must reproduce the reference's greedy ids exactly."""
+    from emu_amd import EmuModel, TextDecoderCfg
+    from emu_amd.llama import EmuHipContext
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    ctx = EmuHipContext(torch.device("cuda", 0), 0, 1)
+    ctx.init_tp(lambda b: b, force=True)
+    m = EmuModel(v, TextDecoderCfg(instruct=True), llama_cfg=l, device="cuda", ctx=ctx)
+    m.load_state_dict(W, strict=True)
+    for graph in (False, True):
+        m.use_graph = graph
+        new1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), _t(z["image"]).cuda(), max_new_tokens=8)
+        assert new1.cpu().tolist() == z["new1"].tolist(), graph
+    t = torch.arange(4096, dtype=torch.float32).to(torch.bfloat16).cuda()
+    want = t.clone()
+    ctx.allreduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
