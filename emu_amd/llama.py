@@ -277,6 +277,106 @@ class LlamaEngine:
         return apply_eos_padding(ids, eos_id, pad_id)
 
 
+    # ------------------------------------------------------------------ beam search
+    @torch.no_grad()
+    def beam_search_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, num_beams: int,
+                             max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0, eos_id: int = 2,
+                             pad_id: int = 32000) -> torch.Tensor:
+        """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False, early_stopping=False)`` -- the reference's
+        DEFAULT decoding mode (num_beams=5, length_penalty=-1, Emu2/emu/emu.py:163-172,213-229).  Restates
+        transformers' vectorised beam search: per step keep the 2N best continuations over beams x vocab, the N best
+        non-finished ones keep running, finished ones (EOS, or the length limit) compete for the N result slots with
+        score / len**length_penalty, and the loop ends when no running beam can beat the worst kept result.
+        One prefill for the B prompts; the KV cache is then replicated per beam and re-ordered by beam index each
+        step (rows are gathered on the device).  Returns the best sequence per prompt [B, <= max_new_tokens]."""
+        B, S, H = embeds.shape
+        nb, V, dev = num_beams, self.vocab, self.device
+        s_max = self.cfg.max_position_embeddings
+        if S + max_new_tokens > s_max:
+            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
+        logits = self.logits(hidden[:, -1, :]).float()                                  # [B, V]
+        # replicate the prompt's KV rows for every beam: row b*nb + j <- row b
+        k_old, v_old = self.kcache, self.vcache
+        self.kcache = self.vcache = None
+        self.alloc_kv(B * nb, s_max)
+        rep = torch.arange(B, device=dev).repeat_interleave(nb)
+        self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
+        self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
+        del k_old, v_old
+        kstart_b = kstart.repeat_interleave(nb).contiguous()
+        pos = next_pos.repeat_interleave(nb).contiguous()
+
+        max_len = max_new_tokens
+        NEG = -1.0e9
+        running_seq = torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=dev)
+        sequences = running_seq.clone()
+        running_scores = torch.zeros(B, nb, device=dev)
+        running_scores[:, 1:] = NEG
+        beam_scores = torch.full((B, nb), NEG, device=dev)
+        finished = torch.zeros(B, nb, dtype=torch.bool, device=dev)
+        seq_len = torch.zeros(B, nb, dtype=torch.int64, device=dev)                     # generated length of kept results
+        heuristic_open = torch.ones(B, 1, dtype=torch.bool, device=dev)
+        top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)]).to(dev)
+        gather = lambda t, idx: torch.gather(t, 1, idx.reshape(B, -1, *([1] * (t.dim() - 2))).expand(-1, -1, *t.shape[2:]))
+        hid = torch.empty(B * nb, H, device=dev, dtype=BF16)
+
+        cur = 0
+        lp_rows = logits[:, None, :].expand(B, nb, V)                                   # step 0: every beam = the prompt
+        while True:
+            log_probs = torch.log_softmax(lp_rows, dim=-1)
+            if cur < min_len:
+                log_probs = log_probs.clone()
+                log_probs[..., eos_id] = -float("inf")
+            acc = (log_probs + running_scores[:, :, None]).reshape(B, nb * V)
+            top_lp, top_idx = torch.topk(acc, k=2 * nb)
+            src_beam = top_idx // V
+            tok = top_idx % V
+            cand_seq = gather(running_seq, src_beam)
+            cand_seq[:, :, cur] = tok
+            hits = (tok == eos_id) | (cur + 1 >= max_len)
+            # running beams for the next step: best N non-finished candidates
+            run_lp = top_lp + hits.float() * NEG
+            nxt = torch.topk(run_lp, k=nb)[1]
+            running_seq = gather(cand_seq, nxt)
+            running_scores = torch.gather(run_lp, 1, nxt)
+            beam_idx = torch.gather(src_beam, 1, nxt)                                   # which old beam each new beam extends
+            # finished results: only the top-N candidates may finish; merge with the kept ones
+            fin_lp = top_lp / float((cur + 1) ** length_penalty)
+            fin_lp = fin_lp + (~heuristic_open).float() * NEG
+            just = hits & top_mask[None, :]
+            fin_lp = fin_lp + (~just).float() * NEG
+            m_seq = torch.cat((sequences, cand_seq), dim=1)
+            m_sc = torch.cat((beam_scores, fin_lp), dim=1)
+            m_fin = torch.cat((finished, just), dim=1)
+            m_len = torch.cat((seq_len, torch.full((B, 2 * nb), cur + 1, dtype=torch.int64, device=dev)), dim=1)
+            keep = torch.topk(m_sc, k=nb)[1]
+            sequences = gather(m_seq, keep)
+            beam_scores = torch.gather(m_sc, 1, keep)
+            finished = torch.gather(m_fin, 1, keep)
+            seq_len = torch.gather(m_len, 1, keep)
+            cur += 1
+            # early-stop heuristic (early_stopping=False): can the best running beam still beat the worst kept result?
+            best_run = running_scores[:, :1] / float(cur ** length_penalty)
+            worst_fin = torch.where(finished, beam_scores.min(dim=1, keepdim=True)[0], torch.full_like(beam_scores, NEG))
+            heuristic_open = heuristic_open & (best_run > worst_fin).any(dim=-1, keepdim=True)
+            if not bool(heuristic_open.any()) or bool(hits.all()):
+                break
+            # advance the model: reorder the cache rows by beam, feed the chosen tokens
+            flat = (beam_idx + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
+            ctx = S + cur - 1
+            self.kcache[:, :, :, :ctx] = self.kcache[:, flat, :, :ctx]
+            self.vcache[:, :, :, :ctx] = self.vcache[:, flat, :, :ctx]
+            toks = running_seq[:, :, cur - 1].reshape(-1).to(torch.int32).contiguous()
+            ops.embed_gather(toks, self.embed, out=hid)
+            slot = torch.full((B * nb,), ctx, device=dev, dtype=torch.int32)
+            self.forward(hid, B * nb, 1, pos, slot, kstart_b, ctx=ctx + 1)
+            pos = pos + 1
+            lp_rows = self.logits(hid).float().view(B, nb, V)
+        out_len = int(seq_len[:, 0].max().item())
+        return sequences[:, 0, :out_len]
+
+
 def apply_eos_padding(ids: torch.Tensor, eos_id: int, pad_id: int) -> torch.Tensor:
     """HF greedy bookkeeping: after a row emits EOS it emits PAD; generation stops once every row is finished."""
     ids = ids.clone()

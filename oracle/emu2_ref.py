@@ -309,6 +309,68 @@ def greedy_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: Lla
     return ids
 
 
+def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: LlamaCfg, num_beams: int,
+                         max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0) -> Tensor:
+    """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False)`` with the reference's defaults
+    (Emu2/emu/emu.py:163-172,213-229: num_beams=5, length_penalty=-1, early_stopping unset=False): restatement of
+    transformers' beam search -- 2N best continuations of (beam, token) per step; the N best unfinished ones keep
+    running; finished ones (EOS or the length limit) enter the N result slots scored log-prob / len**length_penalty;
+    stop when the best running beam cannot beat the worst kept result (heuristic at the current length)."""
+    B, S, _ = embeds.shape
+    nb, NEG = num_beams, -1.0e9
+    x = embeds.repeat_interleave(nb, dim=0)
+    mask = attention_mask.repeat_interleave(nb, dim=0).clone()
+    pos = (mask.long().cumsum(-1) - 1).masked_fill(mask == 0, 1)
+    cache = KVCache(cfg.layers)
+    V = W["decoder.lm.lm_head.weight"].shape[0]
+    run_seq = torch.full((B, nb, max_new_tokens), PAD_ID, dtype=torch.long)
+    seqs = run_seq.clone()
+    run_sc = torch.zeros(B, nb); run_sc[:, 1:] = NEG
+    fin_sc = torch.full((B, nb), NEG)
+    finished = torch.zeros(B, nb, dtype=torch.bool)
+    lens = torch.zeros(B, nb, dtype=torch.long)
+    open_ = torch.ones(B, 1, dtype=torch.bool)
+    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)])
+    g3 = lambda t, i: torch.gather(t, 1, i[:, :, None].expand(-1, -1, t.shape[2]))
+    cur = 0
+    while True:
+        h = llama_model(x, mask, W, cfg, position_ids=pos, cache=cache)
+        logits = F.linear(h[:, -1, :], W["decoder.lm.lm_head.weight"]).to(torch.float32)
+        lp = torch.log_softmax(logits, dim=-1)
+        if cur < min_len:
+            lp[:, EOS_ID] = -float("inf")
+        acc = (lp.view(B, nb, V) + run_sc[:, :, None]).reshape(B, nb * V)
+        top_lp, top_i = torch.topk(acc, k=2 * nb)
+        src, tok = top_i // V, top_i % V
+        cand = g3(run_seq, src)
+        cand[:, :, cur] = tok
+        hits = (tok == EOS_ID) | (cur + 1 >= max_new_tokens)
+        r_lp = top_lp + hits.float() * NEG
+        nxt = torch.topk(r_lp, k=nb)[1]
+        run_seq, run_sc, beam_idx = g3(cand, nxt), torch.gather(r_lp, 1, nxt), torch.gather(src, 1, nxt)
+        f_lp = top_lp / float((cur + 1) ** length_penalty) + (~open_).float() * NEG
+        just = hits & top_mask[None, :]
+        f_lp = f_lp + (~just).float() * NEG
+        m_seq, m_sc = torch.cat((seqs, cand), 1), torch.cat((fin_sc, f_lp), 1)
+        m_fin = torch.cat((finished, just), 1)
+        m_len = torch.cat((lens, torch.full((B, 2 * nb), cur + 1)), 1)
+        keep = torch.topk(m_sc, k=nb)[1]
+        seqs, fin_sc = g3(m_seq, keep), torch.gather(m_sc, 1, keep)
+        finished, lens = torch.gather(m_fin, 1, keep), torch.gather(m_len, 1, keep)
+        cur += 1
+        best_run = run_sc[:, :1] / float(cur ** length_penalty)
+        worst = torch.where(finished, fin_sc.min(dim=1, keepdim=True)[0], torch.full_like(fin_sc, NEG))
+        open_ = open_ & (best_run > worst).any(dim=-1, keepdim=True)
+        if not bool(open_.any()) or bool(hits.all()):
+            break
+        flat = (beam_idx + torch.arange(B)[:, None] * nb).reshape(-1)
+        cache.reorder(flat)
+        x = embed_tokens(run_seq[:, :, cur - 1].reshape(-1, 1), W)
+        mask = torch.cat((mask, torch.ones(B * nb, 1, dtype=mask.dtype)), dim=1)
+        pos = pos[:, -1:] + 1
+    return seqs[:, 0, : int(lens[:, 0].max())]
+
+
 # --------------------------------------------------------------------------- EmuModel
 def scatter_image_embeds(text_embeds: Tensor, input_ids: Tensor, image_embeds: Tensor,
                          token_id: int = IMAGE_ID) -> Tensor:
@@ -324,13 +386,15 @@ def scatter_image_embeds(text_embeds: Tensor, input_ids: Tensor, image_embeds: T
 
 def emu_generate(input_ids: Tensor, attention_mask: Tensor, image: Optional[Tensor], W: Weights,
                  cfg: EmuCfg, max_new_tokens: int, min_len: int = 1, n_query: Optional[int] = None,
-                 return_margins: bool = False):
-    """EmuModel.generate greedy path at the token-id level, Emu2/emu/emu.py:184-229."""
+                 return_margins: bool = False, num_beams: int = 1):
+    """EmuModel.generate at the token-id level (greedy or beam search), Emu2/emu/emu.py:184-229."""
     x = embed_tokens(input_ids, W)
     if image is not None:
         e = encode_image(image, W, cfg, n_query)
         e = F.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"])
         x = scatter_image_embeds(x, input_ids, e)
+    if num_beams > 1:
+        return beam_search_generate(x, attention_mask, W, cfg.llama, num_beams, max_new_tokens, min_len)
     return greedy_generate(x, attention_mask, W, cfg.llama, max_new_tokens, min_len, return_margins)
 
 

@@ -77,7 +77,7 @@ def main():
     text1 = ["[<IMG_PLH>]describe the image in detail:"]
     text2 = ["a photo of", "an image of a very large dog that"]
 
-    def run_generate(text, image, n_new):
+    def run_generate(text, image, n_new, num_beams=1):
         exp = [x.replace("[<IMG_PLH>]", m.image_placeholder) for x in text]
         enc_ = tok(exp, padding="longest", return_tensors="pt")
         # the reference returns decoded strings; capture ids by calling lm.generate the same way
@@ -91,16 +91,22 @@ def main():
         tok.batch_decode = hook
         try:
             with torch.no_grad():
-                strs = m.generate(text=text, image=image, num_beams=1, max_new_tokens=n_new)
+                strs = m.generate(text=text, image=image, num_beams=num_beams, max_new_tokens=n_new)
         finally:
             tok.batch_decode = orig
         return enc_.input_ids, enc_.attention_mask, captured["ids"], strs
 
     ids1, am1, new1, s1 = run_generate(text1, img1, 8)
     ids2, am2, new2, s2 = run_generate(text2, None, 6)
+    # the reference's DEFAULT decoding: beam search, num_beams=5, max_new_tokens=10, length_penalty=-1 (emu.py:163-172)
+    _, _, beam1, sb1 = run_generate(text1, img1, 10, num_beams=5)
+    _, _, beam2, sb2 = run_generate(text2, None, 10, num_beams=5)
     np.savez(os.path.join(OUT, "generate_tiny.npz"), image=img1.numpy(),
              ids1=ids1.numpy(), mask1=am1.numpy(), new1=new1.numpy(),
-             ids2=ids2.numpy(), mask2=am2.numpy(), new2=new2.numpy(), **meta)
+             ids2=ids2.numpy(), mask2=am2.numpy(), new2=new2.numpy(),
+             beam1=beam1.numpy(), beam2=beam2.numpy(), **meta)
+    print("beam B=1:", beam1.tolist(), sb1)
+    print("beam B=2:", beam2.tolist(), sb2)
     print("generate B=1:", new1.tolist(), s1)
     print("generate B=2:", new2.tolist(), s2)
 
@@ -116,6 +122,41 @@ def main():
     np.savez(os.path.join(OUT, "generate_image_tiny.npz"), image=img1.numpy(),
              prompt_text=p_text.numpy(), out_text=gi_text.numpy(),
              prompt_img=p_img.numpy(), out_img=gi_img.numpy(), **meta)
+    # --- 5. chat prompt templates (chat.py:121-195): the real reference functions with a torchvision stub (the module
+    #        only needs the names at import time; the stub transform returns a zero tensor, strings are what is pinned)
+    import json
+    import types
+    from PIL import Image
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    tvt.Compose = lambda fs: (lambda x: torch.zeros(3, 2, 2))
+    tvt.Resize = tvt.ToTensor = tvt.Normalize = lambda *a, **k: None
+    tvt.InterpolationMode = types.SimpleNamespace(BICUBIC=3)
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    from emu.chat import EmuChatGeneration as RefChat
+    fake = types.SimpleNamespace(transform=lambda x: torch.zeros(3, 2, 2))
+    fake._prepare_inputs = lambda *a, **k: RefChat._prepare_inputs(fake, *a, **k)
+    img = Image.new("RGB", (8, 8))
+    cases = {
+        "plain": ["describe ", img, " and ", img, " please"],
+        "video": ["[VIDEO]", img, img, "[/VIDEO]", "what happens?"],
+        "chat1": [["hello ", img]],
+        "chat3": [[img, "what is this?"], ["a dog."], ["and this? ", img]],
+        "ground": [["find the dog ", img]],
+    }
+    enc = lambda seq: ["<IMG>" if not isinstance(x, str) else x for x in seq]
+    out = {}
+    for name, inp in cases.items():
+        if isinstance(inp[0], list):
+            t, im, vd, _, _ = RefChat._prepare_chat_inputs(fake, inp, name == "ground")
+            key_in = [enc(m) for m in inp]
+        else:
+            t, im, vd, _, _ = RefChat._prepare_inputs(fake, inp)
+            key_in = enc(inp)
+        out[name] = {"inputs": key_in, "text": t[0], "n_image": 0 if im is None else im.shape[0],
+                     "n_video": 0 if vd is None else vd.shape[0]}
+    json.dump(out, open(os.path.join(OUT, "chat_templates.json"), "w"), indent=1)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -88,6 +88,17 @@ def test_generate_greedy_token_exact(tiny_model, golden_dir):
     assert new2.cpu().tolist() == z["new2"].tolist()
 
 
+def test_generate_beam_search_token_exact(tiny_model, golden_dir):
+    """The reference's DEFAULT decoding mode (num_beams=5, length_penalty=-1, max_new_tokens=10): ids of the real
+    reference, B=1 with an image and B=2 left-padded text-only (KV cache replicated per beam and re-ordered per step)."""
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    b1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), _t(z["image"]).cuda(), max_new_tokens=10, num_beams=5)
+    assert b1.cpu().tolist() == z["beam1"].tolist()
+    b2 = m.generate_ids(_t(z["ids2"]), _t(z["mask2"]), None, max_new_tokens=10, num_beams=5)
+    assert b2.cpu().tolist() == z["beam2"].tolist()
+
+
 def test_generate_graph_replay_equals_eager(tiny_model, golden_dir):
     m, W, cfg = tiny_model
     z = tiny.load(golden_dir, "generate_tiny.npz")

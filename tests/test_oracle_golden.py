@@ -52,6 +52,17 @@ def test_generate_greedy_token_exact(golden_dir):
     assert float(m1.min()) > 0.05 and float(m2.min()) > 0.05, (m1, m2)
 
 
+def test_generate_beam_search_token_exact(golden_dir):
+    """The reference's default decoding (num_beams=5, max_new_tokens=10, length_penalty=-1): ids of the real reference."""
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    b1 = R.emu_generate(_t(z["ids1"]), _t(z["mask1"]), _t(z["image"]), W, cfg, max_new_tokens=10, num_beams=5)
+    assert b1.tolist() == z["beam1"].tolist()
+    b2 = R.emu_generate(_t(z["ids2"]), _t(z["mask2"]), None, W, cfg, max_new_tokens=10, num_beams=5)
+    assert b2.tolist() == z["beam2"].tolist()
+
+
 @pytest.mark.parametrize("cached", [False, True])
 def test_generate_image(golden_dir, cached):
     z = tiny.load(golden_dir, "generate_image_tiny.npz")
