@@ -310,7 +310,8 @@ def greedy_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: Lla
 
 
 def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: LlamaCfg, num_beams: int,
-                         max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0) -> Tensor:
+                         max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0,
+                         return_margin: bool = False):
     """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False)`` with the reference's defaults
     (Emu2/emu/emu.py:163-172,213-229: num_beams=5, length_penalty=-1, early_stopping unset=False): restatement of
     transformers' beam search -- 2N best continuations of (beam, token) per step; the N best unfinished ones keep
@@ -333,6 +334,7 @@ def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg
     top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)])
     g3 = lambda t, i: torch.gather(t, 1, i[:, :, None].expand(-1, -1, t.shape[2]))
     cur = 0
+    margin = float("inf")          # smallest gap at a pruning boundary (N-th vs N+1-th running candidate) seen so far
     while True:
         h = llama_model(x, mask, W, cfg, position_ids=pos, cache=cache)
         logits = F.linear(h[:, -1, :], W["decoder.lm.lm_head.weight"]).to(torch.float32)
@@ -347,6 +349,9 @@ def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg
         hits = (tok == EOS_ID) | (cur + 1 >= max_new_tokens)
         r_lp = top_lp + hits.float() * NEG
         nxt = torch.topk(r_lp, k=nb)[1]
+        if cur + 1 < max_new_tokens:
+            srt = torch.sort(r_lp, dim=1, descending=True)[0]
+            margin = min(margin, float((srt[:, nb - 1] - srt[:, nb]).min()))
         run_seq, run_sc, beam_idx = g3(cand, nxt), torch.gather(r_lp, 1, nxt), torch.gather(src, 1, nxt)
         f_lp = top_lp / float((cur + 1) ** length_penalty) + (~open_).float() * NEG
         just = hits & top_mask[None, :]
@@ -368,7 +373,12 @@ def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg
         x = embed_tokens(run_seq[:, :, cur - 1].reshape(-1, 1), W)
         mask = torch.cat((mask, torch.ones(B * nb, 1, dtype=mask.dtype)), dim=1)
         pos = pos[:, -1:] + 1
-    return seqs[:, 0, : int(lens[:, 0].max())]
+    out = seqs[:, 0, : int(lens[:, 0].max())]
+    if return_margin:
+        # also the gap between the two best final results (the returned one must win clearly)
+        final_gap = float((fin_sc[:, 0] - fin_sc[:, 1]).min())
+        return out, min(margin, final_gap)
+    return out
 
 
 # --------------------------------------------------------------------------- EmuModel
@@ -394,7 +404,8 @@ def emu_generate(input_ids: Tensor, attention_mask: Tensor, image: Optional[Tens
         e = F.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"])
         x = scatter_image_embeds(x, input_ids, e)
     if num_beams > 1:
-        return beam_search_generate(x, attention_mask, W, cfg.llama, num_beams, max_new_tokens, min_len)
+        return beam_search_generate(x, attention_mask, W, cfg.llama, num_beams, max_new_tokens, min_len,
+                                    return_margin=return_margins)
     return greedy_generate(x, attention_mask, W, cfg.llama, max_new_tokens, min_len, return_margins)
 
 

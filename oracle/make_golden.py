@@ -101,10 +101,16 @@ def main():
     # the reference's DEFAULT decoding: beam search, num_beams=5, max_new_tokens=10, length_penalty=-1 (emu.py:163-172)
     _, _, beam1, sb1 = run_generate(text1, img1, 10, num_beams=5)
     _, _, beam2, sb2 = run_generate(text2, None, 10, num_beams=5)
+    # a beam-search case whose pruning decisions have a usable margin (0.1 nat; random-init models make most beam
+    # decisions near-ties, see tests/test_oracle_golden.py): 3 beams, 6 tokens -- used for the bf16 GPU comparison
+    text3 = ["[<IMG_PLH>]where was this taken?"]
+    ids3, am3, beam3, sb3 = run_generate(text3, img1, 6, num_beams=3)
     np.savez(os.path.join(OUT, "generate_tiny.npz"), image=img1.numpy(),
              ids1=ids1.numpy(), mask1=am1.numpy(), new1=new1.numpy(),
              ids2=ids2.numpy(), mask2=am2.numpy(), new2=new2.numpy(),
-             beam1=beam1.numpy(), beam2=beam2.numpy(), **meta)
+             beam1=beam1.numpy(), beam2=beam2.numpy(),
+             ids3=ids3.numpy(), mask3=am3.numpy(), beam3=beam3.numpy(), **meta)
+    print("beam3 (nb=3):", beam3.tolist(), sb3)
     print("beam B=1:", beam1.tolist(), sb1)
     print("beam B=2:", beam2.tolist(), sb2)
     print("generate B=1:", new1.tolist(), s1)

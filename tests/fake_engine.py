@@ -1,0 +1,57 @@
+"""CPU stand-in for emu_amd.llama.LlamaEngine that runs the oracle arithmetic, so the product's HOST logic (beam search
+bookkeeping, cache replication / re-ordering, position handling) can be tested without a GPU.  Only the methods the
+host logic calls are provided; kcache/vcache are plain tensors laid out like the product's [L, B, H, S_max, D]."""
+import torch
+
+from emu_amd.conf.emu_conf import LlamaCfg
+from oracle import emu2_ref as R
+
+
+class FakeEngine:
+    def __init__(self, lcfg: LlamaCfg, vocab: int, W, rcfg: R.LlamaCfg):
+        self.cfg, self.vocab, self.W, self.rcfg = lcfg, vocab, W, rcfg
+        self.device = torch.device("cpu")
+        self.embed = W["decoder.lm.model.embed_tokens.weight"]
+        self.kcache = self.vcache = None
+        self.kv_batch = self.s_max = 0
+
+    def alloc_kv(self, batch, s_max):
+        L, H, D = self.rcfg.layers, self.rcfg.heads, self.rcfg.head_dim
+        self.kcache = torch.zeros(L, batch, H, s_max, D)
+        self.vcache = torch.zeros(L, batch, H, s_max, D)
+        self.kv_batch, self.s_max = batch, s_max
+
+    def _run(self, x, pos, n_past, kstart):
+        """x [B,T,H]; writes k/v of the T new slots at [n_past, n_past+T)."""
+        B, T, _ = x.shape
+        cache = R.KVCache(self.rcfg.layers)
+        if n_past > 0:
+            for i in range(self.rcfg.layers):
+                cache.k[i] = self.kcache[i, :B, :, :n_past].clone()
+                cache.v[i] = self.vcache[i, :B, :, :n_past].clone()
+        mask = (torch.arange(n_past + T)[None, :] >= kstart[:, None]).long()
+        h = R.llama_model(x, mask, self.W, self.rcfg, position_ids=pos.long().view(B, T), cache=cache, final_norm=False)
+        for i in range(self.rcfg.layers):
+            self.kcache[i, :B, :, n_past:n_past + T] = cache.k[i][:, :, n_past:]
+            self.vcache[i, :B, :, n_past:n_past + T] = cache.v[i][:, :, n_past:]
+        return h
+
+    def prefill(self, embeds, attention_mask, s_max=None, hf_generate_positions=True):
+        B, S, _ = embeds.shape
+        am = attention_mask.long()
+        self.alloc_kv(B, s_max or self.cfg.max_position_embeddings)
+        pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1) if hf_generate_positions else torch.arange(S)[None].expand(B, -1)
+        kstart = (S - am.sum(1)).to(torch.int32)
+        h = self._run(embeds.float(), pos, 0, kstart)
+        nxt = am.sum(1) if hf_generate_positions else torch.full((B,), S)
+        return h, kstart, nxt.to(torch.int32)
+
+    def forward(self, hidden, B, T, pos, slot, kstart, ctx, ctx_dev=None):
+        assert T == 1
+        h = self._run(hidden.float().view(B, 1, -1), pos, int(slot[0]), kstart)
+        hidden.copy_(h.view(B, -1))
+        return hidden
+
+    def logits(self, rows, out=None):
+        h = R.rms_norm(rows.float(), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
+        return torch.nn.functional.linear(h, self.W["decoder.lm.lm_head.weight"])

@@ -93,3 +93,24 @@ def test_config_mirrors_reference_defaults():
     assert (v.width, v.layers, v.head_width, v.heads, v.mlp_hidden, v.tokens, v.n_query) == (1792, 64, 112, 16, 15360, 1025, 64)
     l = LlamaCfg.from_json(__import__("os").path.join(__import__("os").path.dirname(synth.__file__), "conf", "llama_config"))
     assert (l.hidden_size, l.num_attention_heads, l.num_hidden_layers, l.intermediate_size, l.head_dim) == (6656, 52, 60, 17920, 128)
+
+
+def test_product_beam_search_host_logic_matches_reference(golden_dir, monkeypatch):
+    """emu_amd.llama.LlamaEngine.beam_search_generate (the PRODUCT's host bookkeeping: 2N candidates, finished-beam merge,
+    early-stop heuristic, per-beam KV replication and re-ordering) driven by a CPU stand-in engine: ids of the real
+    reference for the default decoding mode (num_beams=5, max_new_tokens=10)."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    eng = FakeEngine(l, vocab, W, cfg.llama)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    ids, mask = t(z["ids2"]), t(z["mask2"])
+    x = R.embed_tokens(ids, W)
+    out = L.LlamaEngine.beam_search_generate(eng, x, mask, 5, 10)
+    assert out.tolist() == z["beam2"].tolist()
