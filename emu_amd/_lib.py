@@ -52,6 +52,7 @@ _PROTOS = {
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "emu_softmax_rows_bf16": (i32, [vp, i32, i32, i32, f32, vp]),
     "emu_embed_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_scatter_rows_bf16": (i32, [vp, vp, vp, i32, i32, vp]),
     "emu_argmax_bf16": (i32, [vp, i32, i32, i32, i32, vp, vp]),

@@ -25,7 +25,7 @@ def image_transform(img, size: int = EVA_IMAGE_SIZE, mean=OPENAI_DATASET_MEAN, s
     if not isinstance(img, Image.Image):
         raise TypeError(f"expected a PIL image, got {type(img)}")
     img = img.resize((size, size), Image.BICUBIC)
-    a = np.asarray(img)
+    a = np.array(img)                     # copy: torch.from_numpy needs a writable buffer
     if a.ndim == 2:
         a = a[:, :, None]
     t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1).to(torch.float32) / 255.0       # ToTensor

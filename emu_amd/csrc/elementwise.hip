@@ -176,7 +176,49 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restr
     }
 }
 
+// softmax over one row per workgroup, fp32 statistics; the row is re-read from L2 for each pass
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, int cols, int ld, float scale) {
+    __shared__ float scratch[4];
+    bf16_t* row = x + (size_t)blockIdx.x * ld;
+    const int nv = cols >> 3;
+    float m = -INFINITY;
+    for (int vi = threadIdx.x; vi < nv; vi += 256) {
+        float f[8];
+        unpack8(ld16(row + vi * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, f[j] * scale);
+    }
+    m = wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    float l = 0.f;
+    for (int vi = threadIdx.x; vi < nv; vi += 256) {
+        float f[8];
+        unpack8(ld16(row + vi * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l += __expf(f[j] * scale - m);
+    }
+    l = block_sum<4>(l, scratch);
+    const float inv = 1.f / l;
+    for (int vi = threadIdx.x; vi < nv; vi += 256) {
+        float f[8];
+        unpack8(ld16(row + vi * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = __expf(f[j] * scale - m) * inv;
+        st16(row + vi * 8, pack8(f));
+    }
+}
+
 }  // namespace
+
+int launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, float scale, hipStream_t s) {
+    if (rows < 1 || (cols & 7) || (ld & 7)) return -22;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, cols, ld, scale);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s) {
     if (rows < 1 || (cols & 7) || (ldx & 7) || (ldy & 7)) return -22;

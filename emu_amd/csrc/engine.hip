@@ -152,6 +152,9 @@ int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* 
                        float eps, emu_stream_t s) {
     return launch_layernorm(B(x), B(w), B(b), B(res), B(y), rows, cols, eps, S(s));
 }
+int emu_softmax_rows_bf16(void* x, int rows, int cols, int ld, float scale, emu_stream_t s) {
+    return launch_softmax_rows(B(x), rows, cols, ld, scale, S(s));
+}
 int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab, emu_stream_t s) {
     return launch_embed_gather(ids, B(table), B(out), n_tok, hidden, vocab, S(s));
 }

@@ -147,3 +147,7 @@ int launch_cfg_euler_step(const bf16_t* eps_nhwc, bf16_t* latents, const float* 
 int launch_add_silu(const bf16_t* a, const bf16_t* b, bf16_t* sum_out, bf16_t* silu_out, int n, hipStream_t s);
 // out[r, :] = table[step[0], :] for r < rows
 int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out, int rows, int cols, hipStream_t s);
+
+// in-place row softmax of x [rows, ld] over the first `cols` columns: x = bf16(softmax(float(x) * scale))
+// (materialised-score attention for head dims the flash kernel does not cover: the VAE mid block, D = 512)
+int launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, float scale, hipStream_t s);

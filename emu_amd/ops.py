@@ -183,3 +183,11 @@ def conv3x3_nhwc(x, w, bias=None, bias2=None, res=None, mode: int = CONV_3X3):
     check(lib().emu_conv3x3_nhwc_bf16(_p(x), _p(w), _p(bias), _p(bias2), bias2.stride(0) if bias2 is not None else 0, _p(res),
                                       _p(y), B, H, W, Cin, Cout, mode, stream()), "emu_conv3x3_nhwc_bf16")
     return y
+
+
+def softmax_rows_(x, scale: float = 1.0):
+    """In-place x = bf16(softmax(x * scale, dim=-1)) for a 2-D bf16 tensor."""
+    _req(x, "x")
+    assert x.dim() == 2
+    check(lib().emu_softmax_rows_bf16(_p(x), x.shape[0], x.shape[1], x.stride(0), float(scale), stream()), "emu_softmax_rows_bf16")
+    return x

@@ -63,6 +63,9 @@ int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, 
 /* nn.LayerNorm + post-norm residual (eva_vit.py:298-300): y = (res ? res + : ) bf16(LN(x) * w + b) */
 int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* res, void* y, int rows,
                        int cols, float eps, emu_stream_t s);
+/* in-place row softmax x = bf16(softmax(x * scale)) over [rows, cols] (row stride ld): materialised-score attention for
+ * the VAE mid block (AutoencoderKL attention, 1 head of 512; reached from Emu2/emu/diffusion.py:216) */
+int emu_softmax_rows_bf16(void* x, int rows, int cols, int ld, float scale, emu_stream_t s);
 /* embed_tokens (emu.py:119,193) and the masked row overwrite text_embeds[ids == IMAGE] = ... (emu.py:202-203) */
 int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab,
                           emu_stream_t s);
