@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-denoise", action="store_true", help="skip the UNet denoise leg")
     p.add_argument("--denoise-steps", type=int, default=50)
+    p.add_argument("--only-denoise", action="store_true", help="profiling aid: run just the UNet leg (prints its object)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
 
@@ -194,6 +195,11 @@ def main():
     import ctypes as C
 
     ctx = EmuHipContext(dev, rank, world)
+    if a.only_denoise:
+        d = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None)
+        if rank == 0:
+            print(json.dumps(d), flush=True)
+        return
     if world > 1:
         def bcast(b):
             box = [b]

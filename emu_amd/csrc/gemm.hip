@@ -268,10 +268,13 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
 }
 
 // Tile configuration: WN x WM waves, each owning NF x MF 32x32 accumulators; NSTG-deep LDS ring of 64-wide k tiles.
-template <int WN_, int WM_, int NF_, int MF_, int NSTG_>
+// KG > 1: KG groups of WN x WM waves split the four 16-wide k-steps of every tile between them (intra-workgroup split-K:
+// twice the waves per SIMD for the same tile, partial accumulators summed through LDS in the epilogue).
+template <int WN_, int WM_, int NF_, int MF_, int NSTG_, int KG_ = 1>
 struct TileCfg {
-    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_;
-    static constexpr int THREADS = WN * WM * 64;
+    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_, KG = KG_;
+    static constexpr int THREADS = WN * WM * KG * 64;
+    static_assert(KG == 1 || KG == 2, "k-groups: 1 or 2");
     static constexpr int BNv = WN * NF * 32, BMv = WM * MF * 32;
     static constexpr int W_BYTES = BNv * 128, A_BYTES = BMv * 128, ST_BYTES = W_BYTES + A_BYTES;
     static constexpr int NLW = (BNv * 8) / THREADS, NLA = (BMv * 8) / THREADS, LPT = NLW + NLA;   // LDS-DMA per thread per tile
@@ -282,11 +285,14 @@ struct TileCfg {
 
 template <int EPI, bool CONV, class T>
 __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
-    constexpr int NW = T::WN * T::WM;                   // waves per workgroup
-    __shared__ __attribute__((aligned(16))) char smem[T::NSTG * T::ST_BYTES];
+    constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
+    constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
+    constexpr int SMEM_BYTES = T::NSTG * T::ST_BYTES > RED_BYTES ? T::NSTG * T::ST_BYTES : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave / T::WM, wm = wave % T::WM;
+    const int kg = wave / (T::WN * T::WM), wtile = wave % (T::WN * T::WM);
+    const int wn = wtile / T::WM, wm = wtile % T::WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
     const int nwg = gridDim.x, b = blockIdx.x;
@@ -382,10 +388,12 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
             for (int j = 0; j < T::MF; ++j)
                 af[buf][j] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off((wm * T::MF + j) * 32 + l31, ch));
         };
-        frags(0, 0);
+        constexpr int KSTEPS = 4 / T::KG;              // k-steps of this wave's k-group
+        const int kk0 = kg * KSTEPS;
+        frags(kk0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) frags(kk + 1, (kk + 1) & 1);
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            if (kk < KSTEPS - 1) frags(kk0 + kk + 1, (kk + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);         // keep the next k-step's ds_reads ABOVE this k-step's MFMAs
 #pragma unroll
             for (int i = 0; i < T::NF; ++i)
@@ -396,6 +404,28 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
         }
     }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
+
+    if constexpr (T::KG > 1) {
+        // sum the two k-groups' partial accumulators through LDS (the ring is dead now): group 1 writes, group 0 adds
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem) + (size_t)wtile * T::NF * T::MF * 16 * 64;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < T::NF; ++i)
+#pragma unroll
+                for (int j = 0; j < T::MF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * T::MF + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < T::NF; ++i)
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::MF + j) * 16 + r) * 64 + lane];
+    }
 
 #pragma unroll
     for (int j = 0; j < T::MF; ++j) {
@@ -423,6 +453,10 @@ using CfgE = TileCfg<2, 2, 2, 1, 4>;     // 128(n) x 64(m), 4 waves, 4 stages (9
 using CfgF = TileCfg<2, 4, 2, 2, 3>;     // 128(n) x 256(m), 8 waves, 3 stages (144 KiB)
 using CfgG = TileCfg<2, 2, 1, 1, 3>;     // 64 x 64, 4 waves, 3 stages (48 KiB, 3 workgroups per CU): latency-bound small GEMMs
 using CfgH = TileCfg<2, 2, 2, 1, 3>;     // 128(n) x 64(m), 4 waves, 3 stages (72 KiB, 2 workgroups per CU)
+using CfgI = TileCfg<2, 2, 2, 1, 6>;     // 128(n) x 64(m), 4 waves, 6 stages (144 KiB): 5 tiles (120 KiB) in flight per CU
+using CfgJ = TileCfg<2, 2, 2, 2, 4>;     // 128 x 128, 4 waves, 4 stages (128 KiB): 3 tiles (96 KiB) in flight per CU
+using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves, 3 stages (72 KiB, 2 workgroups per CU)
+using CfgL = TileCfg<2, 2, 2, 2, 2, 2>;  // 128 x 128, 2 k-groups x 4 waves, 2 stages (64 KiB, 2 workgroups per CU)
 
 template <int EPI, bool CONV, class T>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
@@ -437,17 +471,18 @@ void launch_v2(const GemmArgs& a, hipStream_t s) {
     static const char* force = getenv("EMU_GEMM_CFG");      // A/B runs: force one configuration
     char cfg = force ? force[0] : 0;
     if (!cfg) {
-        // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so large problems take the
-        // 256(n) x 128(m) tile; mid-size ones 128x128 with two workgroups per CU; problems with few tiles (UNet 32x32
-        // level, skinny ViT fc2) take 128 x 64 tiles, 3-stage ring, two workgroups per CU (measured: tools/kbench.py).
-        if (tiles_of(a, 256, 128) >= 512) cfg = 'C';
-        else if (tiles_of(a, 128, 128) >= 320) cfg = 'B';
-        else cfg = 'H';
+        // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so the largest problems take the
+        // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
+        // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
+        // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
+        if (tiles_of(a, 256, 128) >= 1024) cfg = 'C';
+        else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
+        else cfg = 'K';
     }
     switch (cfg) {
         case 'C': launch_cfg<EPI, CONV, CfgC>(a, s); break;
-        case 'D': launch_cfg<EPI, CONV, CfgD>(a, s); break;
-        case 'H': launch_cfg<EPI, CONV, CfgH>(a, s); break;
+        case 'K': launch_cfg<EPI, CONV, CfgK>(a, s); break;
+        case 'L': launch_cfg<EPI, CONV, CfgL>(a, s); break;
         default:  launch_cfg<EPI, CONV, CfgB>(a, s); break;
     }
 }
