@@ -164,13 +164,20 @@ class EmuModel:
     @torch.no_grad()
     def generate_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, image: Optional[torch.Tensor] = None,
                      video: Optional[torch.Tensor] = None, max_new_tokens: int = 10, min_len: int = 1,
-                     stop_on_eos: bool = True, num_beams: int = 1, length_penalty: float = -1.0) -> torch.Tensor:
+                     stop_on_eos: bool = True, num_beams: int = 1, length_penalty: float = -1.0, do_sample: bool = False,
+                     temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0) -> torch.Tensor:
         """``generate`` at the token-id level (greedy for num_beams=1, else beam search): returns the NEW ids [B, n]
         (what HF returns for inputs_embeds)."""
         B, S = input_ids.shape
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
             x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
+        if do_sample or repetition_penalty != 1.0:
+            if num_beams > 1:
+                raise NotImplementedError("beam search combined with sampling / repetition penalty is not built")
+            return self.decoder.lm.sample_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len, do_sample,
+                                                   temperature, top_k, top_p, repetition_penalty, eos_id=EOS_TOKEN_ID,
+                                                   pad_id=PAD_TOKEN_ID)
         if num_beams > 1:
             return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
                                                         length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID)
@@ -184,15 +191,15 @@ class EmuModel:
                  num_beams=5, max_new_tokens=10, min_len=1, do_sample=False, penalty_alpha=None, top_p=None,
                  top_k=None, temperature=None, length_penalty=-1, repetition_penalty=1.0, synced_gpus=False,
                  skip_special_tokens=True, **kwargs):
-        if do_sample or penalty_alpha is not None or repetition_penalty != 1.0:
-            raise NotImplementedError("sampling / contrastive search / repetition penalty are not built yet "
-                                      "(SURVEY 8f row 3); use do_sample=False, repetition_penalty=1.0")
+        if penalty_alpha is not None:
+            raise NotImplementedError("contrastive search (penalty_alpha) is not built")
         tok = self.decoder.tokenizer
         text = [t.replace(image_placeholder, self.image_placeholder).replace(video_placeholder, self.video_placeholder)
                 for t in text]
         inputs = tok(text, padding="longest", return_tensors="pt")
         ids = self.generate_ids(inputs.input_ids, inputs.attention_mask, image, video, max_new_tokens, min_len,
-                                num_beams=num_beams, length_penalty=length_penalty)
+                                num_beams=num_beams, length_penalty=length_penalty, do_sample=do_sample,
+                                temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty)
         return tok.batch_decode(ids.cpu(), skip_special_tokens=skip_special_tokens)
 
     # ------------------------------------------------------------------ generate_image (emu.py:92-153)

@@ -277,6 +277,64 @@ class LlamaEngine:
         return apply_eos_padding(ids, eos_id, pad_id)
 
 
+    # ------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, min_len: int = 1,
+                        do_sample: bool = True, temperature: Optional[float] = None, top_k: Optional[int] = None,
+                        top_p: Optional[float] = None, repetition_penalty: float = 1.0, eos_id: int = 2,
+                        pad_id: int = 32000) -> torch.Tensor:
+        """``lm.generate(inputs_embeds=..., num_beams=1)`` with logits processing: repetition penalty, min_length, then
+        (when sampling) temperature / top-k / top-p warpers and a multinomial draw from torch's global CUDA generator
+        (transformers' processor order).  The decoder runs on the HIP engine; the tiny per-step logits post-processing is
+        host-driven, so this path is not graph-replayed."""
+        B, S, H = embeds.shape
+        dev = self.device
+        s_max = self.cfg.max_position_embeddings
+        if S + max_new_tokens > s_max:
+            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        hidden, kstart, pos = self.prefill(embeds, attention_mask, s_max)
+        row = hidden[:, -1, :]
+        out = torch.full((B, max_new_tokens), pad_id, dtype=torch.int64, device=dev)
+        unfinished = torch.ones(B, dtype=torch.int64, device=dev)
+        hid = torch.empty(B, H, device=dev, dtype=BF16)
+        n = 0
+        for step in range(max_new_tokens):
+            scores = self.logits(row).float()
+            if repetition_penalty != 1.0 and step > 0:
+                prev = out[:, :step]
+                g = torch.gather(scores, 1, prev)
+                g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
+                scores.scatter_(1, prev, g)
+            if step < min_len:
+                scores[:, eos_id] = -float("inf")
+            if do_sample:
+                if temperature is not None and temperature != 1.0:
+                    scores = scores / temperature
+                if top_k is not None and top_k > 0:
+                    kth = torch.topk(scores, min(top_k, scores.shape[-1]))[0][..., -1, None]
+                    scores = scores.masked_fill(scores < kth, -float("inf"))
+                if top_p is not None and top_p < 1.0:
+                    srt, idx = torch.sort(scores, descending=False)
+                    cum = srt.softmax(dim=-1).cumsum(dim=-1)
+                    remove = cum <= (1 - top_p)
+                    remove[..., -1:] = False
+                    scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
+                nxt = torch.multinomial(torch.softmax(scores, dim=-1), num_samples=1).squeeze(1)
+            else:
+                nxt = scores.argmax(dim=-1)
+            nxt = nxt * unfinished + pad_id * (1 - unfinished)
+            out[:, step] = nxt
+            n = step + 1
+            unfinished = unfinished * (nxt != eos_id).long()
+            if int(unfinished.max().item()) == 0 or n == max_new_tokens:
+                break
+            ops.embed_gather(nxt.to(torch.int32).contiguous(), self.embed, out=hid)
+            slot = torch.full((B,), S + step, device=dev, dtype=torch.int32)
+            self.forward(hid, B, 1, pos, slot, kstart, ctx=S + step + 1)
+            pos = pos + 1
+            row = hid
+        return out[:, :n]
+
     # ------------------------------------------------------------------ beam search
     @torch.no_grad()
     def beam_search_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, num_beams: int,

@@ -193,3 +193,41 @@ def test_rccl_single_rank_path_eager_and_graph(golden_dir):
     ctx.allreduce(t)
     torch.cuda.synchronize()
     assert torch.equal(t, want)
+
+
+def test_sampling_and_repetition_penalty_paths(tiny_model, golden_dir):
+    """do_sample=False with repetition_penalty=1 through the host-driven loop equals the device greedy loop; top_k=1
+    sampling is greedy; a repetition penalty changes the repeated-token fixture; sampled ids are valid and seed-stable."""
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    ids, mask, img = _t(z["ids1"]), _t(z["mask1"]), _t(z["image"]).cuda()
+    greedy = z["new1"].tolist()
+    lm = m.decoder.lm
+    x = m._prompt_embeds(ids, img, m.n_query).view(1, ids.shape[1], -1)
+    assert lm.sample_generate(x, mask, 8, do_sample=False).cpu().tolist() == greedy
+    assert m.generate_ids(ids, mask, img, max_new_tokens=8, do_sample=True, top_k=1).cpu().tolist() == greedy
+    rep = m.generate_ids(ids, mask, img, max_new_tokens=8, repetition_penalty=1.5).cpu().tolist()
+    assert rep != greedy and len(set(rep[0])) > len(set(greedy[0]))           # greedy repeats 10724/30726; the penalty breaks it
+    torch.manual_seed(3)
+    a = m.generate_ids(ids, mask, img, max_new_tokens=8, do_sample=True, temperature=0.9, top_p=0.95, top_k=50)
+    torch.manual_seed(3)
+    b = m.generate_ids(ids, mask, img, max_new_tokens=8, do_sample=True, temperature=0.9, top_p=0.95, top_k=50)
+    assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < cfg.llama.vocab
+
+
+def test_api_errors_and_video_path(tiny_model, golden_dir):
+    """Reference error behaviour: a prompt whose number of <image> slots differs from the image rows raises (emu.py:202-203
+    masked assignment); video frames go through the same encoder with v_query tokens and the [gIMG] slots (emu.py:205-211)."""
+    from emu_amd.constants import IMAGE_TOKEN_ID, IMG_END_TOKEN_ID, IMG_TOKEN_ID, gIMG_TOKEN_ID
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    ids, mask, img = _t(z["ids1"]), _t(z["mask1"]), _t(z["image"]).cuda()
+    with pytest.raises(ValueError):
+        m.generate_ids(ids, mask, torch.cat([img, img]), max_new_tokens=2)
+    with pytest.raises(AssertionError):
+        m.encode_image(torch.zeros(1, 3, 28, 28).cuda())
+    # video: replace the <image> slots by [gIMG] slots -> same embeddings are scattered, so the ids must equal the image run
+    vid_ids = ids.clone()
+    vid_ids[vid_ids == IMAGE_TOKEN_ID] = gIMG_TOKEN_ID
+    out_v = m.generate_ids(vid_ids, mask, None, video=img, max_new_tokens=8)
+    assert out_v.cpu().tolist() == z["new1"].tolist()
