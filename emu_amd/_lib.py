@@ -30,7 +30,7 @@ class LlamaCfgC(C.Structure):
 
 class VitCfgC(C.Structure):
     _fields_ = [("image_size", i32), ("patch_size", i32), ("width", i32), ("layers", i32), ("heads", i32),
-                ("head_width", i32), ("mlp_hidden", i32), ("kpad", i32), ("ln_eps", f32)]
+                ("head_width", i32), ("mlp_hidden", i32), ("kpad", i32), ("ln_eps", f32), ("prenorm", i32)]
 
 
 class UNetCfgC(C.Structure):
@@ -52,7 +52,7 @@ _PROTOS = {
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
-    "emu_softmax_rows_bf16": (i32, [vp, i32, i32, i32, f32, vp]),
+    "emu_softmax_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_embed_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_scatter_rows_bf16": (i32, [vp, vp, vp, i32, i32, vp]),
     "emu_argmax_bf16": (i32, [vp, i32, i32, i32, i32, vp, vp]),

@@ -98,7 +98,7 @@ __device__ __forceinline__ int sw_off(int row, int chunk) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void flash_kernel(const FlashArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
     constexpr int KROWB = D * 2;                      // K tile [64 keys][D]
     constexpr int KCH = D / 8;                        // 16-byte chunks per K row
     constexpr int NKK = D / 16;                       // k-steps of QK^T

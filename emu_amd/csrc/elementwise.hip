@@ -176,17 +176,32 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* __restr
     }
 }
 
-// softmax over one row per workgroup, fp32 statistics; the row is re-read from L2 for each pass
-__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, int cols, int ld, float scale) {
+// softmax over one row per workgroup, fp32 statistics; the row is re-read from L2 for each pass.  Optional additive bias
+// (T5 relative-position bias + causal mask, bf16): logits = bf16(x * scale + bias) as the bf16 tensor add of the reference.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ bias, int cols, int ld,
+                                                          int ld_bias, float scale) {
     __shared__ float scratch[4];
     bf16_t* row = x + (size_t)blockIdx.x * ld;
+    const bf16_t* brow = bias ? bias + (size_t)blockIdx.x * ld_bias : nullptr;
     const int nv = cols >> 3;
+    auto logits = [&](int vi, float* f) {
+        unpack8(ld16(row + vi * 8), f);
+        if (brow) {
+            float b[8];
+            unpack8(ld16(brow + vi * 8), b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = bfround(f[j] * scale + b[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= scale;
+        }
+    };
     float m = -INFINITY;
     for (int vi = threadIdx.x; vi < nv; vi += 256) {
         float f[8];
-        unpack8(ld16(row + vi * 8), f);
+        logits(vi, f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m = fmaxf(m, f[j] * scale);
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, f[j]);
     }
     m = wave_max(m);
     __syncthreads();
@@ -196,26 +211,26 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ 
     float l = 0.f;
     for (int vi = threadIdx.x; vi < nv; vi += 256) {
         float f[8];
-        unpack8(ld16(row + vi * 8), f);
+        logits(vi, f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) l += __expf(f[j] * scale - m);
+        for (int j = 0; j < 8; ++j) l += __expf(f[j] - m);
     }
     l = block_sum<4>(l, scratch);
     const float inv = 1.f / l;
     for (int vi = threadIdx.x; vi < nv; vi += 256) {
         float f[8];
-        unpack8(ld16(row + vi * 8), f);
+        logits(vi, f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = __expf(f[j] * scale - m) * inv;
+        for (int j = 0; j < 8; ++j) f[j] = __expf(f[j] - m) * inv;
         st16(row + vi * 8, pack8(f));
     }
 }
 
 }  // namespace
 
-int launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, float scale, hipStream_t s) {
-    if (rows < 1 || (cols & 7) || (ld & 7)) return -22;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, cols, ld, scale);
+int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s) {
+    if (rows < 1 || (cols & 7) || (ld & 7) || (bias && (ld_bias & 7))) return -22;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, bias, cols, ld, ld_bias, scale);
     EMU_CHECK_LAUNCH();
     return 0;
 }

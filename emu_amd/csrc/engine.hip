@@ -152,8 +152,8 @@ int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* 
                        float eps, emu_stream_t s) {
     return launch_layernorm(B(x), B(w), B(b), B(res), B(y), rows, cols, eps, S(s));
 }
-int emu_softmax_rows_bf16(void* x, int rows, int cols, int ld, float scale, emu_stream_t s) {
-    return launch_softmax_rows(B(x), rows, cols, ld, scale, S(s));
+int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s) {
+    return launch_softmax_rows(B(x), B(bias), rows, cols, ld, ld_bias, scale, S(s));
 }
 int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab, emu_stream_t s) {
     return launch_embed_gather(ids, B(table), B(out), n_tok, hidden, vocab, S(s));
@@ -454,7 +454,12 @@ int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, voi
     for (int l = 0; l < c.layers; ++l) {
         const emu_vit::Block& Bk = m->blocks[l];
         if (!Bk.wqkv) return fail(cx, -22, "emu_vit_forward: block weights not set");
-        TRY(cx, linear(x, Bk.wqkv, Bk.bqkv, nullptr, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, 0.f, EPI_NONE, s));
+        const bf16_t* ain = x;                           // attention input
+        if (c.prenorm) {
+            TRY(cx, launch_layernorm(x, Bk.ln1w, Bk.ln1b, nullptr, w.tmp, M, C, c.ln_eps, s));
+            ain = w.tmp;
+        }
+        TRY(cx, linear(ain, Bk.wqkv, Bk.bqkv, nullptr, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, 0.f, EPI_NONE, s));
         TransposeVArgs tv{w.qkv + 2 * QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK, w.vt, Bn, Hh, N, VIT_DP, npad};
         TRY(cx, launch_transpose_v(tv, s));
         FlashArgs f{w.qkv, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
@@ -462,11 +467,19 @@ int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, voi
                     w.vt, w.attn, (long)N * QK, (long)VIT_DP, (long)QK, nullptr,
                     Bn, Hh, N, N, npad, VIT_DP, 0, scale};
         TRY(cx, launch_flash_attn(f, s));
-        TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s));
-        TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
-        TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
-        TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s));
-        TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+        if (c.prenorm) {
+            // x = x + proj(attn);  x = x + fc2(gelu(fc1(LN2(x))))
+            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, x, nullptr, x, M, C, QK, QK, QK, C, C, 0.f, EPI_RESID, s));
+            TRY(cx, launch_layernorm(x, Bk.ln2w, Bk.ln2b, nullptr, w.tmp, M, C, c.ln_eps, s));
+            TRY(cx, linear(w.tmp, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
+            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, x, nullptr, x, M, C, F, F, F, C, C, 0.f, EPI_RESID, s));
+        } else {
+            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s));
+            TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
+            TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
+            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s));
+            TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+        }
     }
     return 0;
 }

@@ -150,4 +150,4 @@ int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out
 
 // in-place row softmax of x [rows, ld] over the first `cols` columns: x = bf16(softmax(float(x) * scale))
 // (materialised-score attention for head dims the flash kernel does not cover: the VAE mid block, D = 512)
-int launch_softmax_rows(bf16_t* x, int rows, int cols, int ld, float scale, hipStream_t s);
+int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s);

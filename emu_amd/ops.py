@@ -185,9 +185,13 @@ def conv3x3_nhwc(x, w, bias=None, bias2=None, res=None, mode: int = CONV_3X3):
     return y
 
 
-def softmax_rows_(x, scale: float = 1.0):
-    """In-place x = bf16(softmax(x * scale, dim=-1)) for a 2-D bf16 tensor."""
+def softmax_rows_(x, scale: float = 1.0, bias=None):
+    """In-place x = bf16(softmax(x * scale [+ bias], dim=-1)) for a 2-D bf16 tensor (bias: bf16 [rows, cols])."""
     _req(x, "x")
     assert x.dim() == 2
-    check(lib().emu_softmax_rows_bf16(_p(x), x.shape[0], x.shape[1], x.stride(0), float(scale), stream()), "emu_softmax_rows_bf16")
+    if bias is not None:
+        _req(bias, "bias")
+        assert bias.shape == x.shape
+    check(lib().emu_softmax_rows_bf16(_p(x), _p(bias), x.shape[0], x.shape[1], x.stride(0),
+                                      bias.stride(0) if bias is not None else 0, float(scale), stream()), "emu_softmax_rows_bf16")
     return x

@@ -26,12 +26,13 @@ _BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.q_bias", "attn.v_bias", "attn
 
 class VitEngine:
     def __init__(self, cfg: CLIPVisionCfg, ctx):
-        if not cfg.postnorm or cfg.rope or cfg.naiveswiglu or cfg.subln or cfg.init_value:
-            raise NotImplementedError("only the Emu2 EVA-CLIP configuration (post-norm, GELU MLP, no rope) is built")
+        """``cfg.postnorm`` True = Emu2's EVA-CLIP-4B blocks; False = Emu1's EVA-CLIP-g pre-norm blocks."""
+        if cfg.rope or cfg.naiveswiglu or cfg.subln or cfg.init_value:
+            raise NotImplementedError("only the EVA-CLIP configurations Emu uses (GELU MLP, no rope / sub-LN / layer scale) are built")
         self.cfg, self.ctx, self.device = cfg, ctx, ctx.device
         self.kpad = (3 * cfg.patch_size * cfg.patch_size + 63) // 64 * 64
         c = VitCfgC(cfg.image_size, cfg.patch_size, cfg.width, cfg.layers, cfg.heads, cfg.head_width,
-                    cfg.mlp_hidden, self.kpad, 1e-6)
+                    cfg.mlp_hidden, self.kpad, 1e-6, 0 if cfg.postnorm else 1)
         h = C.c_void_p()
         check(lib().emu_vit_create(ctx.handle, C.byref(c), C.byref(h)), "emu_vit_create", ctx.handle)
         self.handle = h

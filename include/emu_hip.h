@@ -63,9 +63,11 @@ int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, 
 /* nn.LayerNorm + post-norm residual (eva_vit.py:298-300): y = (res ? res + : ) bf16(LN(x) * w + b) */
 int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* res, void* y, int rows,
                        int cols, float eps, emu_stream_t s);
-/* in-place row softmax x = bf16(softmax(x * scale)) over [rows, cols] (row stride ld): materialised-score attention for
- * the VAE mid block (AutoencoderKL attention, 1 head of 512; reached from Emu2/emu/diffusion.py:216) */
-int emu_softmax_rows_bf16(void* x, int rows, int cols, int ld, float scale, emu_stream_t s);
+/* in-place row softmax x = bf16(softmax(x * scale [+ bias])) over [rows, cols] (row stride ld): materialised-score
+ * attention for the VAE mid block (AutoencoderKL attention, 1 head of 512; Emu2/emu/diffusion.py:216) and, with the additive
+ * bf16 bias [rows, cols] (relative-position bias + causal mask), T5Attention of Emu1's CausalFormer
+ * (Emu1/models/modeling_t5.py:629-666) */
+int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s);
 /* embed_tokens (emu.py:119,193) and the masked row overwrite text_embeds[ids == IMAGE] = ... (emu.py:202-203) */
 int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab,
                           emu_stream_t s);
@@ -151,6 +153,8 @@ int emu_llama_greedy_step(emu_llama* m, int B, int32_t* cur_ids, int32_t* pos, i
 typedef struct {
     int image_size, patch_size, width, layers, heads, head_width, mlp_hidden, kpad;
     float ln_eps;
+    int prenorm;   /* 0: Emu2 post-norm blocks (eva_vit.py:298-300); 1: Emu1 EVA-CLIP-g pre-norm blocks
+                      (Emu1/models/eva_vit_model.py:409-416: x += attn(LN1(x)); x += mlp(LN2(x))) */
 } emu_vit_cfg;
 int emu_vit_create(emu_ctx* ctx, const emu_vit_cfg* cfg, emu_vit** out);
 void emu_vit_destroy(emu_vit* m);

@@ -1,0 +1,67 @@
+"""GPU parity tests of the Emu1 caption path (BASELINE.json configs[0]) against oracle/emu1_ref.py (PARITY UNPINNED: the
+Emu1 reference modules cannot be imported, the oracle restates them from source)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def rel_err(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-12))
+
+
+@pytest.fixture(scope="module")
+def tiny_emu1():
+    from emu_amd import synth
+    from emu_amd.emu1 import Emu, T5DecoderCfg, emu1_llama_cfg, emu1_param_shapes, emu1_vision_cfg
+    from oracle import emu1_ref as E, emu2_ref as R
+    v = emu1_vision_cfg(image_size=56, width=176, layers=2, head_width=88, mlp_ratio=2.0)     # 2 heads x 88 (padded to 128)
+    l = emu1_llama_cfg(hidden_size=256, intermediate_size=512, num_attention_heads=2, num_hidden_layers=2)
+    t5 = T5DecoderCfg(d_model=128, num_layers=2, num_heads=2, d_ff=256, n_causal=8)
+    W = synth.synth_state_dict(emu1_param_shapes(v, t5, l, 32006), seed=4, lm_head_scale=8.0)
+    m = Emu(v, l, t5, vocab=32006, device="cuda")
+    m.load_state_dict(W, strict=True)
+    cfg = E.Emu1Cfg(vit=R.VitCfg(image_size=56, patch_size=14, width=176, layers=2, head_width=88, mlp_hidden=v.mlp_hidden),
+                    t5=E.T5Cfg(d_model=128, layers=2, heads=2, d_ff=256, n_causal=8),
+                    llama=R.LlamaCfg(hidden=256, heads=2, layers=2, ffn=512, vocab=32006))
+    return m, R.bf16_round(W), cfg
+
+
+def test_vit_g_prenorm_and_causal_former(tiny_emu1):
+    """EVA-CLIP-g pre-norm blocks + ln_visual + CausalFormer (T5 decoder, relative-position bias, unscaled attention):
+    relative L2 error < 3e-2 on the 8 visual tokens handed to the LLaMA."""
+    from oracle import emu1_ref as E
+    m, W, cfg = tiny_emu1
+    img = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(1)).to(BF16)
+    feats = m.visual(img.cuda())
+    want_f = E.vit_g_forward(img.float(), W, cfg.vit)
+    assert rel_err(feats, want_f) < 2e-2, rel_err(feats, want_f)
+    got = m.encode_image(img.cuda())
+    want = E.encode_image(img.float(), W, cfg)
+    assert got.shape == want.shape == (2, 8, 256)
+    assert rel_err(got, want) < 3e-2, rel_err(got, want)
+
+
+def test_emu1_generate_greedy_and_beam(tiny_emu1):
+    """Emu.generate at the id level: greedy ids exact vs the oracle when its top-2 margins allow it; beam search (the
+    reference default, 5 beams, length_penalty 0) returns a sequence of the right shape through the same engine path."""
+    from oracle import emu1_ref as E
+    m, W, cfg = tiny_emu1
+    img = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(2)).to(BF16)
+    ids = torch.tensor([[1, 32001] + [32003] * 8 + [32002, 500, 600, 700]])
+    mask = torch.ones_like(ids)
+    want, margins = E.emu1_generate(ids, mask, img.float(), W, cfg, 6, num_beams=1, return_margins=True)
+    got = m.generate_ids(ids, mask, img.cuda(), num_beams=1, max_new_tokens=6)
+    n_ok = 0
+    for t in range(want.shape[1]):                       # compare up to the first near-tie
+        if float(margins[0, t]) < 0.05:
+            break
+        n_ok += 1
+    assert n_ok >= 3, margins
+    assert got.cpu()[0, :n_ok].tolist() == want[0, :n_ok].tolist()
+    beam = m.generate_ids(ids, mask, img.cuda(), num_beams=5, max_new_tokens=6)
+    assert beam.shape[0] == 1 and 1 <= beam.shape[1] <= 6
+    with pytest.raises(ValueError):
+        m.generate_ids(ids[:, :-5], mask[:, :-5], torch.cat([img, img]).cuda(), num_beams=1, max_new_tokens=2)
