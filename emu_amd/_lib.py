@@ -50,6 +50,10 @@ _PROTOS = {
     "emu_tp_init": (i32, [vp, vp]),
     "emu_allreduce_bf16": (i32, [vp, vp, sz, vp]),
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "emu_gemv_stream_giveups": (C.c_uint, []),
+    "emu_gemv_stream_engine": (None, [i32]),
+    "emu_quantize_fp8_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, vp]),
+    "emu_linear_fp8w_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "emu_softmax_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
@@ -68,6 +72,9 @@ _PROTOS = {
     "emu_llama_create": (i32, [vp, C.POINTER(LlamaCfgC), C.POINTER(vp)]),
     "emu_llama_destroy": (None, [vp]),
     "emu_llama_set_layer": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
+    "emu_llama_set_layer_fp8": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "emu_llama_set_head_fp8": (i32, [vp, vp, vp]),
+    "emu_llama_use_fp8": (i32, [vp, i32]),
     "emu_llama_set_head": (i32, [vp, vp, vp, vp, vp, vp]),
     "emu_llama_set_kv": (i32, [vp, vp, vp, i32, i32]),
     "emu_llama_workspace_bytes": (sz, [vp, i32, i32]),

@@ -10,6 +10,7 @@ typedef uint16_t bf16_t;                                             // raw bflo
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));         // one MFMA A/B fragment
 typedef float f32x16_t __attribute__((ext_vector_type(16)));         // one 32x32 accumulator
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));           // 16-byte load/store unit (8 bf16)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 

@@ -226,6 +226,38 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ 
     }
 }
 
+// per-row symmetric fp8 (OCP e4m3fn) quantisation of a packed bf16 weight: scale = amax / 448, q = rne_fp8(w / scale)
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ w, int ldw, uint8_t* __restrict__ q,
+                                                             int ldq, float* __restrict__ scale, int K) {
+    __shared__ float scratch[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* src = w + (size_t)n * ldw;
+    float amax = 0.f;
+    for (int vi = tid; vi < (K >> 3); vi += 256) {
+        float f[8];
+        unpack8(ld16(src + vi * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+    amax = wave_max(amax);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) scale[n] = sc;
+    uint8_t* dst = q + (size_t)n * ldq;
+    for (int vi = tid; vi < (K >> 3); vi += 256) {
+        float f[8];
+        unpack8(ld16(src + vi * 8), f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] / sc, f[1] / sc, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] / sc, f[3] / sc, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] / sc, f[5] / sc, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] / sc, f[7] / sc, hi, true);
+        *reinterpret_cast<uint2*>(dst + vi * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
 }  // namespace
 
 int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s) {
@@ -285,6 +317,12 @@ int launch_avgpool_tokens(const bf16_t* x, bf16_t* out, int B, int g, int C, int
 int launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int T, int C, hipStream_t s) {
     if (B < 1 || (C & 7)) return -22;
     hipLaunchKernelGGL(vit_assemble_kernel, dim3(B * (T + 1)), dim3(256), 0, s, patches, cls, pos, x, T, C);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+int launch_quant_fp8_rows(const bf16_t* w, int ldw, uint8_t* q, int ldq, float* scale, int N, int K, hipStream_t s) {
+    if (N < 1 || K < 8 || (K & 7) || (ldw & 7) || (ldq & 7)) return -22;
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, s, w, ldw, q, ldq, scale, K);
     EMU_CHECK_LAUNCH();
     return 0;
 }

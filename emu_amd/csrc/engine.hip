@@ -39,9 +39,11 @@ struct GemvProfiler {
 } g_prof;
 
 int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* res, const bf16_t* norm_w,
-           bf16_t* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, hipStream_t s) {
+           bf16_t* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, hipStream_t s,
+           const float* wscale = nullptr) {
+    if (wscale && M > 2) return -22;                 // fp8 weights are a decode-only stream
     if (M <= 8) {
-        GemvArgs g{A, W, norm_w, bias, res, C, M, N, K, lda, ldw, ldres, ldc, eps, epi, 0};
+        GemvArgs g{A, W, norm_w, bias, res, C, M, N, K, lda, ldw, ldres, ldc, eps, epi, 0, wscale};
         if (!g_prof.on) return launch_gemv(g, s);
         if (g_prof.used == g_prof.ev.size()) {
             hipEvent_t a, b;
@@ -49,7 +51,7 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
             g_prof.ev.emplace_back(a, b);
         }
         auto& e = g_prof.ev[g_prof.used++];
-        g_prof.bytes += 2.0 * (double)N * (double)K;
+        g_prof.bytes += (wscale ? 1.0 : 2.0) * (double)N * (double)K;
         (void)hipEventRecord(e.first, s);
         const int st = launch_gemv(g, s);
         (void)hipEventRecord(e.second, s);
@@ -66,6 +68,9 @@ int emu_ctx_fail(emu_ctx* c, int code, const char* what) { return fail(c, code, 
 extern "C" {
 
 int emu_version(void) { return 1; }
+
+unsigned int emu_gemv_stream_giveups(void) { return emu_gemv_stream_giveups_read(); }
+void emu_gemv_stream_engine(int enable) { emu_gemv_stream_engine_set(enable); }
 
 int emu_profile_gemv(int enable) {
     g_prof.on = enable != 0;
@@ -145,6 +150,16 @@ int emu_linear_bf16(const void* A, const void* W, const void* bias, const void* 
                     int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, emu_stream_t s) {
     return linear(B(A), B(W), B(bias), B(res), B(norm_w), B(C), M, N, K, lda, ldw, ldres, ldc, eps, epi, S(s));
 }
+int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, const void* bias, const void* res,
+                         const void* norm_w, void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps,
+                         int epi, emu_stream_t s) {
+    if (!wscale) return -22;
+    return linear(B(A), B(W8), B(bias), B(res), B(norm_w), B(C), M, N, K, lda, ldw, ldres, ldc, eps, epi, S(s), wscale);
+}
+int emu_quantize_fp8_rows(const void* w, int ldw, void* q, int ldq, float* scale, int N, int K, emu_stream_t s) {
+    if (!w || !q || !scale) return -22;
+    return launch_quant_fp8_rows(B(w), ldw, reinterpret_cast<uint8_t*>(q), ldq, scale, N, K, S(s));
+}
 int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, int ldx, int ldy, float eps, emu_stream_t s) {
     return launch_rmsnorm(B(x), B(w), B(y), rows, cols, ldx, ldy, eps, S(s));
 }
@@ -209,6 +224,13 @@ struct emu_llama {
     emu_llama_cfg cfg;
     struct Layer { const bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2; };
     std::vector<Layer> layers;
+    // optional fp8 (e4m3) copies of the packed weights for the decode stream: bytes + one fp32 scale per output row
+    struct Layer8 { const uint8_t *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
+                    const float *sqkv = nullptr, *so = nullptr, *sgu = nullptr, *sdown = nullptr; };
+    std::vector<Layer8> layers8;
+    const uint8_t* lm_head8 = nullptr;
+    const float* lm_scale8 = nullptr;
+    bool fp8_decode = false;
     const bf16_t *final_norm = nullptr, *lm_head = nullptr, *embed = nullptr, *cos = nullptr, *sin = nullptr;
     bf16_t *kcache = nullptr, *vcache = nullptr;
     int kv_batch = 0, s_max = 0;
@@ -261,6 +283,30 @@ int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* w
     m->layers[layer] = {B(wqkv), B(wo), B(wgu), B(wdown), B(ln1), B(ln2)};
     return 0;
 }
+int emu_llama_set_layer_fp8(emu_llama* m, int layer, const void* wqkv8, const float* sqkv, const void* wo8, const float* so,
+                            const void* wgu8, const float* sgu, const void* wdown8, const float* sdown) {
+    if (!m || layer < 0 || layer >= m->cfg.layers) return -22;
+    if (!wqkv8 || !sqkv || !wo8 || !so || !wgu8 || !sgu || !wdown8 || !sdown) return -22;
+    const emu_llama_cfg& c = m->cfg;
+    if ((c.hidden & 15) || ((c.heads_local * c.head_dim) & 15) || (c.ffn_local & 15))
+        return fail(m->ctx, -22, "emu_llama_set_layer_fp8: reduction widths must be multiples of 16");
+    if (m->layers8.size() != (size_t)c.layers) m->layers8.assign(c.layers, emu_llama::Layer8{});
+    auto U = [](const void* p) { return reinterpret_cast<const uint8_t*>(p); };
+    m->layers8[layer] = {U(wqkv8), U(wo8), U(wgu8), U(wdown8), sqkv, so, sgu, sdown};
+    return 0;
+}
+int emu_llama_set_head_fp8(emu_llama* m, const void* lm_head8, const float* lm_scale) {
+    if (!m || !lm_head8 || !lm_scale) return -22;
+    m->lm_head8 = reinterpret_cast<const uint8_t*>(lm_head8); m->lm_scale8 = lm_scale;
+    return 0;
+}
+int emu_llama_use_fp8(emu_llama* m, int enable) {
+    if (!m) return -22;
+    if (enable && m->layers8.size() != (size_t)m->cfg.layers)
+        return fail(m->ctx, -22, "emu_llama_use_fp8: fp8 layer weights not set");
+    m->fp8_decode = enable != 0;
+    return 0;
+}
 int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed, const void* rope_cos,
                        const void* rope_sin) {
     if (!m) return -22;
@@ -302,7 +348,12 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         bf16_t* kc = m->kcache + l * kv_layer;
         bf16_t* vc = m->vcache + l * kv_layer;
         // ---- attention
-        if (M <= 8) {
+        const bool f8 = m->fp8_decode && M <= 2;
+        const emu_llama::Layer8 L8 = f8 ? m->layers8[l] : emu_llama::Layer8{};
+        if (f8 && !L8.wqkv) return fail(cx, -22, "emu_llama_forward: fp8 decode enabled but fp8 layer weights not set");
+        if (f8) {
+            TRY(cx, linear(hA, B(L8.wqkv), nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s, L8.sqkv));
+        } else if (M <= 8) {
             TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
         } else {
             TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
@@ -324,16 +375,20 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
                         Bn, Hl, T, ctx, spad, D, 1, scale};
             TRY(cx, launch_flash_attn(f, s));
         }
-        TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s));
+        if (f8) TRY(cx, linear(w.attn, B(L8.wo), nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, L8.so));
+        else TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, w.hB, (size_t)M * H, s_));
         // ---- SwiGLU MLP
-        if (M <= 8) {
+        if (f8) {
+            TRY(cx, linear(w.hB, B(L8.wgu), nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s, L8.sgu));
+        } else if (M <= 8) {
             TRY(cx, linear(w.hB, L.wgu, nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s));
         } else {
             TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
             TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s));
         }
-        TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s));
+        if (f8) TRY(cx, linear(w.act, B(L8.wdown), nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, L8.sdown));
+        else TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)M * H, s_));
     }
     return 0;
@@ -349,6 +404,9 @@ int emu_llama_logits(emu_llama* m, const void* hidden, int ldh, int M, void* log
                      size_t ws_bytes, emu_stream_t s) {
     if (!m || !m->lm_head || !m->final_norm) return -22;
     const emu_llama_cfg& c = m->cfg;
+    if (m->fp8_decode && M <= 2 && m->lm_head8)
+        return linear(B(hidden), B(m->lm_head8), nullptr, nullptr, m->final_norm, B(logits), M, c.vocab, c.hidden, ldh,
+                      c.hidden, 0, ld, c.rms_eps, EPI_NONE, S(s), m->lm_scale8);
     if (M <= 8)
         return linear(B(hidden), m->lm_head, nullptr, nullptr, m->final_norm, B(logits), M, c.vocab, c.hidden, ldh,
                       c.hidden, 0, ld, c.rms_eps, EPI_NONE, S(s));

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -181,6 +182,480 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
 }
 
+// Single-round-trip GEMV (decode, M = 1): every load of the block -- x, gain, and the block's WHOLE weight slice
+// (R rows x KIT 256-lane trips, fully unrolled into registers) -- is issued before anything waits, so a block pays one
+// HBM latency instead of one per loop trip plus one for the RMSNorm prologue.  The prologue's cross-wave reduction uses
+// a raw s_barrier (a __syncthreads would drain vmcnt and serialise the weight loads behind it).  FP8: 8-byte loads of
+// e4m3 weights with a per-row fp32 scale.  KIT = ceil(K / 8 / 256) rounded up to a built value.
+template <int R, int KIT, bool NORM, int EPI, bool FP8>
+__global__ __launch_bounds__(256) void gemv_rt_kernel(const GemvArgs a) {
+    using WT = typename std::conditional<FP8, u32x2, u32x4>::type;
+    __shared__ float red[4][R];
+    __shared__ float fin[R];
+    __shared__ float ssp[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int KV = a.K >> 3;
+    const int n0 = blockIdx.x * R;
+    constexpr int WB = FP8 ? 1 : 2;                                   // bytes per weight
+    const unsigned char* W8 = reinterpret_cast<const unsigned char*>(a.W);
+
+    u32x4 xv[KIT], gv[KIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int vi = tid + 256 * it;
+        xv[it] = u32x4{0u, 0u, 0u, 0u};
+        gv[it] = u32x4{0u, 0u, 0u, 0u};
+        if (vi < KV) {
+            xv[it] = ld16(a.x + vi * 8);
+            if constexpr (NORM) gv[it] = ld16(a.norm_w + vi * 8);
+        }
+    }
+    WT wv[KIT][R];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int vi = tid + 256 * it;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int n = n0 + r;
+            n = n < a.N ? n : a.N - 1;
+            wv[it][r] = WT{};
+            if (vi < KV)
+                wv[it][r] = __builtin_nontemporal_load(
+                    reinterpret_cast<const WT*>(W8 + ((size_t)n * a.ldw + (size_t)vi * 8) * WB));
+        }
+    }
+
+    float rinv = 1.f;
+    if constexpr (NORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int it = 0; it < KIT; ++it) {
+            float f[8];
+            unpack8(xv[it], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) *reinterpret_cast<volatile float*>(&ssp[wave]) = ss;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const volatile float* sp = ssp;
+        rinv = rsqrtf((sp[0] + sp[1] + sp[2] + sp[3]) / (float)a.K + a.eps);
+    }
+
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        float xf[8];
+        unpack8(xv[it], xf);
+        if constexpr (NORM) {
+            float g[8];
+            unpack8(gv[it], g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = bfround(g[j] * bfround(xf[j] * rinv));
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float wf[8];
+            if constexpr (FP8) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wv[it][r][q], false);
+                    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(wv[it][r][q], true);
+                    wf[4 * q] = lo[0]; wf[4 * q + 1] = lo[1]; wf[4 * q + 2] = hi[0]; wf[4 * q + 3] = hi[1];
+                }
+            } else {
+                unpack8(wv[it][r], wf);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r] = fmaf(wf[j], xf[j], acc[r]);
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float v = wave_sum(acc[r]);
+        if (lane == 0) red[wave][r] = v;
+    }
+    __syncthreads();
+    if (tid < R) {
+        float t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if constexpr (FP8) { const int n = n0 + tid; t *= a.wscale[n < a.N ? n : a.N - 1]; }
+        fin[tid] = t;
+    }
+    __syncthreads();
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (tid < R / 2) {
+            const int n = n0 + 2 * tid;
+            if (n + 1 < a.N) {
+                const float gt = bfround(fin[2 * tid]);
+                const float up = bfround(fin[2 * tid + 1]);
+                a.out[n >> 1] = f2bf(bfround(silu(gt)) * up);
+            }
+        }
+    } else {
+        if (tid < R) {
+            const int n = n0 + tid;
+            if (n < a.N) {
+                float v = fin[tid];
+                if (a.bias) v += bf2f(a.bias[n]);
+                v = bfround(v);
+                if constexpr (EPI == EPI_SILU) v = bfround(silu(v));
+                if constexpr (EPI == EPI_GELU) v = bfround(gelu_erf(v));
+                if constexpr (EPI == EPI_RESID) v = v + bf2f(a.res[n]);
+                a.out[n] = f2bf(v);
+            }
+        }
+    }
+}
+
+template <int R, int KIT, bool FP8>
+int launch_rt(const GemvArgs& a, hipStream_t s) {
+    const dim3 grid((a.N + R - 1) / R), block(256);
+    const bool norm = a.norm_w != nullptr;
+#define EMU_RT_CASE(E)                                                                                               \
+    case E:                                                                                                          \
+        if (norm) hipLaunchKernelGGL((gemv_rt_kernel<R, KIT, true, E, FP8>), grid, block, 0, s, a);                  \
+        else hipLaunchKernelGGL((gemv_rt_kernel<R, KIT, false, E, FP8>), grid, block, 0, s, a);                      \
+        break;
+    switch (a.epi) {
+        EMU_RT_CASE(EPI_NONE)
+        EMU_RT_CASE(EPI_RESID)
+        EMU_RT_CASE(EPI_SWIGLU)
+        EMU_RT_CASE(EPI_SILU)
+        EMU_RT_CASE(EPI_GELU)
+        default: return -22;
+    }
+#undef EMU_RT_CASE
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// M = 1 dispatch onto the single-round-trip kernel; returns 1 when the shape is not covered.
+int try_launch_rt(const GemvArgs& a, hipStream_t s) {
+    static const char* env = getenv("EMU_GEMV_RT");                   // A/B: 0 disables, R value overrides rows/block
+    const int mode = env ? atoi(env) : -1;
+    if (mode == 0 || a.M != 1) return 1;
+    if (a.epi == EPI_SWIGLU && (a.N & 1)) return 1;
+    const int kit = ((a.K >> 3) + 255) / 256;
+    const bool f8 = a.wscale != nullptr;
+    if (f8 && (a.epi == EPI_SILU || a.epi == EPI_GELU)) return 1;
+    if (mode < 0) {
+        // measured (tools/kbench.py, profiles/r01_gemv_variants.log): one round trip wins for matrices small enough
+        // that latency, not bandwidth, sets the time (TP shards, tiny models) and for long rows without the RMSNorm
+        // prologue (down_proj: 6.3 vs 5.85 TB/s); big fused-norm matrices amortise the prologue better over 8 rows
+        const size_t bytes = (size_t)a.N * a.K * (f8 ? 1 : 2);
+        const bool small = bytes < ((size_t)(f8 ? 32 : 64) << 20);
+        const bool long_rows = !f8 && kit >= 5 && a.norm_w == nullptr;
+        if (!small && !long_rows) return 1;
+    }
+    if (kit <= 4) {
+        if (f8) return mode == 4 ? launch_rt<4, 4, true>(a, s) : launch_rt<8, 4, true>(a, s);
+        return mode == 2 ? launch_rt<2, 4, false>(a, s) : launch_rt<4, 4, false>(a, s);
+    }
+    if (kit <= 9) {
+        if (f8) return mode == 2 ? launch_rt<2, 9, true>(a, s) : launch_rt<4, 9, true>(a, s);
+        return launch_rt<2, 9, false>(a, s);
+    }
+    return 1;
+}
+
+// fp8 (OCP e4m3fn) weight stream: half the HBM bytes per token.  One 16-byte load = 16 weights of one row; the per-row
+// fp32 scale is applied once to the fp32 dot product.  Same fused RMSNorm prologue / epilogues as the bf16 kernel.
+template <int R, int MB, bool NORM, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
+    __shared__ float red[NW][R * MB];
+    __shared__ float fin[R * MB];
+    __shared__ float scratch[NW];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int KV = a.K >> 4;                       // 16-element groups per row
+    const int n0 = blockIdx.x * R;
+    const uint8_t* W8 = reinterpret_cast<const uint8_t*>(a.W);
+    const uint8_t* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;
+        wrow[r] = W8 + (size_t)n * a.ldw;
+    }
+    float rinv[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) rinv[m] = 1.f;
+    if constexpr (NORM) {
+        float ss[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) ss[m] = 0.f;
+        for (int vi = tid; vi < (a.K >> 3); vi += NW * 64) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m < a.M) {
+                    float f[8];
+                    unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss[m] += f[j] * f[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float t = block_sum<NW>(ss[m], scratch);
+            rinv[m] = rsqrtf(t / (float)a.K + a.eps);
+        }
+    }
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+
+#pragma unroll 2
+    for (int vi = tid; vi < KV; vi += NW * 64) {
+        u32x4 wv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[r] = ld_stream(reinterpret_cast<const u32x4*>(wrow[r] + vi * 16));
+        float xf[MB][16];
+        float g[16];
+        if constexpr (NORM) { unpack8(ld16(a.norm_w + vi * 16), g); unpack8(ld16(a.norm_w + vi * 16 + 8), g + 8); }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m < a.M) {
+                unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 16), xf[m]);
+                unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 16 + 8), xf[m] + 8);
+                if constexpr (NORM) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xf[m][j] = bfround(g[j] * bfround(xf[m][j] * rinv[m]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xf[m][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float wf[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], false);
+                const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], true);
+                wf[4 * q] = lo[0]; wf[4 * q + 1] = lo[1]; wf[4 * q + 2] = hi[0]; wf[4 * q + 3] = hi[1];
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float v = wave_sum(acc[r][m]);
+            if (lane == 0) red[wave][r * MB + m] = v;
+        }
+    __syncthreads();
+    if (tid < R * MB) {
+        const int n = n0 + tid / MB;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][tid];
+        fin[tid] = t * a.wscale[n < a.N ? n : a.N - 1];
+    }
+    __syncthreads();
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (tid < (R / 2) * MB) {
+            const int j = tid / MB, m = tid % MB;
+            const int n = n0 + 2 * j;
+            if (m < a.M && n + 1 < a.N) {
+                const float gt = bfround(fin[(2 * j) * MB + m]);
+                const float up = bfround(fin[(2 * j + 1) * MB + m]);
+                a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
+            }
+        }
+    } else {
+        if (tid < R * MB) {
+            const int r = tid / MB, m = tid % MB;
+            const int n = n0 + r;
+            if (m < a.M && n < a.N) {
+                float v = fin[tid];
+                if (a.bias) v += bf2f(a.bias[n]);
+                v = bfround(v);
+                if constexpr (EPI == EPI_RESID) v = v + bf2f(a.res[(size_t)m * a.ldres + n]);
+                a.out[(size_t)m * a.ldo + n] = f2bf(v);
+            }
+        }
+    }
+}
+
+template <int R, int MB, bool NORM, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
+    __shared__ float red[NW][R * MB];
+    __shared__ float fin[R * MB];
+    __shared__ float scratch[NW];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int KV = a.K >> 3;                       // 8-element groups per row (8-byte weight loads)
+    const int n0 = blockIdx.x * R;
+    const uint8_t* W8 = reinterpret_cast<const uint8_t*>(a.W);
+    const uint8_t* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;
+        wrow[r] = W8 + (size_t)n * a.ldw;
+    }
+    float rinv[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) rinv[m] = 1.f;
+    if constexpr (NORM) {
+        float ss[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) ss[m] = 0.f;
+        for (int vi = tid; vi < (a.K >> 3); vi += NW * 64) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m < a.M) {
+                    float f[8];
+                    unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss[m] += f[j] * f[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float t = block_sum<NW>(ss[m], scratch);
+            rinv[m] = rsqrtf(t / (float)a.K + a.eps);
+        }
+    }
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+
+#pragma unroll 2
+    for (int vi = tid; vi < KV; vi += NW * 64) {
+        u32x2 wv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow[r] + vi * 8));
+        float xf[MB][8];
+        float g[8];
+        if constexpr (NORM) unpack8(ld16(a.norm_w + vi * 8), g);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m < a.M) {
+                unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), xf[m]);
+                if constexpr (NORM) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[m][j] = bfround(g[j] * bfround(xf[m][j] * rinv[m]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[m][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float wf[8];
+            const unsigned int wq[2] = {wv[r][0], wv[r][1]};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wq[q], false);
+                const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(wq[q], true);
+                wf[4 * q] = lo[0]; wf[4 * q + 1] = lo[1]; wf[4 * q + 2] = hi[0]; wf[4 * q + 3] = hi[1];
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float v = wave_sum(acc[r][m]);
+            if (lane == 0) red[wave][r * MB + m] = v;
+        }
+    __syncthreads();
+    if (tid < R * MB) {
+        const int n = n0 + tid / MB;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][tid];
+        fin[tid] = t * a.wscale[n < a.N ? n : a.N - 1];
+    }
+    __syncthreads();
+    if constexpr (EPI == EPI_SWIGLU) {
+        if (tid < (R / 2) * MB) {
+            const int j = tid / MB, m = tid % MB;
+            const int n = n0 + 2 * j;
+            if (m < a.M && n + 1 < a.N) {
+                const float gt = bfround(fin[(2 * j) * MB + m]);
+                const float up = bfround(fin[(2 * j + 1) * MB + m]);
+                a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
+            }
+        }
+    } else {
+        if (tid < R * MB) {
+            const int r = tid / MB, m = tid % MB;
+            const int n = n0 + r;
+            if (m < a.M && n < a.N) {
+                float v = fin[tid];
+                if (a.bias) v += bf2f(a.bias[n]);
+                v = bfround(v);
+                if constexpr (EPI == EPI_RESID) v = v + bf2f(a.res[(size_t)m * a.ldres + n]);
+                a.out[(size_t)m * a.ldo + n] = f2bf(v);
+            }
+        }
+    }
+}
+
+template <int R, int MB, int NW>
+int launch_fp8v8(const GemvArgs& a, hipStream_t s) {
+    static_assert(R * MB <= NW * 64, "epilogue needs one thread per (row, m)");
+    const dim3 grid((a.N + R - 1) / R), block(NW * 64);
+    const bool norm = a.norm_w != nullptr;
+#define EMU_FP8_CASE(E)                                                                                              \
+    case E:                                                                                                          \
+        if (norm) hipLaunchKernelGGL((gemv_fp8v8_kernel<R, MB, true, E, NW>), grid, block, 0, s, a);                 \
+        else hipLaunchKernelGGL((gemv_fp8v8_kernel<R, MB, false, E, NW>), grid, block, 0, s, a);                     \
+        break;
+    switch (a.epi) {
+        EMU_FP8_CASE(EPI_NONE)
+        EMU_FP8_CASE(EPI_RESID)
+        EMU_FP8_CASE(EPI_SWIGLU)
+        default: return -22;
+    }
+#undef EMU_FP8_CASE
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int R, int MB, int NW>
+int launch_fp8(const GemvArgs& a, hipStream_t s) {
+    static_assert(R * MB <= NW * 64, "epilogue needs one thread per (row, m)");
+    const dim3 grid((a.N + R - 1) / R), block(NW * 64);
+    const bool norm = a.norm_w != nullptr;
+#define EMU_FP8_CASE(E)                                                                                              \
+    case E:                                                                                                          \
+        if (norm) hipLaunchKernelGGL((gemv_fp8_kernel<R, MB, true, E, NW>), grid, block, 0, s, a);                       \
+        else hipLaunchKernelGGL((gemv_fp8_kernel<R, MB, false, E, NW>), grid, block, 0, s, a);                           \
+        break;
+    switch (a.epi) {
+        EMU_FP8_CASE(EPI_NONE)
+        EMU_FP8_CASE(EPI_RESID)
+        EMU_FP8_CASE(EPI_SWIGLU)
+        default: return -22;
+    }
+#undef EMU_FP8_CASE
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int R, int MB, bool NORM, int PRE>
 int launch_epi(const GemvArgs& a, hipStream_t s) {
     const dim3 grid((a.N + R - 1) / R), block(256);
@@ -228,9 +703,354 @@ int emu_gemv_rows_per_block(int N, int K, bool norm) {
     return R;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA weight-streaming engine (decode, M = 1, bf16).  One persistent 4-wave workgroup per CU: wave 0 is a LOADER
+// that streams this CU's contiguous slice of W through an 8-slot LDS ring with `global_load_lds ... nt` (16 B per
+// lane, 1 KiB per instruction, no VGPR staging) and never waits on arithmetic -- three chunks stay in flight behind
+// the one being retired (counted s_waitcnt vmcnt(N)); waves 1-3 are CONSUMERS that first build the (RMS-normalised)
+// activation vector in LDS, then retire chunks with v_dot2c_f32_bf16 straight out of LDS.  Ring hand-off is two
+// monotonic LDS counters per slot (ready / done), so the HBM queue of every CU stays full from the first instruction
+// of the launch to the last chunk, independent of block scheduling rounds.  Rows are whole KiB (K % 512 == 0) and a
+// row is cut into C equal-ish chunks of <= 13 KiB; partial sums are combined in a fixed order in the epilogue.
+namespace {
+constexpr int ST_MAXSLOT = 12;
+constexpr int ST_MAXKIB = 13;
+constexpr int ST_DEPTH = 3;                         // chunks left in flight while the oldest is awaited
+constexpr int ST_SPIN_LIMIT = 1 << 21;
+
+__device__ unsigned int g_stream_giveups = 0;       // a bounded spin expired (protocol bug): results are invalid
+
+struct StreamGeom {
+    int C;            // chunks per row
+    int kc_base;      // KiB per chunk (the first `extra` chunks carry one more)
+    int extra;
+    int slot_bytes;
+    int part_floats;
+    int unit;         // rows are dealt to workgroups in units of 1 (2 for SwiGLU pairs)
+    int nl, nslot;    // loader waves (consumers = 4 - nl), ring slots
+    int debug;        // 1: loader free-runs, consumers idle (bandwidth probe); 2: consumers skip the arithmetic
+};
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define EMU_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        EMU_VM(0) EMU_VM(3) EMU_VM(6) EMU_VM(9) EMU_VM(12) EMU_VM(15) EMU_VM(18) EMU_VM(21) EMU_VM(24) EMU_VM(27)
+        EMU_VM(30) EMU_VM(33) EMU_VM(36) EMU_VM(39)
+#undef EMU_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ bool spin_ge(volatile unsigned int* f, unsigned int target) {
+    int n = 0;
+    while (*f < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > ST_SPIN_LIMIT) return false;
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+// LDS flag accesses of the LOADER wave go through inline asm: the compiler's waitcnt pass treats every LDS access it
+// can see as possibly aliasing an in-flight global_load_lds and drains the DMA queue (s_waitcnt vmcnt(0)) in front of
+// it, which would serialise the stream to one chunk in flight.
+__device__ __forceinline__ unsigned int lds_addr(const volatile void* p) {
+    return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const volatile void*)p;
+}
+__device__ __forceinline__ unsigned int lds_load_u32(unsigned int addr) {
+    unsigned int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_store_u32(unsigned int addr, unsigned int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ bool spin_ge_asm(unsigned int addr, unsigned int target) {
+    int n = 0;
+    while (lds_load_u32(addr) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > ST_SPIN_LIMIT) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ float dot2(unsigned int w, unsigned int x, float acc) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
+}
+
+template <bool NORM, int EPI>
+__global__ __launch_bounds__(256, 1) void gemv_stream_kernel(const GemvArgs a, const StreamGeom g) {
+    extern __shared__ __align__(1024) unsigned char smem[];
+    unsigned char* ring = smem;
+    unsigned char* xs = smem + g.nslot * g.slot_bytes;                      // bf16 activation vector, K elements
+    float* part = reinterpret_cast<float*>(xs + (size_t)a.K * 2);
+    volatile unsigned int* ready = reinterpret_cast<volatile unsigned int*>(part + g.part_floats);
+    volatile unsigned int* done = ready + ST_MAXSLOT;
+    volatile float* ss_part = reinterpret_cast<volatile float*>(done + ST_MAXSLOT);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int NL = g.nl, NC = 4 - g.nl;                                     // loader waves 0..NL-1, consumers after
+    const int units = a.N / g.unit;
+    const int base = units / (int)gridDim.x, rem = units % (int)gridDim.x;
+    const int bid = blockIdx.x;
+    const int r0 = (bid * base + (bid < rem ? bid : rem)) * g.unit;
+    const int nrows = (base + (bid < rem ? 1 : 0)) * g.unit;
+    const int nchunks = nrows * g.C;
+    const size_t row_bytes = (size_t)a.K * 2;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (size_t)r0 * row_bytes;
+
+    auto chunk_kib = [&](int c) { return g.kc_base + (c < g.extra ? 1 : 0); };
+    auto chunk_off = [&](int c) { return (c * g.kc_base + (c < g.extra ? c : g.extra)) * 1024; };
+    auto issue = [&](int q) {                       // loader: DMA chunk q into its ring slot
+        const int row = q / g.C, c = q - row * g.C;
+        const unsigned char* src = wbase + (size_t)row * row_bytes + chunk_off(c) + lane * 16;
+        unsigned char* dst = ring + (q % g.nslot) * g.slot_bytes;
+        const int kc = chunk_kib(c);
+        for (int i = 0; i < kc; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
+    };
+
+    // loader wave l owns chunks l, l + NL, ...; `issued` / `published` count its own chunks
+    const int mine = wave < NL ? (nchunks - wave + NL - 1) / NL : 0;
+    int issued = 0;
+    if (wave < NL) {
+        const int pre = mine < ST_DEPTH ? mine : ST_DEPTH;                  // slots are free at launch: no waits
+        for (; issued < pre; ++issued) issue(wave + issued * NL);
+    } else {
+        const int ct = tid - 64 * NL, nct = 64 * NC;                        // consumer threads build x in LDS
+        if (ct < 2 * ST_MAXSLOT) ready[ct] = 0;                             // ready[] and done[] are contiguous
+        if constexpr (NORM) {
+            float ss = 0.f;
+            for (int vi = ct; vi < (a.K >> 3); vi += nct) {
+                float f[8];
+                unpack8(ld16(a.x + vi * 8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) ss_part[wave - NL] = ss;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // A: flags + ss partials visible
+    if (wave >= NL) {
+        const int ct = tid - 64 * NL, nct = 64 * NC;
+        float rinv = 1.f;
+        if constexpr (NORM) {
+            float t = 0.f;
+            for (int i = 0; i < NC; ++i) t += ss_part[i];
+            rinv = rsqrtf(t / (float)a.K + a.eps);
+        }
+        for (int vi = ct; vi < (a.K >> 3); vi += nct) {
+            u32x4 v = ld16(a.x + vi * 8);
+            if constexpr (NORM) {
+                float f[8], gw[8];
+                unpack8(v, f);
+                unpack8(ld16(a.norm_w + vi * 8), gw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = bfround(gw[j] * bfround(f[j] * rinv));
+                v = pack8(f);
+            }
+            *reinterpret_cast<u32x4*>(xs + (size_t)vi * 16) = v;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // B: x resident in LDS
+
+    bool ok = true;
+    if (wave < NL) {
+        int published = 0;
+        const int keep = ST_DEPTH * g.kc_base;                              // loads of the DEPTH newest chunks >= keep
+        const unsigned int ready_a = lds_addr(ready), done_a = lds_addr(done);
+        while (published < mine && ok) {
+            if (issued < mine) {
+                const int q = wave + issued * NL;
+                const int s = q % g.nslot, gen = q / g.nslot;
+                if (gen > 0 && g.debug != 1) ok = spin_ge_asm(done_a + 4 * s, (unsigned)gen);   // previous tenant retired
+                issue(q);
+                ++issued;
+                if (issued - published > ST_DEPTH) {
+                    wait_vmcnt_dyn(keep);
+                    const int qp = wave + published * NL;
+                    lds_store_u32(ready_a + 4 * (qp % g.nslot), (unsigned)(qp / g.nslot + 1));
+                    ++published;
+                }
+            } else {
+                wait_vmcnt_dyn(0);
+                for (; published < mine; ++published) {
+                    const int qp = wave + published * NL;
+                    lds_store_u32(ready_a + 4 * (qp % g.nslot), (unsigned)(qp / g.nslot + 1));
+                }
+            }
+        }
+        wait_vmcnt_dyn(0);
+    } else {
+        for (int q = wave - NL; q < nchunks && ok && g.debug != 1; q += NC) {
+            const int s = q % g.nslot, gen = q / g.nslot;
+            const int row = q / g.C, c = q - row * g.C;
+            ok = spin_ge(&ready[s], (unsigned)(gen + 1));
+            const u32x4* wp = reinterpret_cast<const u32x4*>(ring + s * g.slot_bytes) + lane;
+            const u32x4* xp = reinterpret_cast<const u32x4*>(xs + chunk_off(c)) + lane;
+            const int kc = g.debug == 2 ? 0 : chunk_kib(c);
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+            for (int i = 0; i < kc; ++i) {
+                const u32x4 w = wp[i * 64], xv = xp[i * 64];
+                acc0 = dot2(w.x, xv.x, acc0);
+                acc1 = dot2(w.y, xv.y, acc1);
+                acc0 = dot2(w.z, xv.z, acc0);
+                acc1 = dot2(w.w, xv.w, acc1);
+            }
+            const float v = wave_sum(acc0 + acc1);
+            asm volatile("" ::: "memory");
+            if (lane == 0) {
+                part[q] = v;
+                done[s] = (unsigned)(gen + 1);                               // slot free for chunk q + nslot
+            }
+        }
+    }
+    if (!ok && lane == 0) atomicAdd(&g_stream_giveups, 1u);
+    __syncthreads();
+
+    // epilogue: every thread finishes rows of this workgroup (fixed-order combine of the C partial sums)
+    if constexpr (EPI == EPI_SWIGLU) {
+        for (int j = tid; j < nrows / 2; j += 256) {
+            float gt = 0.f, up = 0.f;
+            for (int c = 0; c < g.C; ++c) { gt += part[(2 * j) * g.C + c]; up += part[(2 * j + 1) * g.C + c]; }
+            const int n = r0 + 2 * j;
+            if (a.bias) { gt += bf2f(a.bias[n]); up += bf2f(a.bias[n + 1]); }
+            gt = bfround(gt); up = bfround(up);
+            a.out[n >> 1] = f2bf(bfround(silu(gt)) * up);
+        }
+    } else {
+        for (int r = tid; r < nrows; r += 256) {
+            float v = 0.f;
+            for (int c = 0; c < g.C; ++c) v += part[r * g.C + c];
+            const int n = r0 + r;
+            if (a.bias) v += bf2f(a.bias[n]);
+            v = bfround(v);
+            if constexpr (EPI == EPI_RESID) v = v + bf2f(a.res[n]);
+            a.out[n] = f2bf(v);
+        }
+    }
+}
+
+// Off by default: measured on MI355X the engine tops out at the same ~5.6-5.9 TB/s as the block kernels even with the
+// consumers idle (two loader waves; one loader wave: 4.2 TB/s), see DESIGN.md section 4.  Kept as a selectable path.
+int g_stream_engine = -1;
+bool stream_engine_enabled() {
+    if (g_stream_engine < 0) {
+        const char* env = getenv("EMU_GEMV_STREAM");
+        g_stream_engine = env ? (atoi(env) != 0) : 0;
+    }
+    return g_stream_engine != 0;
+}
+
+int stream_cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return v;
+    }();
+    return n;
+}
+
+// Shapes the engine takes; everything else stays on gemv_kernel.
+bool stream_applicable(const GemvArgs& a) {
+    if (!stream_engine_enabled()) return false;
+    if (a.M != 1 || a.wscale || (a.K & 511) || a.ldw != a.K) return false;
+    if (a.epi != EPI_NONE && a.epi != EPI_RESID && a.epi != EPI_SWIGLU) return false;
+    const int ncu = stream_cu_count();
+    if (ncu < 1 || a.N < 8 * ncu) return false;                             // >= 8 rows per CU
+    if ((size_t)a.N * a.K * 2 < ((size_t)16 << 20)) return false;           // small matrices are launch-latency work
+    const int row_kib = a.K >> 9;
+    const int C = (row_kib + ST_MAXKIB - 1) / ST_MAXKIB;
+    const int kc_base = row_kib / C;
+    if ((kc_base * ST_DEPTH) % 3 != 0 || kc_base * ST_DEPTH > 39) return false;
+    if ((ST_DEPTH + 1) * (kc_base + 1) > 63) return false;                  // vmcnt is a 6-bit counter
+    return true;
+}
+
+template <bool NORM, int EPI>
+int launch_stream_t(const GemvArgs& a, const StreamGeom& g, size_t lds, int grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_stream_kernel<NORM, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemv_stream_kernel<NORM, EPI>), dim3(grid), dim3(256), lds, s, a, g);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_stream(const GemvArgs& a, hipStream_t s) {
+    const int ncu = stream_cu_count();
+    StreamGeom g;
+    const int row_kib = a.K >> 9;
+    g.C = (row_kib + ST_MAXKIB - 1) / ST_MAXKIB;
+    g.kc_base = row_kib / g.C;
+    g.extra = row_kib % g.C;
+    g.slot_bytes = (g.kc_base + (g.extra ? 1 : 0)) * 1024;
+    g.unit = a.epi == EPI_SWIGLU ? 2 : 1;
+    static const char* dbg = getenv("EMU_ST_DEBUG");
+    g.debug = dbg ? atoi(dbg) : 0;
+    const int units = a.N / g.unit;
+    g.part_floats = ((units + ncu - 1) / ncu) * g.unit * g.C;
+    static const char* nl_env = getenv("EMU_ST_NL");
+    g.nl = nl_env ? atoi(nl_env) : 2;
+    if (g.nl < 1 || g.nl > 3) return -22;
+    const size_t fixed = (size_t)a.K * 2 + (size_t)g.part_floats * 4 + 2 * ST_MAXSLOT * 4 + 16;
+    g.nslot = (int)((160 * 1024 - fixed) / g.slot_bytes);                   // the ring takes what LDS is left
+    if (g.nslot > ST_MAXSLOT) g.nslot = ST_MAXSLOT;
+    if (g.nslot < g.nl * (ST_DEPTH + 1) + 1) return -22;
+    const size_t lds = (size_t)g.nslot * g.slot_bytes + fixed;
+    const bool norm = a.norm_w != nullptr;
+#define EMU_ST_CASE(E)                                                                                               \
+    case E: return norm ? launch_stream_t<true, E>(a, g, lds, ncu, s) : launch_stream_t<false, E>(a, g, lds, ncu, s);
+    switch (a.epi) {
+        EMU_ST_CASE(EPI_NONE)
+        EMU_ST_CASE(EPI_RESID)
+        EMU_ST_CASE(EPI_SWIGLU)
+        default: return -22;
+    }
+#undef EMU_ST_CASE
+}
+}  // namespace
+
+void emu_gemv_stream_engine_set(int enable) { g_stream_engine = enable ? 1 : 0; }
+
+unsigned int emu_gemv_stream_giveups_read() {
+    unsigned int v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_stream_giveups), sizeof v);
+    return v;
+}
+
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.M < 1 || a.M > 8 || (a.K & 7) || a.N < 1) return -22;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return -22;
+    if (a.wscale && ((a.K & 15) || a.M > 2)) return -22;
+    { const int st = try_launch_rt(a, s); if (st != 1) return st; }
+    if (a.wscale) {                                  // fp8 weight stream (decode, batch <= 2 built)
+        // 16 weights per 16-byte load: K = 6656 is only 416 groups, so short rows run 2-wave blocks (3.25 trips per
+        // lane, like the bf16 kernel) and long rows (down_proj, K = 17920) 4-wave blocks
+        static const char* f8 = getenv("EMU_GEMV_FP8_NW");
+        const int nw = f8 ? atoi(f8) : 2;
+        static const char* v8 = getenv("EMU_GEMV_FP8_V8");               // A/B: 8-byte weight loads, R rows per block
+        const int v8r = v8 ? atoi(v8) : (a.K <= 8192 ? 8 : 0);   // 8-byte loads keep 3.25 trips per lane at K = 6656
+        if (v8r == 16) return a.M <= 1 ? launch_fp8v8<16, 1, 4>(a, s) : launch_fp8v8<16, 2, 4>(a, s);
+        if (v8r == 8) return a.M <= 1 ? launch_fp8v8<8, 1, 4>(a, s) : launch_fp8v8<8, 2, 4>(a, s);
+        if (v8r == 32) return a.M <= 1 ? launch_fp8v8<32, 1, 4>(a, s) : launch_fp8v8<32, 2, 4>(a, s);
+        const bool small = (a.N + 7) / 8 < 512;
+        if (a.M <= 1) {
+            if (small) return launch_fp8<4, 1, 2>(a, s);
+            return nw == 2 ? launch_fp8<8, 1, 2>(a, s) : nw == 1 ? launch_fp8<8, 1, 1>(a, s) : launch_fp8<8, 1, 4>(a, s);
+        }
+        if (small) return launch_fp8<4, 2, 2>(a, s);
+        return nw == 2 ? launch_fp8<8, 2, 2>(a, s) : nw == 1 ? launch_fp8<8, 2, 1>(a, s) : launch_fp8<8, 2, 4>(a, s);
+    }
+    if (stream_applicable(a)) return launch_stream(a, s);
     static const char* force_r = getenv("EMU_GEMV_R");     // A/B runs
     int R = a.rows_per_block > 0 ? a.rows_per_block
                                  : (force_r ? atoi(force_r) : emu_gemv_rows_per_block(a.N, a.K, a.norm_w != nullptr));

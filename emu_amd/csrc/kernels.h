@@ -19,8 +19,12 @@ struct GemvArgs {
     float eps;
     int epi;
     int rows_per_block;     // 0 = heuristic
+    const float* wscale;    // non-null: W holds OCP fp8 e4m3 bytes [N, ldw] with one fp32 scale per row (K % 16 == 0)
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
+// LDS-DMA streaming engine diagnostics: number of bounded ring spins that expired since load (must stay 0)
+unsigned int emu_gemv_stream_giveups_read();
+void emu_gemv_stream_engine_set(int enable);
 
 // Implicit-GEMM 3x3 convolution over an NHWC activation: A is [B, Hin, Win, Cin], the GEMM row m is the output
 // pixel (b, yo, xo), K = 9*Cin ordered (ky, kx, ci) -- weights repacked to [Cout, 3, 3, Cin].  Cin % 64 == 0.
@@ -150,4 +154,6 @@ int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out
 
 // in-place row softmax of x [rows, ld] over the first `cols` columns: x = bf16(softmax(float(x) * scale))
 // (materialised-score attention for head dims the flash kernel does not cover: the VAE mid block, D = 512)
+// per-row fp8 e4m3fn quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = rne(w / scale)
+int launch_quant_fp8_rows(const bf16_t* w, int ldw, uint8_t* q, int ldq, float* scale, int N, int K, hipStream_t s);
 int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s);

@@ -174,7 +174,7 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
 int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, const bf16_t* res, bf16_t* C, int M, int N, int K,
          int lda, int ldres, int ldc, int epi, hipStream_t s) {
     if (M <= 8) {
-        GemvArgs g{A, Wt, nullptr, bias, res, C, M, N, K, lda, K, ldres, ldc, 0.f, epi, 0};
+        GemvArgs g{A, Wt, nullptr, bias, res, C, M, N, K, lda, K, ldres, ldc, 0.f, epi, 0, nullptr};
         return launch_gemv(g, s);
     }
     GemmArgs g{A, Wt, bias, res, C, M, N, K, lda, K, ldres, ldc, epi, NOCONV, nullptr, 0, 0};

@@ -149,8 +149,42 @@ class LlamaEngine:
 
     def weight_bytes_per_token(self) -> int:
         """Algorithmic bytes one decode step of THIS shard must stream (all packed matrices once + lm_head)."""
-        per = sum(v.numel() * 2 for k, v in self._keep.items() if k.split(".")[1] in ("wqkv", "wo", "wgu", "wdown"))
-        return per + (self.lm_head.numel() * 2 if self.lm_head is not None else 0)
+        b = 1 if getattr(self, "fp8_decode", False) else 2
+        per = sum(v.numel() * b for k, v in self._keep.items() if k.split(".")[1] in ("wqkv", "wo", "wgu", "wdown"))
+        return per + (self.lm_head.numel() * b if self.lm_head is not None else 0)
+
+    # ------------------------------------------------------------------ optional fp8 decode stream
+    def quantize_fp8(self) -> None:
+        """Build per-row-scaled e4m3fn copies of every packed matrix (+ lm_head) on the device and register them for the
+        decode stream (B*T <= 2 rows).  Prefill keeps the bf16 weights, so both sets stay resident (288 GB HBM:
+        33B bf16 + fp8 = 98 GB).  Not a reference feature (the reference is bf16 end to end); off unless enabled."""
+        if not self.ready:
+            raise RuntimeError("quantize_fp8: load all weights first")
+        if getattr(self, "_fp8", None):
+            return
+        self._fp8 = {}
+        for i in range(self.cfg.num_hidden_layers):
+            a = []
+            for k in ("wqkv", "wo", "wgu", "wdown"):
+                q, sc = ops.quantize_fp8_rows(self._keep[f"{i}.{k}"])
+                self._fp8[f"{i}.{k}"] = (q, sc)
+                a += [q.data_ptr(), sc.data_ptr()]
+            check(lib().emu_llama_set_layer_fp8(self.handle, i, *a), "emu_llama_set_layer_fp8", self.ctx.handle)
+        q, sc = ops.quantize_fp8_rows(self.lm_head)
+        self._fp8["lm_head"] = (q, sc)
+        check(lib().emu_llama_set_head_fp8(self.handle, q.data_ptr(), sc.data_ptr()), "emu_llama_set_head_fp8")
+
+    def use_fp8(self, enable: bool = True) -> None:
+        """Switch the decode stream between the bf16 and the fp8 weights (invalidates captured decode graphs)."""
+        if enable:
+            self.quantize_fp8()
+        check(lib().emu_llama_use_fp8(self.handle, int(bool(enable))), "emu_llama_use_fp8", self.ctx.handle)
+        self.fp8_decode = bool(enable)
+
+    def fp8_dequantized(self, key: str) -> torch.Tensor:
+        """fp32 value of a registered fp8 tensor (tests: feed the oracle the exact weights the stream uses)."""
+        q, sc = self._fp8[key]
+        return q.view(torch.float8_e4m3fn).to(torch.float32) * sc[:, None]
 
     # ------------------------------------------------------------------ KV cache / workspace
     def alloc_kv(self, batch: int, s_max: int) -> None:

@@ -50,6 +50,37 @@ def linear(x, w, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = 
     return out
 
 
+def quantize_fp8_rows(w):
+    """Per-row symmetric OCP e4m3fn quantisation of a packed bf16 weight [N, K]: returns (bytes uint8 [N, K], scale fp32
+    [N]) with w ~= fp8(bytes) * scale[:, None]; see emu_quantize_fp8_rows."""
+    _req(w, "w")
+    assert w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    q = torch.empty(N, K, device=w.device, dtype=torch.uint8)
+    sc = torch.empty(N, device=w.device, dtype=torch.float32)
+    check(lib().emu_quantize_fp8_rows(_p(w), w.stride(0), _p(q), q.stride(0), _p(sc), N, K, stream()),
+          "emu_quantize_fp8_rows")
+    return q, sc
+
+
+def linear_fp8w(x, w8, wscale, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = EPI_NONE, out=None):
+    """``linear`` over an fp8 weight stream (decode rows only, M <= 2); see emu_linear_fp8w_bf16."""
+    _req(x, "x"); _req(w8, "w8", torch.uint8); _req(wscale, "wscale", torch.float32)
+    assert x.dim() == 2 and w8.dim() == 2 and x.shape[1] == w8.shape[1], (x.shape, w8.shape)
+    M, K = x.shape
+    N = w8.shape[0]
+    n_out = N // 2 if epi == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, device=x.device, dtype=BF16)
+    _req(out, "out")
+    if res is not None:
+        _req(res, "res")
+    check(lib().emu_linear_fp8w_bf16(_p(x), _p(w8), _p(wscale), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K,
+                                     x.stride(0), w8.stride(0), res.stride(0) if res is not None else 0,
+                                     out.stride(0), float(eps), int(epi), stream()), "emu_linear_fp8w_bf16")
+    return out
+
+
 def rmsnorm(x, w, eps: float, out=None):
     _req(x, "x"); _req(w, "w")
     rows, cols = x.shape

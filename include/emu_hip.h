@@ -42,6 +42,13 @@ int emu_tp_unique_id(void* out128);                      /* rank 0: 128-byte RCC
 int emu_tp_init(emu_ctx* ctx, const void* id128);        /* all ranks: ncclCommInitRank               */
 int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);   /* in-place sum          */
 
+/* Diagnostic of the LDS-DMA weight-streaming GEMV engine (decode rows, K % 512 == 0, >= 16 MiB of weights): number of
+ * bounded ring hand-off spins that expired since the library was loaded.  Non-zero means a launch gave up instead of
+ * hanging the GPU and its output is invalid; the parity tests assert it stays 0. */
+unsigned int emu_gemv_stream_giveups(void);
+/* Select the LDS-DMA engine for the shapes it covers (default 0 = block kernels; env EMU_GEMV_STREAM=1 also enables). */
+void emu_gemv_stream_engine(int enable);
+
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while
  * enabled (eager launches only, not inside stream capture).  read: sum of launch durations (ms), algorithmic
  * weight bytes (2*N*K per launch) and launch count since the last enable. */
@@ -57,6 +64,14 @@ int emu_profile_gemv_read(double* total_ms, double* weight_bytes, long* launches
 int emu_linear_bf16(const void* A, const void* W, const void* bias, const void* res, const void* norm_w,
                     void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi,
                     emu_stream_t s);
+/* emu_linear_bf16 with an fp8 (e4m3fn) weight stream: W8 [N, ldw] bytes, wscale fp32 [N]; M <= 2, K % 16 == 0,
+ * epi in {NONE, RESID, SWIGLU}.  out = epi(bf16((sum_k fp8(W8[n,k]) * x[k]) * wscale[n] + bias[n])) */
+int emu_quantize_fp8_rows(const void* w_bf16, int ldw, void* q_fp8, int ldq, float* scale, int N, int K,
+                          emu_stream_t s);   /* scale[n] = amax_n / 448 (1 if the row is zero); q = rne_e4m3fn(w / scale) */
+int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, const void* bias, const void* res,
+                         const void* norm_w, void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc,
+                         float eps, int epi, emu_stream_t s);
+
 /* LlamaRMSNorm (transformers; emu.py:133-138): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) */
 int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, int ldx, int ldy, float eps,
                      emu_stream_t s);
@@ -122,6 +137,15 @@ int emu_llama_create(emu_ctx* ctx, const emu_llama_cfg* cfg, emu_llama** out);
 void emu_llama_destroy(emu_llama* m);
 int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* wo, const void* wgu,
                         const void* wdown, const void* ln1, const void* ln2);
+/* Optional fp8 decode stream (not in the reference, which runs bf16 end to end -- Emu2/emu/chat.py:199-213; this is
+ * the weight-only quantised serving mode of BASELINE.json configs[5]).  W8: OCP e4m3fn bytes in the SAME packed row
+ * layout as the bf16 weight; scale: fp32 [rows], W ~= fp8 * scale[row].  Only decode rows (B*T <= 2) use them; prefill
+ * keeps the bf16 weights.  emu_llama_use_fp8 toggles the stream (fails if the fp8 tensors were not registered). */
+int emu_llama_set_layer_fp8(emu_llama* m, int layer, const void* wqkv8, const float* sqkv, const void* wo8,
+                            const float* so, const void* wgu8, const float* sgu, const void* wdown8,
+                            const float* sdown);
+int emu_llama_set_head_fp8(emu_llama* m, const void* lm_head8, const float* lm_scale);
+int emu_llama_use_fp8(emu_llama* m, int enable);
 int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed,
                        const void* rope_cos, const void* rope_sin);
 int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max);

@@ -57,6 +57,20 @@ def main():
             ops.linear(x, ws[st["i"]], res=res, norm_w=g, eps=1e-6, epi=epi)
         cases.append((f"gemv {name} M{M} N{N} K{K}", fn, 2.0 * N * K, "hbm"))
 
+    def gemv8(name, M, N, K, epi=0, norm=False):
+        n_copy = max(1, int(600e6 // (N * K)) + 1)
+        ws = [ops.quantize_fp8_rows(r(N, K, scale=0.02)) for _ in range(n_copy)]
+        x = r(M, K)
+        res = r(M, N) if epi == 1 else None
+        g = r(K) if norm else None
+        st = {"i": 0}
+
+        def fn():
+            st["i"] = (st["i"] + 1) % n_copy
+            q, sc = ws[st["i"]]
+            ops.linear_fp8w(x, q, sc, res=res, norm_w=g, eps=1e-6, epi=epi)
+        cases.append((f"gemv-fp8 {name} M{M} N{N} K{K}", fn, 1.0 * N * K, "hbm"))
+
     def gemm(name, M, N, K, epi=0):
         x, w = r(M, K), r(N, K, scale=0.02)
         res = r(M, N) if epi == 1 else None
@@ -80,6 +94,11 @@ def main():
     gemv("gateup+norm+swiglu", 1, 35840, 6656, 2, True)
     gemv("down+res", 1, 6656, 17920, 1)
     gemv("lm_head+norm", 1, 32274, 6656, 0, True)
+    gemv8("qkv+norm", 1, 19968, 6656, 0, True)
+    gemv8("o+res", 1, 6656, 6656, 1)
+    gemv8("gateup+norm+swiglu", 1, 35840, 6656, 2, True)
+    gemv8("down+res", 1, 6656, 17920, 1)
+    gemv8("lm_head+norm", 1, 32274, 6656, 0, True)
     gemv("qkv beams5", 5, 19968, 6656, 0, True)
     gemv("tp8 qkv", 1, 2688, 6656, 0, True)
     gemv("tp8 o", 1, 6656, 896, 1)
