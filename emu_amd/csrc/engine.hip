@@ -42,7 +42,11 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
            bf16_t* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, hipStream_t s,
            const float* wscale = nullptr) {
     if (wscale && M > 2) return -22;                 // fp8 weights are a decode-only stream
-    if (M <= 8) {
+    // rows <= 8 stream the weights through the GEMV family (M >= 2 without a fused norm: skinny MFMA kernel); 9..16
+    // rows too when the MFMA kernel covers the shape -- a 128-row GEMM tile would be > 87 % padding there
+    const bool skinny = M > 8 && M <= 16 && !norm_w && (K & 31) == 0 && (ldw & 7) == 0 && (lda & 7) == 0 &&
+                        (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SWIGLU || epi == EPI_SILU || epi == EPI_GELU);
+    if (M <= 8 || skinny) {
         GemvArgs g{A, W, norm_w, bias, res, C, M, N, K, lda, ldw, ldres, ldc, eps, epi, 0, wscale};
         if (!g_prof.on) return launch_gemv(g, s);
         if (g_prof.used == g_prof.ev.size()) {
@@ -353,9 +357,9 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         if (f8 && !L8.wqkv) return fail(cx, -22, "emu_llama_forward: fp8 decode enabled but fp8 layer weights not set");
         if (f8) {
             TRY(cx, linear(hA, B(L8.wqkv), nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s, L8.sqkv));
-        } else if (M <= 8) {
+        } else if (M == 1) {
             TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
-        } else {
+        } else {                                     // 2..16 rows: norm once, skinny MFMA stream; more: GEMM
             TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
             TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s));
         }
@@ -381,7 +385,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         // ---- SwiGLU MLP
         if (f8) {
             TRY(cx, linear(w.hB, B(L8.wgu), nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s, L8.sgu));
-        } else if (M <= 8) {
+        } else if (M == 1) {
             TRY(cx, linear(w.hB, L.wgu, nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s));
         } else {
             TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
@@ -407,7 +411,7 @@ int emu_llama_logits(emu_llama* m, const void* hidden, int ldh, int M, void* log
     if (m->fp8_decode && M <= 2 && m->lm_head8)
         return linear(B(hidden), B(m->lm_head8), nullptr, nullptr, m->final_norm, B(logits), M, c.vocab, c.hidden, ldh,
                       c.hidden, 0, ld, c.rms_eps, EPI_NONE, S(s), m->lm_scale8);
-    if (M <= 8)
+    if (M == 1 || (M <= 8 && ws_bytes < (size_t)M * c.hidden * 2))
         return linear(B(hidden), m->lm_head, nullptr, nullptr, m->final_norm, B(logits), M, c.vocab, c.hidden, ldh,
                       c.hidden, 0, ld, c.rms_eps, EPI_NONE, S(s));
     if (ws_bytes < (size_t)M * c.hidden * 2) return fail(m->ctx, -12, "emu_llama_logits: workspace too small");

@@ -362,6 +362,112 @@ int try_launch_rt(const GemvArgs& a, hipStream_t s) {
     return 1;
 }
 
+// Skinny-M weight stream on the matrix cores (2 <= M <= 16 rows: beam search, CFG pairs).  The FMA kernel above costs
+// M FMAs + an unpack per weight and goes VALU-bound past M = 2 (M = 5: 0.9 TB/s); here one v_mfma_f32_16x16x32_bf16
+// consumes a 16-row x 32-k weight fragment exactly as it arrives from HBM (A operand: lane -> row l & 15, 8 consecutive k
+// at 8 * (l >> 4)) against the activations as the B operand (col = activation row, same k), so the VALU does nothing in
+// the loop.  A block owns 16 weight rows; its 4 waves interleave over 32-k blocks (together 256 contiguous bytes per
+// row per step) and reduce through LDS.  Activations are re-read from L2 per fragment (no LDS staging, any K % 32 == 0).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const GemvArgs a) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    __shared__ f32x4_t part[4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = n0 + i < a.N ? n0 + i : a.N - 1;
+    const int mrow = i < a.M ? i : a.M - 1;                            // columns >= M duplicate the last row (discarded)
+    const bf16_t* wp = a.W + (size_t)nrow * a.ldw + g * 8;
+    const bf16_t* xp = a.x + (size_t)mrow * a.ldx + g * 8;
+    const int KB = a.K >> 5;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    int kb = wave;
+    for (; kb + 28 < KB; kb += 32) {                                   // 8 fragments (128 B of weights per lane) in flight
+        u32x4 wv[8], xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wv[j] = ld_stream(reinterpret_cast<const u32x4*>(wp + (kb + 4 * j) * 32));
+            xv[j] = ld16(xp + (kb + 4 * j) * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[j]),
+                                                          __builtin_bit_cast(bf16x8_t, xv[j]), acc, 0, 0, 0);
+    }
+    for (; kb < KB; kb += 4) {
+        const u32x4 wv = ld_stream(reinterpret_cast<const u32x4*>(wp + kb * 32));
+        const u32x4 xv = ld16(xp + kb * 32);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xv),
+                                                      acc, 0, 0, 0);
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4_t v = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const f32x4_t t = part[w][lane];
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    // lane holds C[weight row 4g + r][activation row i], r = 0..3
+    const int m = i;
+    if (m >= a.M) return;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            const int n = n0 + 4 * g + r;
+            if (n + 1 < a.N) {
+                float gt = v[r], up = v[r + 1];
+                if (a.bias) { gt += bf2f(a.bias[n]); up += bf2f(a.bias[n + 1]); }
+                gt = bfround(gt); up = bfround(up);
+                a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
+            }
+        }
+    } else {
+        float o[4];
+        bool full = n0 + 4 * g + 3 < a.N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 4 * g + r;
+            float t = v[r];
+            if (n < a.N) {
+                if (a.bias) t += bf2f(a.bias[n]);
+                t = bfround(t);
+                if constexpr (EPI == EPI_SILU) t = bfround(silu(t));
+                if constexpr (EPI == EPI_GELU) t = bfround(gelu_erf(t));
+                if constexpr (EPI == EPI_RESID) t = t + bf2f(a.res[(size_t)m * a.ldres + n]);
+            }
+            o[r] = t;
+        }
+        bf16_t* dst = a.out + (size_t)m * a.ldo + n0 + 4 * g;
+        if (full && ((reinterpret_cast<size_t>(dst) & 7) == 0)) {
+            uint2 pk;
+            pk.x = packbf(o[0], o[1]); pk.y = packbf(o[2], o[3]);
+            *reinterpret_cast<uint2*>(dst) = pk;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + 4 * g + r < a.N) dst[r] = f2bf(o[r]);
+        }
+    }
+}
+
+int launch_gemv_mfma(const GemvArgs& a, hipStream_t s) {
+    const dim3 grid((a.N + 15) / 16), block(256);
+#define EMU_MF_CASE(E) case E: hipLaunchKernelGGL((gemv_mfma_kernel<E>), grid, block, 0, s, a); break;
+    switch (a.epi) {
+        EMU_MF_CASE(EPI_NONE)
+        EMU_MF_CASE(EPI_RESID)
+        EMU_MF_CASE(EPI_SWIGLU)
+        EMU_MF_CASE(EPI_SILU)
+        EMU_MF_CASE(EPI_GELU)
+        default: return -22;
+    }
+#undef EMU_MF_CASE
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
 // fp8 (OCP e4m3fn) weight stream: half the HBM bytes per token.  One 16-byte load = 16 weights of one row; the per-row
 // fp32 scale is applied once to the fp32 dot product.  Same fused RMSNorm prologue / epilogues as the bf16 kernel.
 template <int R, int MB, bool NORM, int EPI, int NW>
@@ -1028,8 +1134,13 @@ unsigned int emu_gemv_stream_giveups_read() {
 }
 
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
-    if (a.M < 1 || a.M > 8 || (a.K & 7) || a.N < 1) return -22;
+    if (a.M < 1 || a.M > 16 || (a.K & 7) || a.N < 1) return -22;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return -22;
+    static const char* mf_env = getenv("EMU_GEMV_MFMA");               // A/B: 0 keeps the FMA kernel for M >= 2
+    if (a.M >= 2 && !a.wscale && !a.norm_w && (a.K & 31) == 0 && (a.ldw & 7) == 0 && (a.ldx & 7) == 0 &&
+        !(mf_env && atoi(mf_env) == 0))
+        return launch_gemv_mfma(a, s);
+    if (a.M > 8) return -22;
     if (a.wscale && ((a.K & 15) || a.M > 2)) return -22;
     { const int st = try_launch_rt(a, s); if (st != 1) return st; }
     if (a.wscale) {                                  // fp8 weight stream (decode, batch <= 2 built)

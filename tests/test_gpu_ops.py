@@ -68,6 +68,36 @@ def test_gemv(M, N, K, epi):
     close(got, ref_linear(x, w, bias, res, epi=epi), what=f"gemv M{M} N{N} K{K} epi{epi}")
 
 
+@pytest.mark.parametrize("M", [2, 5, 9, 13, 16])
+@pytest.mark.parametrize("N,K", [(50, 64), (1002, 896), (264, 6656), (96, 17920)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_skinny_mfma_stream(M, N, K, epi):
+    """2..16 activation rows (beam search, CFG pairs) stream the weights through the 16x16x32 MFMA kernel: ragged N
+    (partial 16-row groups, odd store alignment), every epilogue, bias."""
+    ops = _ops()
+    x, w = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.05)
+    bias = rnd(N, seed=33) if epi in (0, 2, 3) else None
+    res = rnd(M, N, seed=34) if epi == 1 else None
+    got = ops.linear(x.cuda(), w.cuda(), bias=None if bias is None else bias.cuda(),
+                     res=None if res is None else res.cuda(), epi=epi)
+    close(got, ref_linear(x, w, bias, res, epi=epi), what=f"skinny M{M} N{N} K{K} epi{epi}")
+
+
+def test_skinny_mfma_identity_asymmetric():
+    """x = the first 16 rows of I with an asymmetric, exactly representable W: out[m, n] must equal W[n, m] exactly
+    (catches any row/col or k-lane swap in the 16x16x32 fragment maps); strided x and out rows."""
+    ops = _ops()
+    K, N, M = 96, 80, 16
+    x = torch.eye(K)[:M].to(BF16)
+    w = ((torch.arange(N * K).reshape(N, K) * 7) % 251 - 125).float().to(BF16)
+    xb = torch.zeros(M, 2 * K, dtype=BF16)
+    xb[:, :K] = x
+    out = torch.zeros(M, N + 8, dtype=BF16, device="cuda")
+    ops.linear(xb.cuda()[:, :K], w.cuda(), out=out[:, :N])
+    assert torch.equal(out[:, :N].float().cpu(), w.float()[:, :M].t().contiguous())
+    assert float(out[:, N:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M", [1, 4])
 @pytest.mark.parametrize("epi", [0, 2])
 def test_gemv_fused_rmsnorm(M, epi):
