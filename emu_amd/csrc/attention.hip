@@ -389,23 +389,18 @@ constexpr int DF_CHUNK = 128;                          // keys per workgroup (32
 
 template <int D>
 __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs a, int nsplit) {
-    constexpr int LPK = D / 8;                         // lanes per key row (16 bytes each)
+    constexpr int LPK = D / 8;                         // lanes per key row (16 bytes each): 16 (D=128) or 8 (D=64)
     constexpr int KPI = 64 / LPK;                      // keys per wave iteration
     constexpr int ITER = (DF_CHUNK / 4) / KPI;
-    __shared__ float sm[4][D + 2];
+    constexpr int NP = 4 * KPI;                        // partial states per block: (wave, key group)
+    __shared__ float sm[NP][D + 2];
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane / LPK, dl = lane % LPK, d0 = dl * 8;
     const int slot = a.slot[b], ctx = slot + 1;
-    const int kstart = a.kstart ? a.kstart[b] : 0;
     const int k0 = split * DF_CHUNK;
-    float* wout = a.ws + (((size_t)b * a.H + h) * nsplit + split) * (D + 2);
-    if (k0 >= ctx) {                                   // split beyond the live context (launch sized for ctx_max)
-        if (tid < D) wout[tid] = 0.f;
-        if (tid == 0) { wout[D] = -INFINITY; wout[D + 1] = 0.f; }
-        return;
-    }
-    // ---- RoPE of q and of the new key (this lane's 8-wide slice), transformers' rounding points
+    if (k0 >= ctx) return;                             // split beyond the live context: no work, not counted
+    const int kstart = a.kstart ? a.kstart[b] : 0;
     const int pos = a.pos[b];
     const bf16_t* row = a.qkv + (size_t)b * 3 * a.H * D;
     const bf16_t* qh = row + (size_t)h * D;
@@ -414,28 +409,14 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     constexpr int half = D / 2;
     const int dp = (d0 + half) % D, dc = d0 % half;
     const float sgn = d0 < half ? -1.f : 1.f;
-    float c[8], sn[8];
-    unpack8(ld16(a.cos + (size_t)pos * D + dc), c);
-    unpack8(ld16(a.sin + (size_t)pos * D + dc), sn);
-    auto rope = [&](const bf16_t* x, float* out) {
-        float x1[8], x2[8];
-        unpack8(ld16(x + d0), x1);
-        unpack8(ld16(x + dp), x2);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = bfround(bfround(x1[j] * c[j]) + bfround(sgn * x2[j] * sn[j]));
-    };
-    float q[8], nk[8], nv[8];
-    rope(qh, q);
-    rope(kh, nk);
-    unpack8(ld16(vh + d0), nv);
     const size_t hb = ((size_t)b * a.H + h) * a.S_max;
-    if (split == slot / DF_CHUNK && wave == 0 && g == 0) {       // append the new token to the cache (once)
-        st16(a.kcache + (hb + slot) * D + d0, pack8(nk));
-        st16(a.vcache + (hb + slot) * D + d0, pack8(nv));
-    }
     const bf16_t* kc = a.kcache + hb * D;
     const bf16_t* vc = a.vcache + hb * D;
-    // ---- all K/V loads of this wave's 32 keys are issued up front (coalesced: LPK lanes cover one row)
+
+    // ---- every load of the block is issued before anything is consumed: RoPE inputs first (the in-order vmcnt lets
+    // the rotation start while the K/V rows are still in flight), then this wave's 32 keys (LPK lanes cover one row)
+    const u32x4 cv = ld16(a.cos + (size_t)pos * D + dc), sv = ld16(a.sin + (size_t)pos * D + dc);
+    const u32x4 q1v = ld16(qh + d0), q2v = ld16(qh + dp), k1v = ld16(kh + d0), k2v = ld16(kh + dp), nvv = ld16(vh + d0);
     u32x4 kr[ITER], vr[ITER];
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -445,78 +426,104 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
         kr[it] = ld ? ld16(kc + (size_t)key * D + d0) : z;
         vr[it] = ld ? ld16(vc + (size_t)key * D + d0) : z;
     }
-    float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- RoPE of q and of the new key (this lane's 8-wide slice), transformers' rounding points
+    float c[8], sn[8], q[8], nk[8], nv[8];
+    unpack8(cv, c);
+    unpack8(sv, sn);
+    {
+        float x1[8], x2[8];
+        unpack8(q1v, x1); unpack8(q2v, x2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = bfround(bfround(x1[j] * c[j]) + bfround(sgn * x2[j] * sn[j]));
+        unpack8(k1v, x1); unpack8(k2v, x2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) nk[j] = bfround(bfround(x1[j] * c[j]) + bfround(sgn * x2[j] * sn[j]));
+    }
+    unpack8(nvv, nv);
+    if (split == slot / DF_CHUNK && wave == 0 && g == 0) {       // append the new token to the cache (once)
+        st16(a.kcache + (hb + slot) * D + d0, pack8(nk));
+        st16(a.vcache + (hb + slot) * D + d0, pack8(nv));
+    }
+    // ---- scores of this lane group's ITER keys (DPP row reductions, all independent), then a two-pass softmax in
+    // registers: no running max / rescale chain
+    float sd[ITER];
+    float m = -INFINITY;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
-        const bool valid = key < ctx && key >= kstart;
-        float kf[8], vf[8];
+        float kf[8];
         unpack8(kr[it], kf);
+        if (key == slot) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[j] = nk[j];
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t = fmaf(kf[j], q[j], t);
+        t = LPK == 16 ? row16_sum(t) : row8_sum(t);
+        const bool valid = key < ctx && key >= kstart;
+        sd[it] = valid ? t * a.scale : -INFINITY;
+        m = fmaxf(m, sd[it]);
+    }
+    float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
+        float vf[8];
         unpack8(vr[it], vf);
         if (key == slot) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { kf[j] = nk[j]; vf[j] = nv[j]; }
+            for (int j = 0; j < 8; ++j) vf[j] = nv[j];
         }
-        float sd = 0.f;
+        const float p = sd[it] == -INFINITY ? 0.f : __expf(sd[it] - m);
+        l += p;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sd = fmaf(kf[j], q[j], sd);
-#pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) sd += __shfl_xor(sd, o, 64);
-        sd = valid ? sd * a.scale : -INFINITY;
-        const float mn = fmaxf(m, sd);
-        if (mn > -INFINITY) {
-            const float alpha = __expf(m - mn);                 // m = -inf -> 0
-            const float p = valid ? __expf(sd - mn) : 0.f;
-            l = l * alpha + p;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = acc[j] * alpha + p * vf[j];
-            m = mn;
-        }
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
     }
-    // ---- merge the KPI key groups of the wave (lanes with equal dl), then the 4 waves through LDS
+    // ---- the NP (wave, key group) states meet in LDS; D threads merge them
+    {
+        float* dst = sm[wave * KPI + g];
 #pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) {
-        const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
-        const float mt = fmaxf(m, m2);
-        const float f1 = (m == -INFINITY) ? 0.f : __expf(m - mt);
-        const float f2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mt);
-        l = l * f1 + l2 * f2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * f1 + __shfl_xor(acc[j], o, 64) * f2;
-        m = mt;
-    }
-    if (g == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sm[wave][d0 + j] = acc[j];
-        if (dl == 0) { sm[wave][D] = m; sm[wave][D + 1] = l; }
+        for (int j = 0; j < 8; ++j) dst[d0 + j] = acc[j];
+        if (dl == 0) { dst[D] = m; dst[D + 1] = l; }
     }
     __syncthreads();
+    float num = 0.f, den = 0.f, mt = -INFINITY;
     if (tid < D) {
-        const float mt = fmaxf(fmaxf(sm[0][D], sm[1][D]), fmaxf(sm[2][D], sm[3][D]));
-        float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NP; ++w) mt = fmaxf(mt, sm[w][D]);
+#pragma unroll
+        for (int w = 0; w < NP; ++w) {
             const float f = (sm[w][D] == -INFINITY) ? 0.f : __expf(sm[w][D] - mt);
-            num += f * sm[w][tid];
-            den += f * sm[w][D + 1];
+            num = fmaf(f, sm[w][tid], num);
+            den = fmaf(f, sm[w][D + 1], den);
         }
+    }
+    // ---- publish the split's state; decode_fused_combine_kernel merges the live splits (a kernel boundary is the
+    // cheap cross-XCD hand-off here: an in-kernel last-arriver combine needs device-scope fences, i.e. L2 write-backs,
+    // and measured 3.4x slower per layer)
+    if (tid < D) {
+        float* wout = a.ws + (((size_t)b * a.H + h) * nsplit + split) * (D + 2);
         wout[tid] = num;
         if (tid == 0) { wout[D] = mt; wout[D + 1] = den; }
     }
 }
 
 template <int D>
-__global__ void decode_fused_combine_kernel(const float* ws, bf16_t* o, long o_sb, long o_sh, int H, int nsplit) {
+__global__ void decode_fused_combine_kernel(const float* ws, const int32_t* slot, bf16_t* o, long o_sb, long o_sh, int H,
+                                            int nsplit) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const int nlive = (slot[b] + DF_CHUNK) / DF_CHUNK;             // ceil((slot + 1) / DF_CHUNK): dead splits wrote nothing
     const float* w = ws + ((size_t)b * H + h) * nsplit * (D + 2);
     float m = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, w[s * (D + 2) + D]);
+    for (int s = 0; s < nlive; ++s) m = fmaxf(m, w[s * (D + 2) + D]);
     float num = 0.f, den = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
+#pragma unroll 4
+    for (int s = 0; s < nlive; ++s) {
         const float ms = w[s * (D + 2) + D];
         const float f = (ms == -INFINITY) ? 0.f : __expf(ms - m);
-        num += f * w[s * (D + 2) + d];
-        den += f * w[s * (D + 2) + D + 1];
+        num = fmaf(f, w[s * (D + 2) + d], num);
+        den = fmaf(f, w[s * (D + 2) + D + 1], den);
     }
     o[(size_t)b * o_sb + (size_t)h * o_sh + d] = f2bf(den > 0.f ? num / den : 0.f);
 }
@@ -532,10 +539,10 @@ int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s) {
     const int ns = (a.ctx_max + DF_CHUNK - 1) / DF_CHUNK;
     if (a.D == 128) {
         hipLaunchKernelGGL(decode_fused_kernel<128>, dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.o, a.o_sb, a.o_sh, a.H, ns);
+        hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else if (a.D == 64) {
         hipLaunchKernelGGL(decode_fused_kernel<64>, dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.o, a.o_sb, a.o_sh, a.H, ns);
+        hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else return -22;
     EMU_CHECK_LAUNCH();
     return 0;

@@ -44,15 +44,42 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the DPP path (one VALU op per step) instead of ds_bpermute round trips through the LDS
+// crossbar.  quad_perm xor-1 / xor-2, then row_half_mirror and row_mirror (each half / row is uniform by then), leave the
+// sum of every aligned 16-lane row in all of its lanes; the four rows are combined through v_readlane (uniform).
+// All 64 lanes must be active at the call.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_mov<0xB1>(v);                         // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                         // quad_perm [2,3,0,1]
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row8_sum(float v) { v = quad_sum(v); v += dpp_mov<0x141>(v); return v; }   // row_half_mirror
+__device__ __forceinline__ float row16_sum(float v) { v = row8_sum(v); v += dpp_mov<0x140>(v); return v; }  // row_mirror
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
     return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = quad_max(v);
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // block-wide sum for blocks of NW waves; scratch must hold NW floats; all threads get the result
