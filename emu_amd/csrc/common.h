@@ -96,6 +96,12 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return t;
 }
 
+// acc + w.lo * x.lo + w.hi * x.hi over packed bf16 pairs (v_dot2c_f32_bf16, fp32 accumulate)
+__device__ __forceinline__ float bf16_dot2(unsigned int w, unsigned int x, float acc) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 

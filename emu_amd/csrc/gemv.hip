@@ -97,32 +97,39 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
 
+    // The inner product runs on v_dot2c_f32_bf16: weights are consumed as they arrive (no unpack) against the activation
+    // vector re-packed to bf16 pairs once per 16-byte column group -- exact, because the reference rounds the normalised
+    // activations to bf16 anyway.  4 VALU ops per 8 weights instead of 16 (unpack + fma).
     auto consume = [&](int vi, const u32x4 (&wv)[R], const u32x4* xpre) {
         float g[8];
         if constexpr (NORM) unpack8(ld16(a.norm_w + vi * 8), g);
-        float xf[MB][8];
+        u32x4 xp[MB];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m < a.M) {
-                if (xpre) unpack8(*xpre, xf[m]);
-                else unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), xf[m]);
+                xp[m] = xpre ? *xpre : ld16(a.x + (size_t)m * a.ldx + vi * 8);
                 if constexpr (NORM) {
+                    float xf[8];
+                    unpack8(xp[m], xf);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xf[m][j] = bfround(g[j] * bfround(xf[m][j] * rinv[m]));
+                    for (int j = 0; j < 8; ++j) xf[j] = g[j] * bfround(xf[j] * rinv[m]);
+                    xp[m] = pack8(xf);                               // the pack is the reference's second rounding
                 }
             } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xf[m][j] = 0.f;
+                xp[m] = u32x4{0u, 0u, 0u, 0u};
             }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float wf[8];
-            unpack8(wv[r], wf);
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
+            for (int m = 0; m < MB; ++m) {
+                float t = acc[r][m];
+                t = bf16_dot2(wv[r].x, xp[m].x, t);
+                t = bf16_dot2(wv[r].y, xp[m].y, t);
+                t = bf16_dot2(wv[r].z, xp[m].z, t);
+                t = bf16_dot2(wv[r].w, xp[m].w, t);
+                acc[r][m] = t;
+            }
         }
     };
 
@@ -249,28 +256,36 @@ __global__ __launch_bounds__(256) void gemv_rt_kernel(const GemvArgs a) {
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         float xf[8];
-        unpack8(xv[it], xf);
+        u32x4 xp = xv[it];                                           // bf16 pairs for the dot2 path
+        if constexpr (NORM || FP8) unpack8(xv[it], xf);
         if constexpr (NORM) {
             float g[8];
             unpack8(gv[it], g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xf[j] = bfround(g[j] * bfround(xf[j] * rinv));
+            for (int j = 0; j < 8; ++j) xf[j] = g[j] * bfround(xf[j] * rinv);
+            xp = pack8(xf);                                          // the reference's second rounding
+            if constexpr (FP8) unpack8(xp, xf);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float wf[8];
             if constexpr (FP8) {
+                f32x2_t a2 = {0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wv[it][r][q], false);
                     const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(wv[it][r][q], true);
-                    wf[4 * q] = lo[0]; wf[4 * q + 1] = lo[1]; wf[4 * q + 2] = hi[0]; wf[4 * q + 3] = hi[1];
+                    a2 = __builtin_elementwise_fma(lo, f32x2_t{xf[4 * q], xf[4 * q + 1]}, a2);       // v_pk_fma_f32
+                    a2 = __builtin_elementwise_fma(hi, f32x2_t{xf[4 * q + 2], xf[4 * q + 3]}, a2);
                 }
+                acc[r] += a2[0] + a2[1];
             } else {
-                unpack8(wv[it][r], wf);
+                float t = acc[r];
+                t = bf16_dot2(wv[it][r].x, xp.x, t);
+                t = bf16_dot2(wv[it][r].y, xp.y, t);
+                t = bf16_dot2(wv[it][r].z, xp.z, t);
+                t = bf16_dot2(wv[it][r].w, xp.w, t);
+                acc[r] = t;
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r] = fmaf(wf[j], xf[j], acc[r]);
         }
     }
 
@@ -353,6 +368,7 @@ int try_launch_rt(const GemvArgs& a, hipStream_t s) {
     }
     if (kit <= 4) {
         if (f8) return mode == 4 ? launch_rt<4, 4, true>(a, s) : launch_rt<8, 4, true>(a, s);
+        if (mode == 8) return launch_rt<8, 4, false>(a, s);
         return mode == 2 ? launch_rt<2, 4, false>(a, s) : launch_rt<4, 4, false>(a, s);
     }
     if (kit <= 9) {
@@ -541,17 +557,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float wf[16];
+            f32x2_t wf[8];                                            // v_cvt_pk_f32_fp8 pairs feed v_pk_fma_f32
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], false);
-                const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], true);
-                wf[4 * q] = lo[0]; wf[4 * q + 1] = lo[1]; wf[4 * q + 2] = hi[0]; wf[4 * q + 3] = hi[1];
+                wf[2 * q] = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], false);
+                wf[2 * q + 1] = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], true);
             }
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m) {
+                f32x2_t a2 = {0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
+                for (int j = 0; j < 8; ++j)
+                    a2 = __builtin_elementwise_fma(wf[j], f32x2_t{xf[m][2 * j], xf[m][2 * j + 1]}, a2);
+                acc[r][m] += a2[0] + a2[1];
+            }
         }
     }
 #pragma unroll
@@ -665,18 +684,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float wf[8];
-            const unsigned int wq[2] = {wv[r][0], wv[r][1]};
+            f32x2_t wf[4];                                            // v_cvt_pk_f32_fp8 pairs feed v_pk_fma_f32
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wq[q], false);
-                const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(wq[q], true);
-                wf[4 * q] = lo[0]; wf[4 * q + 1] = lo[1]; wf[4 * q + 2] = hi[0]; wf[4 * q + 3] = hi[1];
+                wf[2 * q] = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], false);
+                wf[2 * q + 1] = __builtin_amdgcn_cvt_pk_f32_fp8(wv[r][q], true);
             }
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m) {
+                f32x2_t a2 = {0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[r][m] = fmaf(wf[j], xf[m][j], acc[r][m]);
+                for (int j = 0; j < 4; ++j)
+                    a2 = __builtin_elementwise_fma(wf[j], f32x2_t{xf[m][2 * j], xf[m][2 * j + 1]}, a2);
+                acc[r][m] += a2[0] + a2[1];
+            }
         }
     }
 #pragma unroll
