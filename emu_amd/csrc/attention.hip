@@ -417,14 +417,15 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     // the rotation start while the K/V rows are still in flight), then this wave's 32 keys (LPK lanes cover one row)
     const u32x4 cv = ld16(a.cos + (size_t)pos * D + dc), sv = ld16(a.sin + (size_t)pos * D + dc);
     const u32x4 q1v = ld16(qh + d0), q2v = ld16(qh + dp), k1v = ld16(kh + d0), k2v = ld16(kh + dp), nvv = ld16(vh + d0);
+    // (unconditional, index clamped into the cache: a predicated load becomes a branch whose merge copy makes the
+    // compiler drain vmcnt after the first pair; masked keys are zeroed by select below, never multiplied)
     u32x4 kr[ITER], vr[ITER];
-    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
-        const bool ld = key < ctx && key >= kstart && key != slot;
-        kr[it] = ld ? ld16(kc + (size_t)key * D + d0) : z;
-        vr[it] = ld ? ld16(vc + (size_t)key * D + d0) : z;
+        const int kc_i = key < a.S_max ? key : a.S_max - 1;
+        kr[it] = ld16(kc + (size_t)kc_i * D + d0);
+        vr[it] = ld16(vc + (size_t)kc_i * D + d0);
     }
     // ---- RoPE of q and of the new key (this lane's 8-wide slice), transformers' rounding points
     float c[8], sn[8], q[8], nk[8], nv[8];
@@ -451,17 +452,15 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
+        const bool valid = key < ctx && key >= kstart;
         float kf[8];
         unpack8(kr[it], kf);
-        if (key == slot) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kf[j] = nk[j];
-        }
+        for (int j = 0; j < 8; ++j) kf[j] = key == slot ? nk[j] : (valid ? kf[j] : 0.f);
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) t = fmaf(kf[j], q[j], t);
         t = LPK == 16 ? row16_sum(t) : row8_sum(t);
-        const bool valid = key < ctx && key >= kstart;
         sd[it] = valid ? t * a.scale : -INFINITY;
         m = fmaxf(m, sd[it]);
     }
@@ -471,10 +470,8 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
         const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
         float vf[8];
         unpack8(vr[it], vf);
-        if (key == slot) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vf[j] = nv[j];
-        }
+        for (int j = 0; j < 8; ++j) vf[j] = key == slot ? nv[j] : (sd[it] == -INFINITY ? 0.f : vf[j]);
         const float p = sd[it] == -INFINITY ? 0.f : __expf(sd[it] - m);
         l += p;
 #pragma unroll
