@@ -92,27 +92,40 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restr
 
 // greedy selection: first index of the maximum of float(bf16 logits); optional suppressed id (EOS while
 // fewer than min_length tokens exist, Emu2/emu/emu.py:220 -> MinLengthLogitsProcessor)
-__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t* __restrict__ logits, int ld, int vocab, int suppress,
-                                                     int32_t* __restrict__ out) {
-    __shared__ float sv[256];
-    __shared__ int si[256];
+__global__ __launch_bounds__(1024) void argmax_kernel(const bf16_t* __restrict__ logits, int ld, int vocab, int suppress,
+                                                      int32_t* __restrict__ out) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
     const bf16_t* row = logits + (size_t)blockIdx.x * ld;
+    const int tid = threadIdx.x;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < vocab; i += 256) {
-        const float v = (i == suppress) ? -INFINITY : bf2f(row[i]);
+    auto take = [&](float v, int i) {
+        if (i == suppress) v = -INFINITY;
         if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    };
+    // 16-byte loads over the aligned body (the row start is 16-byte aligned when ld % 8 == 0), scalar head / tail
+    const int head = (int)((16 - (reinterpret_cast<size_t>(row) & 15)) & 15) >> 1;
+    const int h = head < vocab ? head : vocab;
+    const int nv = (vocab - h) >> 3;
+    if (tid < h) take(bf2f(row[tid]), tid);
+    for (int vi = tid; vi < nv; vi += 1024) {
+        float f[8];
+        unpack8(ld16(row + h + vi * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) take(f[j], h + vi * 8 + j);
     }
-    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    for (int i = h + nv * 8 + tid; i < vocab; i += 1024) take(bf2f(row[i]), i);
+    sv[tid] = best; si[tid] = bi;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            const float v = sv[threadIdx.x + o]; const int i = si[threadIdx.x + o];
-            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v = sv[tid + o]; const int i = si[tid + o];
+            if (v > sv[tid] || (v == sv[tid] && i < si[tid])) { sv[tid] = v; si[tid] = i; }
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+    if (tid == 0) out[blockIdx.x] = si[0];
 }
 
 // PatchEmbed conv (stride = kernel = p) as im2col: out[(b, py, px), k = c*p*p + i*p + j], zero-padded to Kpad.
@@ -295,7 +308,7 @@ int launch_scatter_rows(const bf16_t* src, const int32_t* dst_rows, bf16_t* out,
 }
 int launch_argmax(const bf16_t* logits, int ld, int rows, int vocab, int suppress_id, int32_t* out, hipStream_t s) {
     if (rows < 1 || vocab < 1) return -22;
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, s, logits, ld, vocab, suppress_id, out);
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, s, logits, ld, vocab, suppress_id, out);
     EMU_CHECK_LAUNCH();
     return 0;
 }

@@ -824,9 +824,11 @@ int emu_gemv_rows_per_block(int N, int K, bool norm) {
     // measured (tools/kbench.py, profiles/): kernels with the fused RMSNorm prologue want 8 rows per workgroup so the
     // prologue is amortised; plain streams are fastest with 2 rows per workgroup (more, smaller workgroups balance the
     // 256 CUs better).
+    // With the inner product on v_dot2c the per-column activation prep (normalise + re-pack) is the largest VALU
+    // item of a fused-norm block, so big matrices take 16 rows per workgroup (qkv / gate-up / lm_head: +1..2 %).
     (void)K;
-    int R = norm ? 8 : 2;
-    while (R > 2 && (N + R - 1) / R < 512) R >>= 1;
+    int R = norm ? 16 : 2;
+    while (R > 2 && (N + R - 1) / R < (R == 16 ? 1024 : 512)) R >>= 1;
     return R;
 }
 
@@ -1191,6 +1193,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
         case 2: return launch_mb<2>(a, s);
         case 4: return launch_mb<4>(a, s);
         case 8: return launch_mb<8>(a, s);
+        case 16: return a.M <= 1 ? launch_norm<16, 1>(a, s) : launch_mb<8>(a, s);
         default: return -22;
     }
 }

@@ -232,6 +232,25 @@ def test_embed_scatter_argmax_avgpool():
         close(ops.avgpool_tokens(x.cuda(), 4, s), bfr(ref), what=f"avgpool s{s}")
 
 
+@pytest.mark.parametrize("vocab", [7, 64, 1000, 32274])
+def test_argmax_alignment_and_ties(vocab):
+    """Rows that start at every 2-byte phase of a 16-byte line (ld = vocab, odd sizes), first-index tie-break, suppressed
+    id; compared with torch.argmax on the same bf16 values (torch also returns the first maximum on CPU)."""
+    ops = _ops()
+    rows = 9
+    g = torch.Generator().manual_seed(vocab)
+    x = torch.randn(rows, vocab, generator=g).to(BF16)
+    x[1, vocab // 2] = 50.0; x[1, vocab - 1] = 50.0            # tie: the first index wins
+    x[2, 0] = 60.0
+    x[3, vocab - 1] = 60.0
+    want = [int(torch.argmax(x[r].float())) for r in range(rows)]
+    got = ops.argmax(x.cuda()).cpu().tolist()
+    assert got == want
+    sup = want[4]
+    y = x[4:5].float().clone(); y[0, sup] = -float("inf")
+    assert ops.argmax(x[4:5].cuda().contiguous(), suppress_id=sup).cpu().tolist() == [int(torch.argmax(y[0]))]
+
+
 @pytest.mark.parametrize("D", [64, 128])
 def test_rope_kv_append(D):
     from oracle import emu2_ref as R
