@@ -351,6 +351,18 @@ def main():
     if not a.no_denoise:
         denoise = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None)
 
+    # HBM traffic of the GEMV launches comes from PMC counters (FETCH_SIZE), which a timing run cannot collect itself:
+    # the committed pass over THIS command (profiles/r01_gemv_pmc_traffic.json, gfx950-corrected) gives traffic /
+    # algorithmic bytes for the same kernels; traffic = that ratio x this run's algorithmic bytes per launch
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_pmc_traffic.json")))
+        ratio = float(pmc["all_gemv_launches"]["traffic_over_algorithmic"])
+        traffic = ratio * bytes_per_launch
+        traffic_src = f"profiles/r01_gemv_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE pass over bench.py, traffic/algorithmic = {ratio:.4f}"
+    except Exception:
+        pass
+
     if rank == 0:
         prefill_flops = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
                                                    + 2 * S * S * lcfg.hidden_size)
@@ -366,7 +378,7 @@ def main():
                        "valid": bool(a.layers == 60 and a.vit_layers == 64)},
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel (weight-streaming GEMV, all epilogues)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_launch_s * 1e6,
                          "launches_per_token": nl.value / n_prof, "gemv_ms_per_token": gemv_ms_per_tok,
                          "measured": f"HIP events on the launch stream around each GEMV, eager replay of {n_prof} decode steps",
