@@ -188,45 +188,61 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
                 s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[blk], 0, 0, 0);
             }
         }
-        // lane (query qi) holds keys kt0 + 32*blk + 16*(r>>3) + 8*hi + (r&7)
+        // lane (query qi) holds keys kt0 + 32*blk + 16*(r>>3) + 8*hi + (r&7).  The softmax is the VALU-heavy part of a
+        // tile (it outweighs the 16 MFMAs at D = 64), so: interior tiles skip the mask arithmetic (wave-uniform test),
+        // the scale rides in the exponent's fma, exp2 is the bare v_exp_f32, and O is rescaled only when some row's
+        // maximum moved.
+        const bool interior = kt0 + 63 < a.Sk && kt0 >= kstart && (!a.causal || kt0 + 63 <= q0 + off);
         float mloc = -INFINITY;
+        if (interior) {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt0 + 32 * blk + 16 * (r >> 3) + 8 * hi + (r & 7);
-                const bool ok = key < a.Sk && key >= kstart && (!a.causal || key <= qi + off);
-                const float v = ok ? s[blk][r] * sc : -INFINITY;
-                s[blk][r] = v;
-                mloc = fmaxf(mloc, v);
-            }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[blk][r]);
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt0 + 32 * blk + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    const bool ok = key < a.Sk && key >= kstart && (!a.causal || key <= qi + off);
+                    const float v = ok ? s[blk][r] : -INFINITY;
+                    s[blk][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc;          // sc > 0: the maximum commutes with the scale
         const float mnew = fmaxf(m_run, mloc);
         float alpha = 1.f;
         const bool dead = (mnew == -INFINITY);         // every key so far masked for this query
-        if (!dead) alpha = exp2f(m_run - mnew);        // m_run = -inf -> 0
+        if (!dead) alpha = __builtin_amdgcn_exp2f(m_run - mnew);    // m_run = -inf -> 0
+        const float nm = dead ? 0.f : -mnew;
         float psum = 0.f;
-        bf16x8_t pf[4];
+        u32x4 pfw[4];                                  // P as packed bf16 pairs = the B fragments of the PV MFMAs
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = dead ? 0.f : exp2f(s[blk][r] - mnew);
-                psum += p;
-                pf[blk * 2 + (r >> 3)][r & 7] = (__bf16)p;
+            for (int r = 0; r < 16; r += 2) {
+                // masked scores are -inf: fma(-inf, sc, nm) = -inf -> exp2 = 0 (dead rows: nm = 0, still 0)
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[blk][r], sc, nm));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[blk][r + 1], sc, nm));
+                psum += p0 + p1;
+                pfw[blk * 2 + (r >> 3)][(r & 7) >> 1] = packbf(p0, p1);
             }
         l_run = l_run * alpha + psum;
         m_run = mnew;
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
                 const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + sw_off<128>(db * 32 + l31, ks * 2 + hi));
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pfw[ks]), o[db], 0, 0, 0);
             }
     }
 
