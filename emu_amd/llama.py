@@ -187,6 +187,20 @@ class LlamaEngine:
         return q.view(torch.float8_e4m3fn).to(torch.float32) * sc[:, None]
 
     # ------------------------------------------------------------------ KV cache / workspace
+    KV_BUCKETS = (256, 512, 1024)
+
+    def kv_capacity(self, need: int) -> int:
+        """KV slots to allocate for a request that will touch ``need`` positions: the smallest bucket that holds it
+        (requests up to 1024 positions run the one-launch decode attention and a smaller cache), else the model
+        maximum.  Buckets keep the allocation -- and any captured decode graph's launch geometry -- reusable."""
+        cap = self.cfg.max_position_embeddings
+        if need > cap:
+            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        for b in self.KV_BUCKETS:
+            if need <= b <= cap:
+                return b
+        return cap
+
     def alloc_kv(self, batch: int, s_max: int) -> None:
         if batch == self.kv_batch and s_max == self.s_max and self.kcache is not None:
             return
@@ -283,9 +297,7 @@ class LlamaEngine:
         state advance per step, optionally replayed from one hipGraph); EOS/PAD bookkeeping of finished rows is
         applied afterwards on the host, which is equivalent because rows never interact."""
         B, S, H = embeds.shape
-        s_max = self.cfg.max_position_embeddings
-        if S + max_new_tokens > s_max:
-            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        s_max = self.kv_capacity(S + max_new_tokens)
         hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
         last = hidden[:, -1, :]
         logits = torch.empty(B, self.vocab, device=self.device, dtype=BF16)
@@ -323,9 +335,7 @@ class LlamaEngine:
         host-driven, so this path is not graph-replayed."""
         B, S, H = embeds.shape
         dev = self.device
-        s_max = self.cfg.max_position_embeddings
-        if S + max_new_tokens > s_max:
-            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        s_max = self.kv_capacity(S + max_new_tokens)
         hidden, kstart, pos = self.prefill(embeds, attention_mask, s_max)
         row = hidden[:, -1, :]
         out = torch.full((B, max_new_tokens), pad_id, dtype=torch.int64, device=dev)
@@ -383,9 +393,7 @@ class LlamaEngine:
         step (rows are gathered on the device).  Returns the best sequence per prompt [B, <= max_new_tokens]."""
         B, S, H = embeds.shape
         nb, V, dev = num_beams, self.vocab, self.device
-        s_max = self.cfg.max_position_embeddings
-        if S + max_new_tokens > s_max:
-            raise ValueError("prompt + max_new_tokens exceeds max_position_embeddings")
+        s_max = self.kv_capacity(S + max_new_tokens)
         hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
         logits = self.logits(hidden[:, -1, :]).float()                                  # [B, V]
         # replicate the prompt's KV rows for every beam: row b*nb + j <- row b

@@ -4,6 +4,7 @@ host logic calls are provided; kcache/vcache are plain tensors laid out like the
 import torch
 
 from emu_amd.conf.emu_conf import LlamaCfg
+from emu_amd.llama import LlamaEngine
 from oracle import emu2_ref as R
 
 
@@ -14,6 +15,9 @@ class FakeEngine:
         self.embed = W["decoder.lm.model.embed_tokens.weight"]
         self.kcache = self.vcache = None
         self.kv_batch = self.s_max = 0
+
+    KV_BUCKETS = LlamaEngine.KV_BUCKETS
+    kv_capacity = LlamaEngine.kv_capacity            # the product's own bucket logic
 
     def alloc_kv(self, batch, s_max):
         L, H, D = self.rcfg.layers, self.rcfg.heads, self.rcfg.head_dim

@@ -173,6 +173,41 @@ def test_true_width_single_layer_decode_and_prefill():
     assert rel_err(step, want1[:, 0]) < 2e-2, rel_err(step, want1[:, 0])
 
 
+@pytest.mark.parametrize("heads,D", [(4, 64), (3, 128)])
+@pytest.mark.parametrize("s_max", [256, 1024, 2048])
+@pytest.mark.parametrize("S,pad", [(1, 0), (37, 0), (200, 13), (255, 0)])
+def test_decode_attention_paths(heads, D, s_max, S, pad):
+    """A cached decode step against the CPU oracle: both head dims, KV capacities with and without dead splits, left
+    padding, contexts that end inside / at the edge of a 128-key split, batch 2."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import LlamaCfg
+    from emu_amd.llama import EmuHipContext, LlamaEngine
+    from oracle import emu2_ref as R
+    if S + 1 > s_max:
+        pytest.skip("context does not fit")
+    l = LlamaCfg(hidden_size=heads * D, intermediate_size=256, num_attention_heads=heads, num_hidden_layers=2)
+    vocab = 64
+    W = synth.synth_state_dict(synth.llama_param_shapes(l, vocab), seed=heads + D)
+    eng = LlamaEngine(l, vocab, EmuHipContext(torch.device("cuda", 0)))
+    eng.load_weights(W.items())
+    Wr = R.bf16_round(W)
+    cfg = R.LlamaCfg(hidden=heads * D, heads=heads, layers=2, ffn=256, vocab=vocab)
+    g = torch.Generator().manual_seed(S * 7 + pad)
+    x = torch.randn(2, S + 1, l.hidden_size, generator=g).to(BF16)
+    mask = torch.ones(2, S, dtype=torch.long)
+    if pad:
+        mask[1, :pad] = 0                                                # left padding on row 1
+    _, kstart, pos = eng.prefill(x[:, :S].contiguous().cuda(), mask, s_max=s_max)
+    cache = R.KVCache(2)
+    pos_ref = (mask.cumsum(-1) - 1).masked_fill(mask == 0, 1)
+    R.llama_model(x[:, :S].float(), mask, Wr, cfg, position_ids=pos_ref, cache=cache, final_norm=False)
+    step = eng.decode_embeds(x[:, S].contiguous().cuda(), pos, S, kstart)
+    mask1 = torch.cat([mask, torch.ones(2, 1, dtype=torch.long)], dim=1)
+    want = R.llama_model(x[:, S:].float(), mask1, Wr, cfg, position_ids=pos_ref[:, -1:] + 1, cache=cache,
+                         final_norm=False)[:, 0]
+    assert rel_err(step, want) < 2e-2, rel_err(step, want)
+
+
 def test_rccl_single_rank_path_eager_and_graph(golden_dir):
     """The tensor-parallel code path (ncclAllReduce on the launch stream after o_proj / down_proj, also inside hipGraph
     capture) with a 1-rank RCCL communicator: must reproduce the reference's greedy ids exactly."""
