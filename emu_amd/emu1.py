@@ -172,6 +172,38 @@ class CausalFormer:
         return out.view(B, n, self.out_dim)
 
 
+def merge_lora_state_dict(sd, r: int = 16, alpha: float = 16.0):
+    """Fold peft LoRA adapters into their base weights: W' = W + (alpha / r) * B @ A (fp32 math, caller rounds).
+
+    Handles both peft layouts: base weight under ``<mod>.weight`` or ``<mod>.base_layer.weight``; adapters under
+    ``<mod>.lora_A[.default].weight`` / ``<mod>.lora_B[.default].weight``; the ``base_model.model.`` infix that
+    ``get_peft_model`` inserts after ``decoder.lm.`` is dropped.  Dicts without adapters pass through unchanged."""
+    import re
+    scale = float(alpha) / float(r)
+    out, lora = {}, {}
+    for name, t in sd.items():
+        name = name.replace("decoder.lm.base_model.model.", "decoder.lm.")
+        m = re.match(r"^(.*)\.lora_([AB])(?:\.[A-Za-z0-9_]+)?\.weight$", name)
+        if m:
+            lora.setdefault(m.group(1), {})[m.group(2)] = t
+            continue
+        if ".lora_dropout" in name or name.endswith(".lora_embedding_A") or name.endswith(".lora_embedding_B"):
+            continue
+        out[name.replace(".base_layer.weight", ".weight").replace(".base_layer.bias", ".bias")] = t
+    for mod, ab in lora.items():
+        if "A" not in ab or "B" not in ab:
+            raise RuntimeError(f"LoRA adapter of {mod} is incomplete")
+        key = mod + ".weight"
+        if key not in out:
+            raise RuntimeError(f"LoRA adapter for {mod} has no base weight")
+        if ab["A"].shape[0] != ab["B"].shape[1]:
+            raise RuntimeError(f"LoRA rank mismatch at {mod}: A {tuple(ab['A'].shape)}, B {tuple(ab['B'].shape)}")
+        base = out[key]
+        merged = base.float() + scale * (ab["B"].float() @ ab["A"].float())
+        out[key] = merged.to(base.dtype)
+    return out
+
+
 class Emu:
     """Drop-in for the reference's first-generation ``Emu`` model (inference: ``generate``)."""
 
@@ -194,9 +226,13 @@ class Emu:
         self.image_placeholder = "[IMG]" + "<image>" * self.n_causal + "[/IMG]"
         self.tokenizer = None
 
-    def load_state_dict(self, sd, strict: bool = True):
+    def load_state_dict(self, sd, strict: bool = True, lora_r: int = 16, lora_alpha: float = 16.0):
+        """Reference key names (Emu1/models/modeling_emu.py).  The instruct checkpoint is saved with peft LoRA adapters
+        on the attention projections (Emu1/inference.py:40-51: r = 16, alpha = 16 on q/k/v/o_proj); they are merged
+        into the base matrices here, so the engines only ever see plain LLaMA weights."""
+        sd = merge_lora_state_dict(dict(sd.items() if hasattr(sd, "items") else sd), lora_r, lora_alpha)
         unexpected = []
-        for name, t in (sd.items() if hasattr(sd, "items") else sd):
+        for name, t in sd.items():
             if name.startswith("visual."):
                 used = self.visual.load_tensor(name[len("visual."):], t)
             elif name.startswith("decoder.lm."):

@@ -114,3 +114,31 @@ def test_product_beam_search_host_logic_matches_reference(golden_dir, monkeypatc
     x = R.embed_tokens(ids, W)
     out = L.LlamaEngine.beam_search_generate(eng, x, mask, 5, 10)
     assert out.tolist() == z["beam2"].tolist()
+
+
+def test_emu1_lora_merge_both_peft_layouts():
+    """Emu1 instruct checkpoints carry peft LoRA adapters (Emu1/inference.py:40-51); the loader folds them into the base
+    matrices: W' = W + (alpha / r) * B @ A, for both peft key layouts, and leaves adapter-free dicts untouched."""
+    import pytest
+    from emu_amd.emu1 import merge_lora_state_dict
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(32, 24, generator=g)
+    A = torch.randn(4, 24, generator=g)
+    B = torch.randn(32, 4, generator=g)
+    other = torch.randn(5, generator=g)
+    want = W + (8.0 / 4) * (B @ A)
+    pre = "decoder.lm.base_model.model.model.layers.0.self_attn.q_proj."
+    old = {pre + "weight": W, pre + "lora_A.weight": A, pre + "lora_B.weight": B, "ln_visual.weight": other}
+    new = {pre + "base_layer.weight": W, pre + "lora_A.default.weight": A, pre + "lora_B.default.weight": B,
+           "ln_visual.weight": other}
+    for sd in (old, new):
+        out = merge_lora_state_dict(sd, r=4, alpha=8.0)
+        assert set(out) == {"decoder.lm.model.layers.0.self_attn.q_proj.weight", "ln_visual.weight"}
+        assert torch.allclose(out["decoder.lm.model.layers.0.self_attn.q_proj.weight"], want, atol=1e-5)
+        assert out["ln_visual.weight"] is other
+    plain = {"decoder.lm.model.norm.weight": other}
+    assert merge_lora_state_dict(plain) == plain
+    with pytest.raises(RuntimeError):
+        merge_lora_state_dict({pre + "weight": W, pre + "lora_A.weight": A}, r=4, alpha=8.0)
+    with pytest.raises(RuntimeError):
+        merge_lora_state_dict({pre + "lora_A.weight": A, pre + "lora_B.weight": B}, r=4, alpha=8.0)
