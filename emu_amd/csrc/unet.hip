@@ -7,34 +7,72 @@
 
 namespace {
 
-constexpr int GN_ROWS = 64;          // pixels per partial-sum workgroup
+constexpr int GN_DEPTH = 16;         // pixel rows each thread walks serially in the partial-sum pass
 
-// partial sums per (b, chunk, channel): ws[((b*nchunk + chunk)*2 + {0,1})*C + c]
+// How the 256 threads of a partial-sum workgroup are laid out for C channels: nv 16-byte channel vectors per pixel row,
+// RG row groups side by side (all 256 threads busy for C = 320 as well as 1280), GN_DEPTH rows per thread.
+__host__ __device__ inline int gn_row_groups(int C) { const int nv = C >> 3; return nv >= 256 ? 1 : 256 / nv; }
+__host__ __device__ inline int gn_rows_per_block(int C) { return GN_DEPTH * gn_row_groups(C); }
+
+// partial sums per (b, chunk, channel): ws[((b*nchunk + chunk)*2 + {0,1})*C + c]; row groups meet in LDS in a fixed
+// order (deterministic sums)
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C) {
+    __shared__ float sm[256 * 16];
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int nv = C >> 3;
-    const int r0 = chunk * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
+    const int RG = gn_row_groups(C), rows = GN_DEPTH * RG;
+    const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
     float* out = ws + ((size_t)(b * nchunk + chunk) * 2) * C;
-    for (int vi = threadIdx.x; vi < nv; vi += 256) {
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = r0; r < r1; ++r) {
+    const int tid = threadIdx.x;
+    if (RG == 1) {                                   // wide rows: one thread per channel vector (loop when nv > 256)
+        for (int vi = tid; vi < nv; vi += 256) {
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+            for (int r = r0; r < r1; ++r) {
+                float f[8];
+                unpack8(ld16(x + ((size_t)b * HW + r) * C + vi * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { out[vi * 8 + e] = s[e]; out[C + vi * 8 + e] = q[e]; }
+        }
+        return;
+    }
+    const int tr = tid / nv, vi = tid - tr * nv;
+    const bool on = tr < RG;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (on) {
+#pragma unroll 4
+        for (int r = r0 + tr; r < r1; r += RG) {
             float f[8];
             unpack8(ld16(x + ((size_t)b * HW + r) * C + vi * 8), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { out[vi * 8 + e] = s[e]; out[C + vi * 8 + e] = q[e]; }
+        for (int e = 0; e < 8; ++e) { sm[tid * 16 + e] = s[e]; sm[tid * 16 + 8 + e] = q[e]; }
+    }
+    __syncthreads();
+    if (tid < nv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float ts = 0.f, tq = 0.f;
+            for (int g = 0; g < RG; ++g) { ts += sm[(g * nv + tid) * 16 + e]; tq += sm[(g * nv + tid) * 16 + 8 + e]; }
+            out[tid * 8 + e] = ts;
+            out[C + tid * 8 + e] = tq;
+        }
     }
 }
 
 // one workgroup per (b, group): reduce chunks and channels in double, emit scale/shift per channel
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ gamma,
-                                                        const bf16_t* __restrict__ beta, float* __restrict__ ab, int nchunk, int HW,
-                                                        int C, int groups, float eps) {
-    const int b = blockIdx.y, g = blockIdx.x, cg = C / groups, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ gamma,
+                                                         const bf16_t* __restrict__ beta, float* __restrict__ ab, int nchunk, int HW,
+                                                         int C, int groups, float eps) {
+    __shared__ double red[2][4];
+    const int b = blockIdx.y, g = blockIdx.x, cg = C / groups, tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int i = lane; i < nchunk * cg; i += 64) {
+    for (int i = tid; i < nchunk * cg; i += 256) {
         const int chunk = i / cg, c = g * cg + i % cg;
         const float* p = ws + ((size_t)(b * nchunk + chunk) * 2) * C;
         s += (double)p[c];
@@ -42,13 +80,17 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double n = (double)HW * cg;
     const double mean = s / n;
     double var = q / n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     float* A = ab + (size_t)b * 2 * C;
-    for (int i = lane; i < cg; i += 64) {
+    for (int i = tid; i < cg; i += 256) {
         const int c = g * cg + i;
         const float ga = bf2f(gamma[c]) * rstd;
         A[c] = ga;
@@ -147,17 +189,19 @@ __global__ __launch_bounds__(256) void gather_step_row_kernel(const bf16_t* __re
 }  // namespace
 
 size_t gn_ws_floats(int B, int C, int HW) {
-    const int nchunk = (HW + GN_ROWS - 1) / GN_ROWS;
+    const int rows = gn_rows_per_block(C);
+    const int nchunk = (HW + rows - 1) / rows;         // monotone in C and HW: sizing for (max C, max HW) covers every use
     return (size_t)B * nchunk * 2 * C + (size_t)B * 2 * C;
 }
 
 int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, float* ws, int B, int HW, int C,
                      int groups, float eps, int do_silu, hipStream_t s) {
     if (B < 1 || HW < 1 || (C & 7) || C % groups) return -22;
-    const int nchunk = (HW + GN_ROWS - 1) / GN_ROWS;
+    const int rows = gn_rows_per_block(C);
+    const int nchunk = (HW + rows - 1) / rows;
     float* ab = ws + (size_t)B * nchunk * 2 * C;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, s, ws, gamma, beta, ab, nchunk, HW, C, groups, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, ws, gamma, beta, ab, nchunk, HW, C, groups, eps);
     const size_t total = (size_t)B * HW * (C >> 3);
     const int grid = (int)min((size_t)8192, (total + 255) / 256);
     if (do_silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, s, x, ab, y, HW, C, total);
