@@ -457,6 +457,8 @@ using CfgI = TileCfg<2, 2, 2, 1, 6>;     // 128(n) x 64(m), 4 waves, 6 stages (1
 using CfgJ = TileCfg<2, 2, 2, 2, 4>;     // 128 x 128, 4 waves, 4 stages (128 KiB): 3 tiles (96 KiB) in flight per CU
 using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves, 3 stages (72 KiB, 2 workgroups per CU)
 using CfgL = TileCfg<2, 2, 2, 2, 2, 2>;  // 128 x 128, 2 k-groups x 4 waves, 2 stages (64 KiB, 2 workgroups per CU)
+// measured and dropped (profiles/r01_gemm_tilecfg_sweep_MN.log): 4 waves of 128(n) x 64(m) on a 256 x 128 tile
+// (0.75 KB of LDS reads per MFMA instead of 1 KB): -5 % vs C; 4 waves of 128 x 128 on 256 x 256 (AGPR accumulators): -40 %
 
 template <int EPI, bool CONV, class T>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
