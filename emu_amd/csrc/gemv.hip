@@ -384,93 +384,110 @@ int try_launch_rt(const GemvArgs& a, hipStream_t s) {
 // at 8 * (l >> 4)) against the activations as the B operand (col = activation row, same k), so the VALU does nothing in
 // the loop.  A block owns 16 weight rows; its 4 waves interleave over 32-k blocks (together 256 contiguous bytes per
 // row per step) and reduce through LDS.  Activations are re-read from L2 per fragment (no LDS staging, any K % 32 == 0).
-template <int EPI>
+template <int EPI, int RG>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const GemvArgs a) {
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-    __shared__ f32x4_t part[4][64];
+    __shared__ f32x4_t part[4][RG][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int nrow = n0 + i < a.N ? n0 + i : a.N - 1;
+    const int n0 = blockIdx.x * (16 * RG);
     const int mrow = i < a.M ? i : a.M - 1;                            // columns >= M duplicate the last row (discarded)
-    const bf16_t* wp = a.W + (size_t)nrow * a.ldw + g * 8;
+    const bf16_t* wp[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+        const int n = n0 + 16 * rg + i;
+        wp[rg] = a.W + (size_t)(n < a.N ? n : a.N - 1) * a.ldw + g * 8;
+    }
     const bf16_t* xp = a.x + (size_t)mrow * a.ldx + g * 8;
     const int KB = a.K >> 5;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    int kb = wave;
-    for (; kb + 28 < KB; kb += 32) {                                   // 8 fragments (128 B of weights per lane) in flight
-        u32x4 wv[8], xv[8];
+    f32x4_t acc[RG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            wv[j] = ld_stream(reinterpret_cast<const u32x4*>(wp + (kb + 4 * j) * 32));
-            xv[j] = ld16(xp + (kb + 4 * j) * 32);
+    for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = RG >= 4 ? 4 : 8;                                 // fragments in flight per row group
+    int kb = wave;
+    for (; kb + 4 * (U - 1) < KB; kb += 4 * U) {
+        u32x4 wv[RG][U], xv[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            xv[j] = ld16(xp + (kb + 4 * j) * 32);                      // one activation fragment serves RG weight fragments
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) wv[rg][j] = ld_stream(reinterpret_cast<const u32x4*>(wp[rg] + (kb + 4 * j) * 32));
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[j]),
-                                                          __builtin_bit_cast(bf16x8_t, xv[j]), acc, 0, 0, 0);
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+                acc[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[rg][j]),
+                                                                  __builtin_bit_cast(bf16x8_t, xv[j]), acc[rg], 0, 0, 0);
     }
     for (; kb < KB; kb += 4) {
-        const u32x4 wv = ld_stream(reinterpret_cast<const u32x4*>(wp + kb * 32));
         const u32x4 xv = ld16(xp + kb * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), __builtin_bit_cast(bf16x8_t, xv),
-                                                      acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            const u32x4 wv = ld_stream(reinterpret_cast<const u32x4*>(wp[rg] + kb * 32));
+            acc[rg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv),
+                                                              __builtin_bit_cast(bf16x8_t, xv), acc[rg], 0, 0, 0);
+        }
     }
-    part[wave][lane] = acc;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) part[wave][rg][lane] = acc[rg];
     __syncthreads();
-    if (wave != 0) return;
-    f32x4_t v = part[0][lane];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const f32x4_t t = part[w][lane];
-        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-    }
-    // lane holds C[weight row 4g + r][activation row i], r = 0..3
+    // wave w finishes row groups w, w + 4, ...: lane holds C[weight row 4g + r][activation row i], r = 0..3
     const int m = i;
-    if (m >= a.M) return;
-    if constexpr (EPI == EPI_SWIGLU) {
+    for (int rg = wave; rg < RG; rg += 4) {
+        f32x4_t v = part[0][rg][lane];
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-            const int n = n0 + 4 * g + r;
-            if (n + 1 < a.N) {
-                float gt = v[r], up = v[r + 1];
-                if (a.bias) { gt += bf2f(a.bias[n]); up += bf2f(a.bias[n + 1]); }
-                gt = bfround(gt); up = bfround(up);
-                a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
-            }
+        for (int w = 1; w < 4; ++w) {
+            const f32x4_t t = part[w][rg][lane];
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
         }
-    } else {
-        float o[4];
-        bool full = n0 + 4 * g + 3 < a.N;
+        if (m >= a.M) continue;
+        const int nb = n0 + 16 * rg + 4 * g;                           // first of this lane's 4 output columns
+        if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 4 * g + r;
-            float t = v[r];
-            if (n < a.N) {
-                if (a.bias) t += bf2f(a.bias[n]);
-                t = bfround(t);
-                if constexpr (EPI == EPI_SILU) t = bfround(silu(t));
-                if constexpr (EPI == EPI_GELU) t = bfround(gelu_erf(t));
-                if constexpr (EPI == EPI_RESID) t = t + bf2f(a.res[(size_t)m * a.ldres + n]);
+            for (int r = 0; r < 4; r += 2) {
+                const int n = nb + r;
+                if (n + 1 < a.N) {
+                    float gt = v[r], up = v[r + 1];
+                    if (a.bias) { gt += bf2f(a.bias[n]); up += bf2f(a.bias[n + 1]); }
+                    gt = bfround(gt); up = bfround(up);
+                    a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
+                }
             }
-            o[r] = t;
-        }
-        bf16_t* dst = a.out + (size_t)m * a.ldo + n0 + 4 * g;
-        if (full && ((reinterpret_cast<size_t>(dst) & 7) == 0)) {
-            uint2 pk;
-            pk.x = packbf(o[0], o[1]); pk.y = packbf(o[2], o[3]);
-            *reinterpret_cast<uint2*>(dst) = pk;
         } else {
+            float o[4];
+            const bool full = nb + 3 < a.N;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n0 + 4 * g + r < a.N) dst[r] = f2bf(o[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + r;
+                float t = v[r];
+                if (n < a.N) {
+                    if (a.bias) t += bf2f(a.bias[n]);
+                    t = bfround(t);
+                    if constexpr (EPI == EPI_SILU) t = bfround(silu(t));
+                    if constexpr (EPI == EPI_GELU) t = bfround(gelu_erf(t));
+                    if constexpr (EPI == EPI_RESID) t = t + bf2f(a.res[(size_t)m * a.ldres + n]);
+                }
+                o[r] = t;
+            }
+            bf16_t* dst = a.out + (size_t)m * a.ldo + nb;
+            if (full && ((reinterpret_cast<size_t>(dst) & 7) == 0)) {
+                uint2 pk;
+                pk.x = packbf(o[0], o[1]); pk.y = packbf(o[2], o[3]);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < a.N) dst[r] = f2bf(o[r]);
+            }
         }
     }
 }
 
-int launch_gemv_mfma(const GemvArgs& a, hipStream_t s) {
-    const dim3 grid((a.N + 15) / 16), block(256);
-#define EMU_MF_CASE(E) case E: hipLaunchKernelGGL((gemv_mfma_kernel<E>), grid, block, 0, s, a); break;
+template <int RG>
+int launch_gemv_mfma_rg(const GemvArgs& a, hipStream_t s) {
+    const dim3 grid((a.N + 16 * RG - 1) / (16 * RG)), block(256);
+#define EMU_MF_CASE(E) case E: hipLaunchKernelGGL((gemv_mfma_kernel<E, RG>), grid, block, 0, s, a); break;
     switch (a.epi) {
         EMU_MF_CASE(EPI_NONE)
         EMU_MF_CASE(EPI_RESID)
@@ -482,6 +499,19 @@ int launch_gemv_mfma(const GemvArgs& a, hipStream_t s) {
 #undef EMU_MF_CASE
     EMU_CHECK_LAUNCH();
     return 0;
+}
+
+int launch_gemv_mfma(const GemvArgs& a, hipStream_t s) {
+    // Row groups per workgroup (each activation fragment, re-read from L2, then serves RG weight fragments): measured
+    // flat at M = 5 (RG 1 / 2 / 4: 69.5 / 71.7 / 82.9 us on qkv), so the activation re-read is not what holds the kernel
+    // at 3.8 TB/s -- the 64-byte-per-row fragment loads are; RG = 1 keeps the most workgroups in flight.
+    static const char* env = getenv("EMU_GEMV_MFMA_RG");               // A/B
+    int rg = env ? atoi(env) : 1;
+    switch (rg) {
+        case 4: return launch_gemv_mfma_rg<4>(a, s);
+        case 2: return launch_gemv_mfma_rg<2>(a, s);
+        default: return launch_gemv_mfma_rg<1>(a, s);
+    }
 }
 
 // fp8 (OCP e4m3fn) weight stream: half the HBM bytes per token.  One 16-byte load = 16 weights of one row; the per-row

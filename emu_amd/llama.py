@@ -465,8 +465,11 @@ class LlamaEngine:
             # advance the model: reorder the cache rows by beam, feed the chosen tokens
             flat = (beam_idx + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
             ctx = S + cur - 1
-            self.kcache[:, :, :, :ctx] = self.kcache[:, flat, :, :ctx]
-            self.vcache[:, :, :, :ctx] = self.vcache[:, flat, :, :ctx]
+            # beams of one prompt share the prompt's KV rows (replicated above and identical), so only the generated
+            # slots [S, ctx) move with the beam permutation -- a few KB per layer instead of the whole live cache
+            if ctx > S:
+                self.kcache[:, :, :, S:ctx] = self.kcache[:, flat, :, S:ctx]
+                self.vcache[:, :, :, S:ctx] = self.vcache[:, flat, :, S:ctx]
             toks = running_seq[:, :, cur - 1].reshape(-1).to(torch.int32).contiguous()
             ops.embed_gather(toks, self.embed, out=hid)
             slot = torch.full((B * nb,), ctx, device=dev, dtype=torch.int32)
