@@ -351,7 +351,7 @@ def main():
             lm.use_fp8(False) if getattr(lm, "_fp8", None) else None
 
     # ---- extra leg (never the headline): the reference's DEFAULT decoding mode, 5-beam search (emu.py:163-172), whole call
-    # (prefill + KV replication + 24 beam steps through the skinny-MFMA stream); TP=1 only
+    # (prefill + KV replication + 24 beam steps, 5 activation rows per weight stream); TP=1 only
     beam = None
     if not a.no_beam and world == 1:
         try:
@@ -367,7 +367,7 @@ def main():
             steps_b = max(1, out.shape[1] - 1)
             beam = {"num_beams": 5, "new_tokens": int(out.shape[1]), "call_ms": dtb * 1e3,
                     "ms_per_beam_step": (dtb - dpf) * 1e3 / steps_b, "tokens_per_s": steps_b / max(1e-9, dtb - dpf),
-                    "note": "5 rows per weight stream (gemv_mfma_kernel), host-driven beam bookkeeping; prefill excluded from the per-step time"}
+                    "note": "5 rows per weight stream (v_dot2c block kernel, 5-row instantiation), host-driven beam bookkeeping; prefill excluded from the per-step time"}
         except Exception as e:
             beam = {"num_beams": 5, "note": f"beam leg failed: {e}"}
 

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
             const int j = tid / MB, m = tid % MB;
             const int n = n0 + 2 * j;
             if (m < a.M && n + 1 < a.N) {
-                const float gt = bfround(fin[(2 * j) * MB + m]);
-                const float up = bfround(fin[(2 * j + 1) * MB + m]);
+                const float gt = bfround(fin[(2 * j) * MB + m] + (a.bias ? bf2f(a.bias[n]) : 0.f));
+                const float up = bfround(fin[(2 * j + 1) * MB + m] + (a.bias ? bf2f(a.bias[n + 1]) : 0.f));
                 const float act = bfround(silu(gt));
                 a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(act * up);
             }
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void gemv_rt_kernel(const GemvArgs a) {
         if (tid < R / 2) {
             const int n = n0 + 2 * tid;
             if (n + 1 < a.N) {
-                const float gt = bfround(fin[2 * tid]);
-                const float up = bfround(fin[2 * tid + 1]);
+                const float gt = bfround(fin[2 * tid] + (a.bias ? bf2f(a.bias[n]) : 0.f));
+                const float up = bfround(fin[2 * tid + 1] + (a.bias ? bf2f(a.bias[n + 1]) : 0.f));
                 a.out[n >> 1] = f2bf(bfround(silu(gt)) * up);
             }
         }
@@ -624,8 +624,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
             const int j = tid / MB, m = tid % MB;
             const int n = n0 + 2 * j;
             if (m < a.M && n + 1 < a.N) {
-                const float gt = bfround(fin[(2 * j) * MB + m]);
-                const float up = bfround(fin[(2 * j + 1) * MB + m]);
+                const float gt = bfround(fin[(2 * j) * MB + m] + (a.bias ? bf2f(a.bias[n]) : 0.f));
+                const float up = bfround(fin[(2 * j + 1) * MB + m] + (a.bias ? bf2f(a.bias[n + 1]) : 0.f));
                 a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
             }
         }
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
             const int j = tid / MB, m = tid % MB;
             const int n = n0 + 2 * j;
             if (m < a.M && n + 1 < a.N) {
-                const float gt = bfround(fin[(2 * j) * MB + m]);
-                const float up = bfround(fin[(2 * j + 1) * MB + m]);
+                const float gt = bfround(fin[(2 * j) * MB + m] + (a.bias ? bf2f(a.bias[n]) : 0.f));
+                const float up = bfround(fin[(2 * j + 1) * MB + m] + (a.bias ? bf2f(a.bias[n + 1]) : 0.f));
                 a.out[(size_t)m * a.ldo + (n >> 1)] = f2bf(bfround(silu(gt)) * up);
             }
         }
@@ -844,7 +844,9 @@ template <int R>
 int launch_mb(const GemvArgs& a, hipStream_t s) {
     if (a.M <= 1) return launch_norm<R, 1>(a, s);
     if (a.M <= 2) return launch_norm<R, 2>(a, s);
+    if (a.M <= 3) return launch_norm<R, 3>(a, s);
     if (a.M <= 4) return launch_norm<R, 4>(a, s);
+    if (a.M <= 5) return launch_norm<R, 5>(a, s);             // 5 beams: the reference's default decoding mode
     return launch_norm<R, 8>(a, s);
 }
 
@@ -859,6 +861,13 @@ int emu_gemv_rows_per_block(int N, int K, bool norm) {
     (void)K;
     int R = norm ? 16 : 2;
     while (R > 2 && (N + R - 1) / R < (R == 16 ? 1024 : 512)) R >>= 1;
+    return R;
+}
+
+// rows per workgroup for 2..8 activation rows (beam search, CFG pairs): 8 amortises the activation unpack best
+int emu_gemv_rows_per_block_multi(int N) {
+    int R = 8;
+    while (R > 2 && (N + R - 1) / R < 512) R >>= 1;
     return R;
 }
 
@@ -1189,9 +1198,13 @@ unsigned int emu_gemv_stream_giveups_read() {
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.M < 1 || a.M > 16 || (a.K & 7) || a.N < 1) return -22;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return -22;
-    static const char* mf_env = getenv("EMU_GEMV_MFMA");               // A/B: 0 keeps the FMA kernel for M >= 2
-    if (a.M >= 2 && !a.wscale && !a.norm_w && (a.K & 31) == 0 && (a.ldw & 7) == 0 && (a.ldx & 7) == 0 &&
-        !(mf_env && atoi(mf_env) == 0))
+    // 9..16 rows: the 16x16x32 MFMA stream.  Up to 8 rows the v_dot2c block kernel is faster (M = 2: 6.4 vs 4.1 TB/s,
+    // M = 5: 4.5 vs 3.9, M = 8: 3.7 vs 3.5; tools/kbench.py --filter rows): its row-contiguous 1 KiB loads use HBM better
+    // than the MFMA fragment's 64 bytes per row.  EMU_GEMV_MFMA=1 forces the MFMA kernel for every M >= 2 (A/B).
+    static const char* mf_env = getenv("EMU_GEMV_MFMA");
+    const bool mf_all = mf_env && atoi(mf_env) == 1;
+    if ((a.M > 8 || (mf_all && a.M >= 2)) && !a.wscale && !a.norm_w && (a.K & 31) == 0 && (a.ldw & 7) == 0 &&
+        (a.ldx & 7) == 0)
         return launch_gemv_mfma(a, s);
     if (a.M > 8) return -22;
     if (a.wscale && ((a.K & 15) || a.M > 2)) return -22;
@@ -1217,8 +1230,10 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (stream_applicable(a)) return launch_stream(a, s);
     static const char* force_r = getenv("EMU_GEMV_R");     // A/B runs
     int R = a.rows_per_block > 0 ? a.rows_per_block
-                                 : (force_r ? atoi(force_r) : emu_gemv_rows_per_block(a.N, a.K, a.norm_w != nullptr));
-    if (a.M > 4 && R > 4) R = 4;                   // bound the accumulator register file
+                                 : (force_r ? atoi(force_r)
+                                            : (a.M > 1 ? emu_gemv_rows_per_block_multi(a.N)
+                                                       : emu_gemv_rows_per_block(a.N, a.K, a.norm_w != nullptr)));
+    if (a.M > 1 && R > 8) R = 8;                   // 16 rows per workgroup only pays at M = 1 (accumulator registers)
     switch (R) {
         case 2: return launch_mb<2>(a, s);
         case 4: return launch_mb<4>(a, s);

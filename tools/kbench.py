@@ -99,9 +99,12 @@ def main():
     gemv8("gateup+norm+swiglu", 1, 35840, 6656, 2, True)
     gemv8("down+res", 1, 6656, 17920, 1)
     gemv8("lm_head+norm", 1, 32274, 6656, 0, True)
-    gemv("qkv beams5 (skinny mfma)", 5, 19968, 6656, 0, False)
-    gemv("gateup beams5 (skinny mfma)", 5, 35840, 6656, 2, False)
-    gemv("down beams5 (skinny mfma)", 5, 6656, 17920, 1, False)
+    gemv("qkv rows2", 2, 19968, 6656, 0, False)
+    gemv("qkv rows3", 3, 19968, 6656, 0, False)
+    gemv("qkv rows8", 8, 19968, 6656, 0, False)
+    gemv("qkv beams5", 5, 19968, 6656, 0, False)
+    gemv("gateup beams5", 5, 35840, 6656, 2, False)
+    gemv("down beams5", 5, 6656, 17920, 1, False)
     gemv("tp8 qkv", 1, 2688, 6656, 0, True)
     gemv("tp8 o", 1, 6656, 896, 1)
     gemv("tp8 gateup", 1, 4480, 6656, 2, True)
