@@ -477,7 +477,9 @@ void launch_v2(const GemmArgs& a, hipStream_t s) {
         // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
         // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
         // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
-        if (tiles_of(a, 256, 128) >= 1024) cfg = 'C';
+        const int tc = tiles_of(a, 256, 128);
+        if (tc >= 1024) cfg = 'C';
+        else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: LLaMA o/down prefill, ViT qkv
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
         else cfg = 'K';
     }
