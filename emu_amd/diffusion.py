@@ -88,11 +88,16 @@ class EmuVisualGeneration:
         """Steps 2-4 of the reference forward: timesteps, initial latents (``torch.randn`` on the global generator,
         scaled by init_noise_sigma, diffusion.py:126-127) and the denoising loop.  ``latents`` can be injected
         (un-scaled standard normal noise) for reproducible parity runs."""
-        if not guidance_scale > 1.0:
-            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance) is not built; the reference "
-                                      "default is 3.0")
-        if prompt_embeds.shape[0] != 2:
-            raise ValueError("batch size 1 with classifier-free guidance expects prompt_embeds [2, n, C] (cond, uncond)")
+        if guidance_scale > 1.0:
+            if prompt_embeds.shape[0] != 2:
+                raise ValueError("batch size 1 with classifier-free guidance expects prompt_embeds [2, n, C] (cond, uncond)")
+        else:
+            # no classifier-free guidance (diffusion.py:98,133,144: batch 1, the prediction is used as is).  The engine is
+            # built around the CFG pair, so the single prompt rides in both rows: rows of a UNet batch never interact, the
+            # two predictions are bit-identical and uncond + g * (cond - uncond) returns them unchanged.
+            if prompt_embeds.shape[0] != 1:
+                raise ValueError("guidance_scale <= 1 expects prompt_embeds [1, n, C]")
+            prompt_embeds = torch.cat([prompt_embeds, prompt_embeds], dim=0)
         dev = self.device()
         sch = self.unet.set_timesteps(num_inference_steps)
         self.unet.set_context(prompt_embeds, height, width, original_size, crop_info)

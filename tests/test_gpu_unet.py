@@ -206,6 +206,17 @@ def test_pipeline_autoencoding_end_to_end(tiny_unet, tiny_vae, golden_dir):
     want = U.denoise((noise.float() * sch.init_noise_sigma).to(BF16).float(), prompt.float().cpu(), Wr, steps=3, guidance=3.0,
                      height=128, width=128, cfg=ocfg)
     assert rel_err(lat, want) < 5e-2, rel_err(lat, want)
+    # guidance_scale <= 1: no classifier-free guidance (one prompt row; the engine duplicates it, the mix is the identity)
+    one = pipe._prepare_and_encode_inputs([pil], False)
+    assert one.shape == (1, 4, 128) and torch.equal(one, prompt[:1])
+    lat1 = pipe.generate_latents(one, 128, 128, 3, 1.0, latents=noise.cuda().clone())
+    same = pipe.generate_latents(torch.cat([one, one]), 128, 128, 3, 7.5, latents=noise.cuda().clone())
+    assert torch.equal(lat1, same)                                     # identical rows: any guidance value is a no-op
+    want1 = U.denoise((noise.float() * sch.init_noise_sigma).to(BF16).float(), torch.cat([one, one]).float().cpu(), Wr,
+                      steps=3, guidance=1.0, height=128, width=128, cfg=ocfg)
+    assert rel_err(lat1, want1) < 5e-2, rel_err(lat1, want1)
+    out1 = pipe([pil], height=128, width=128, num_inference_steps=2, guidance_scale=1.0)
+    assert out1.image.size == (128, 128)
     img = pipe.decode_latents(lat)
     ref = V.decode_latents(want, Wv, vcfg).permute(0, 2, 3, 1).numpy()
     assert img.shape == ref.shape == (1, 128, 128, 3)
