@@ -326,10 +326,14 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
             px[i] = rr - py[i] * a.conv.Wout;
         }
     }
-    const int nk = a.K / BK;
+    // split-K: this workgroup owns K-tiles [kt0, kt0 + nk) of slice blockIdx.y
+    const int nk_all = a.K / BK;
+    const int ks = blockIdx.y;
+    const int kt0 = (int)((long)ks * nk_all / a.ksplit);
+    const int nk = (int)((long)(ks + 1) * nk_all / a.ksplit) - kt0;
     auto issue = [&](int kt, int stage) {
         kt = kt < nk ? kt : nk - 1;                    // past-the-end tiles re-load the last one (keeps vmcnt counts uniform)
-        const int k0 = kt * BK;
+        const int k0 = (kt0 + kt) * BK;
         char* base = smem + stage * T::ST_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
@@ -440,7 +444,14 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                store_quad<EPI>(a, m, nb, v);
+                if (a.ksplit > 1) {                    // raw fp32 slice; splitk_reduce_kernel applies the epilogue
+                    float* dst = a.partial + ((size_t)ks * a.M + m) * a.N + nb;
+                    if (nb + 3 < a.N) *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
+                    else
+                        for (int e = 0; e < 4 && nb + e < a.N; ++e) dst[e] = v[e];
+                } else {
+                    store_quad<EPI>(a, m, nb, v);
+                }
             }
     }
 }
@@ -460,10 +471,41 @@ using CfgL = TileCfg<2, 2, 2, 2, 2, 2>;  // 128 x 128, 2 k-groups x 4 waves, 2 s
 // measured and dropped (profiles/r01_gemm_tilecfg_sweep_MN.log): 4 waves of 128(n) x 64(m) on a 256 x 128 tile
 // (0.75 KB of LDS reads per MFMA instead of 1 KB): -5 % vs C; 4 waves of 128 x 128 on 256 x 256 (AGPR accumulators): -40 %
 
+// second launch of a split-K GEMM: sum the K-slices in slice order (deterministic) and apply the fused epilogue
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
+    const int nq = (a.N + 3) >> 2;
+    const size_t total = (size_t)a.M * nq;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int m = (int)(q / nq), nb = (int)(q - (size_t)m * nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < a.ksplit; ++ks) {
+            const float* src = a.partial + ((size_t)ks * a.M + m) * a.N + nb;
+            if (nb + 3 < a.N) {
+                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            } else {
+                for (int e = 0; e < 4 && nb + e < a.N; ++e) v[e] += src[e];
+            }
+        }
+        store_quad<EPI>(a, m, nb, v);
+    }
+}
+
+float* g_splitk_scratch = nullptr;
+size_t g_splitk_floats = 0;
+
 template <int EPI, bool CONV, class T>
-void launch_cfg(const GemmArgs& a, hipStream_t s) {
+void launch_cfg(const GemmArgs& a, hipStream_t s, int ksplit = 1) {
     const int tiles = ((a.M + T::BMv - 1) / T::BMv) * ((a.N + T::BNv - 1) / T::BNv);
-    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(tiles), dim3(T::THREADS), 0, s, a);
+    GemmArgs b = a;
+    b.ksplit = ksplit;
+    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(tiles, ksplit), dim3(T::THREADS), 0, s, b);
+    if (ksplit > 1) {
+        const size_t quads = (size_t)a.M * ((a.N + 3) >> 2);
+        const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(grid), dim3(256), 0, s, b);
+    }
 }
 
 inline int tiles_of(const GemmArgs& a, int bn, int bm) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); }
@@ -472,6 +514,25 @@ template <int EPI, bool CONV>
 void launch_v2(const GemmArgs& a, hipStream_t s) {
     static const char* force = getenv("EMU_GEMM_CFG");      // A/B runs: force one configuration
     char cfg = force ? force[0] : 0;
+    // split-K: the 256x128 tile moves the fewest bytes per FLOP through L2 (the binding resource of these kernels), but
+    // a 2048 x 1280 output is only 80 of them; K-slices give every CU one workgroup.  Needs N % 4 == 0 (fp32 quads),
+    // a non-GLU epilogue, >= 16 K-tiles per slice and scratch for the slices.
+    if (!cfg || cfg == 'S') {
+        static const char* sk_env = getenv("EMU_GEMM_SPLITK");         // A/B: 0 disables
+        GemmArgs b = a;
+        if (!b.partial) { b.partial = g_splitk_scratch; b.partial_floats = g_splitk_floats; }
+        const int tc = tiles_of(a, 256, 128), nk = a.K / BK;
+        int ksplit = tc > 0 ? 256 / tc : 1;
+        if (ksplit > 4) ksplit = 4;
+        while (ksplit > 1 && nk / ksplit < 16) --ksplit;
+        const bool epi_ok = EPI != EPI_SWIGLU && EPI != EPI_GEGLU;
+        if (epi_ok && b.partial && ksplit > 1 && (a.N & 3) == 0 && (size_t)ksplit * a.M * a.N <= b.partial_floats &&
+            !(sk_env && atoi(sk_env) == 0)) {
+            launch_cfg<EPI, CONV, CfgC>(b, s, ksplit);
+            return;
+        }
+        if (cfg == 'S') cfg = 0;
+    }
     if (!cfg) {
         // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so the largest problems take the
         // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
@@ -493,6 +554,8 @@ void launch_v2(const GemmArgs& a, hipStream_t s) {
 
 
 }  // namespace
+
+void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7) || (a.ldc & 3)) return -22;

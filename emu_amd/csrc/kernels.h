@@ -44,8 +44,16 @@ struct GemmArgs {
     const bf16_t* bias2;    // [M / rows_per_batch, ld_bias2] or null: per-batch bias added after the first rounding
     int rows_per_batch;     //   (ResnetBlock2D: conv1(x) + time_emb_proj(silu(temb))[:, :, None, None])
     int ld_bias2;
+    // optional split-K scratch (fp32, caller-owned): few-tile long-K problems (UNet 32x32-level convs, ff-out) are cut
+    // into ksplit K-slices of the big 256x128 tile so every CU gets one workgroup; slices land here and a second
+    // launch sums them and applies the epilogue.  null = never split.
+    float* partial = nullptr;
+    size_t partial_floats = 0;
+    int ksplit = 1;         // set by launch_gemm
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// process-wide default split-K scratch for callers that do not pass one (the C-ABI primitives); caller-owned memory
+void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
 
 // ---- row-wise / elementwise (elementwise.hip)
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);

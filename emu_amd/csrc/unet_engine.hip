@@ -50,6 +50,8 @@ struct Level { int c, hw_shift; };
 struct emu_unet {
     emu_ctx* ctx;
     emu_unet_cfg cfg;
+    float* splitk = nullptr;            // bound to the caller's workspace at every entry (plan_ws)
+    size_t splitk_floats = 0;
     std::map<std::string, const bf16_t*> w;
     bool finalized = false;
     // resolved structure
@@ -122,6 +124,8 @@ struct Ws {
     bf16_t* skip[12];
     bf16_t *temb_in, *e1, *emb, *semb, *temb_all, *add1;
     float* gnws;
+    float* splitk;          // fp32 K-slices of the split-K GEMMs / convs of the lowest-resolution level
+    size_t splitk_floats;
     size_t total;
 };
 
@@ -167,6 +171,8 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
     w.semb = (bf16_t*)take(Bn * c.temb_dim); w.temb_all = (bf16_t*)take((size_t)Bn * u->temb_total);
     w.add1 = (bf16_t*)take(Bn * c.temb_dim);
     w.gnws = (float*)take(gn_ws_floats(Bn, 2 * c.ch[2] > c.ch[1] + c.ch[0] ? 2 * c.ch[2] : c.ch[1] + c.ch[0], (int)hw[0]), 4);
+    w.splitk_floats = (size_t)4 * Bn * hw[2] * c.ch[2];
+    w.splitk = (float*)take(w.splitk_floats, 4);
     w.total = off;
     return w;
 }
@@ -178,6 +184,7 @@ int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, con
         return launch_gemv(g, s);
     }
     GemmArgs g{A, Wt, bias, res, C, M, N, K, lda, K, ldres, ldc, epi, NOCONV, nullptr, 0, 0};
+    if (u) { g.partial = u->splitk; g.partial_floats = u->splitk_floats; }    // primitives (u == null): process scratch
     return launch_gemm(g, s);
 }
 
@@ -188,6 +195,7 @@ int conv3(emu_unet* u, const bf16_t* x, const bf16_t* Wt, const bf16_t* bias, co
     if (mode == CONV_3X3_UP2) { Ho = 2 * Hin; Wo = 2 * Win; }
     GemmArgs g{x, Wt, bias, res, y, Bn * Ho * Wo, Cout, 9 * Cin, 0, 9 * Cin, Cout, Cout, res ? EPI_RESID : EPI_NONE,
                ConvGeom{mode, Hin, Win, Ho, Wo, Cin}, bias2, Ho * Wo, ldb2};
+    if (u) { g.partial = u->splitk; g.partial_floats = u->splitk_floats; }    // primitives (u == null): process scratch
     return launch_gemm(g, s);
 }
 
@@ -471,6 +479,7 @@ int emu_unet_step(emu_unet* u, void* latents, int H, int W, const void* temb_tab
     if (!u->ctx_cache) return ufail(u, -22, "emu_unet_step: emu_unet_set_context has not been called");
     if ((H & 3) || (W & 3)) return ufail(u, -22, "emu_unet_step: latent H, W must be multiples of 4");
     const Ws w = plan_ws(u, H, W, workspace);
+    u->splitk = w.splitk; u->splitk_floats = w.splitk_floats;
     if (w.total > ws_bytes) return ufail(u, -12, "emu_unet_step: workspace too small");
     hipStream_t s = S(s_);
     UTRY(launch_unet_prep_input(reinterpret_cast<bf16_t*>(latents), reinterpret_cast<const float*>(sigmas), step_dev, w.colin,
@@ -489,6 +498,7 @@ int emu_unet_forward(emu_unet* u, const void* latents, int H, int W, const void*
     if (!u || !u->finalized || !latents || !temb_table || !sigmas || !step_dev || !eps_out) return -22;
     if (!u->ctx_cache) return ufail(u, -22, "emu_unet_forward: emu_unet_set_context has not been called");
     const Ws w = plan_ws(u, H, W, workspace);
+    u->splitk = w.splitk; u->splitk_floats = w.splitk_floats;
     if (w.total > ws_bytes) return ufail(u, -12, "emu_unet_forward: workspace too small");
     hipStream_t s = S(s_);
     UTRY(launch_unet_prep_input(B16(latents), reinterpret_cast<const float*>(sigmas), step_dev, w.colin, u->cfg.in_ch, H, W,

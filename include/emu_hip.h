@@ -42,6 +42,12 @@ int emu_tp_unique_id(void* out128);                      /* rank 0: 128-byte RCC
 int emu_tp_init(emu_ctx* ctx, const void* id128);        /* all ranks: ncclCommInitRank               */
 int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);   /* in-place sum          */
 
+/* Optional fp32 scratch for split-K GEMMs / convolutions issued through the primitives below (emu_linear_bf16,
+ * emu_conv3x3_nhwc_bf16): few-tile long-K problems are cut into up to 4 K-slices that land here before a second launch
+ * applies the epilogue.  Caller-owned device memory, >= 4 * M * N * 4 bytes for the shapes that should split; NULL / 0
+ * (the default) never splits.  One stream at a time may use it.  The UNet engine carries its own inside its workspace. */
+void emu_set_splitk_scratch(void* ptr, size_t bytes);
+
 /* Diagnostic of the LDS-DMA weight-streaming GEMV engine (decode rows, K % 512 == 0, >= 16 MiB of weights): number of
  * bounded ring hand-off spins that expired since the library was loaded.  Non-zero means a launch gave up instead of
  * hanging the GPU and its output is invalid; the parity tests assert it stays 0. */

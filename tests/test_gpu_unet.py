@@ -65,6 +65,53 @@ def test_conv3x3_time_bias_and_residual():
     assert rel_err(got.permute(0, 3, 1, 2), ref) < 1e-2
 
 
+@pytest.fixture
+def splitk_scratch():
+    """Registers a caller-owned fp32 scratch so the primitives may split K (default: never), and removes it again."""
+    from emu_amd._lib import lib
+    buf = torch.zeros(4 * 2048 * 1280, dtype=torch.float32, device="cuda")
+    lib().emu_set_splitk_scratch(buf.data_ptr(), buf.numel() * 4)
+    yield buf
+    torch.cuda.synchronize()
+    lib().emu_set_splitk_scratch(None, 0)
+
+
+def test_conv3x3_split_k(splitk_scratch):
+    """The UNet's lowest-resolution convs (2 x 32 x 32 pixels x 1280 channels: 80 tiles of 256 x 128) run as K-slices +
+    a reduce/epilogue launch: same result as the unsplit kernel up to summation order, correct against F.conv2d, with
+    the time-embedding bias and the residual applied once, after the reduction."""
+    from emu_amd import ops
+    from emu_amd._lib import lib
+    B, Cin, Cout, H, W = 2, 256, 1280, 32, 32                            # K = 2304 -> 36 K-tiles -> 2 slices
+    x, w = rnd(B, Cin, H, W, seed=31), rnd(Cout, Cin, 3, 3, seed=32, scale=0.03)
+    bias, temb, res = rnd(Cout, seed=33), rnd(B, Cout, seed=34), rnd(B, Cout, H, W, seed=35)
+    xs, ws = x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda()
+    rs = res.permute(0, 2, 3, 1).contiguous().cuda()
+    splitk_scratch.fill_(float("nan"))                                   # every slice element must be overwritten
+    got = ops.conv3x3_nhwc(xs, ws, bias=bias.cuda(), bias2=temb.cuda(), res=rs)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(splitk_scratch[: 2 * B * H * W * Cout]).any())      # the slices were really used
+    lib().emu_set_splitk_scratch(None, 0)
+    plain = ops.conv3x3_nhwc(xs, ws, bias=bias.cuda(), bias2=temb.cuda(), res=rs)
+    assert rel_err(got, plain) < 2e-3
+    ref = F.conv2d(x.float(), w.float(), bias.float(), padding=1).to(BF16).float()
+    ref = (ref + temb.float()[:, :, None, None]).to(BF16).float() + res.float()
+    assert rel_err(got.permute(0, 3, 1, 2), ref) < 1e-2
+
+
+def test_linear_split_k(splitk_scratch):
+    """ff-out shaped GEMM (M 2048, N 1280, K 5120) with bias + residual through the split-K path."""
+    from emu_amd import ops
+    M, N, K = 2048, 1280, 5120
+    x, w, b, r = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.03), rnd(N, seed=43), rnd(M, N, seed=44)
+    splitk_scratch.fill_(float("nan"))
+    got = ops.linear(x.cuda(), w.cuda(), bias=b.cuda(), res=r.cuda(), epi=ops.EPI_RESID)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(splitk_scratch[: 3 * M * N]).any())
+    ref = (x.float() @ w.float().t() + b.float()).to(BF16).float() + r.float()
+    assert rel_err(got, ref) < 1e-2
+
+
 @pytest.fixture(scope="module")
 def tiny_unet():
     """A UNet with the SDXL topology of the reference config at small width (channels 64/128/256, head dim 64)."""
