@@ -40,7 +40,7 @@ struct GemvProfiler {
 
 int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* res, const bf16_t* norm_w,
            bf16_t* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, hipStream_t s,
-           const float* wscale = nullptr) {
+           const float* wscale = nullptr, float* splitk = nullptr, size_t splitk_floats = 0) {
     if (wscale && M > 2) return -22;                 // fp8 weights are a decode-only stream
     // rows <= 8 stream the weights through the GEMV family (M >= 2 without a fused norm: skinny MFMA kernel); 9..16
     // rows too when the MFMA kernel covers the shape -- a 128-row GEMM tile would be > 87 % padding there
@@ -63,6 +63,7 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
     }
     if (norm_w) return -22;
     GemmArgs g{A, W, bias, res, C, M, N, K, lda, ldw, ldres, ldc, epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+    g.partial = splitk; g.partial_floats = splitk_floats;
     return launch_gemm(g, s);
 }
 }  // namespace
@@ -447,7 +448,7 @@ struct emu_vit {
 
 namespace {
 constexpr int VIT_DP = 128;      // padded head dim
-struct VitWs { bf16_t *patches, *pemb, *qkv, *vt, *attn, *tmp, *h1; size_t total; };
+struct VitWs { bf16_t *patches, *pemb, *qkv, *vt, *attn, *tmp, *h1; float* splitk; size_t splitk_floats; size_t total; };
 VitWs vit_ws(const emu_vit* m, int Bn, void* base) {
     const emu_vit_cfg& c = m->cfg;
     const int g = c.image_size / c.patch_size, T = g * g, N = T + 1;
@@ -464,6 +465,8 @@ VitWs vit_ws(const emu_vit* m, int Bn, void* base) {
     w.attn = (bf16_t*)take(M * c.heads * VIT_DP * 2);
     w.tmp = (bf16_t*)take(M * c.width * 2);
     w.h1 = (bf16_t*)take(M * (size_t)c.mlp_hidden * 2);
+    w.splitk_floats = (size_t)4 * M * c.width;            // K-slices of fc2 (M x width output, K = mlp_hidden): 63 tiles of 256x128
+    w.splitk = (float*)take(w.splitk_floats * sizeof(float));
     w.total = off;
     return w;
 }
@@ -535,12 +538,12 @@ int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, voi
             TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, x, nullptr, x, M, C, QK, QK, QK, C, C, 0.f, EPI_RESID, s));
             TRY(cx, launch_layernorm(x, Bk.ln2w, Bk.ln2b, nullptr, w.tmp, M, C, c.ln_eps, s));
             TRY(cx, linear(w.tmp, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
-            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, x, nullptr, x, M, C, F, F, F, C, C, 0.f, EPI_RESID, s));
+            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, x, nullptr, x, M, C, F, F, F, C, C, 0.f, EPI_RESID, s, nullptr, w.splitk, w.splitk_floats));
         } else {
             TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s));
             TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
             TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
-            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s));
+            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
             TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
         }
     }
