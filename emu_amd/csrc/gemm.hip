@@ -539,7 +539,10 @@ void launch_v2(const GemmArgs& a, hipStream_t s) {
         // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
         // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
         const int tc = tiles_of(a, 256, 128);
-        if (tc >= 1024) cfg = 'C';
+        static const char* glu_env = getenv("EMU_GEMM_GLU_CFG");      // A/B for the GEGLU / SwiGLU GEMMs only
+        if (glu_env && (EPI == EPI_GEGLU || EPI == EPI_SWIGLU)) cfg = glu_env[0];
+        else if (tc >= 1024) cfg = 'C';
+        else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step) +1.5 % over 128x128
         else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: LLaMA o/down prefill, ViT qkv
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
         else cfg = 'K';
