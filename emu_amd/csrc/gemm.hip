@@ -545,7 +545,10 @@ void launch_v2(const GemmArgs& a, hipStream_t s) {
         else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step) +1.5 % over 128x128
         else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: LLaMA o/down prefill, ViT qkv
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
-        else cfg = 'K';
+        else {
+            static const char* small_env = getenv("EMU_GEMM_SMALL_CFG");    // A/B for the few-tile fallback
+            cfg = small_env ? small_env[0] : 'K';
+        }
     }
     switch (cfg) {
         case 'C': launch_cfg<EPI, CONV, CfgC>(a, s); break;

@@ -127,6 +127,33 @@ def test_generate_graph_replay_equals_eager(tiny_model, golden_dir):
     assert new1.cpu().tolist() == z["new1"].tolist()
 
 
+def test_greedy_across_split_and_bucket_edges_graph_equals_eager_and_oracle(tiny_model):
+    """Generation that walks across a 128-key attention split (context 120 -> 150) and lands exactly on a KV bucket edge
+    (256): hipGraph replay == eager launches token for token, and both follow the CPU oracle up to its first near-tie."""
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    g = torch.Generator().manual_seed(11)
+    for S, n_new in ((120, 30), (226, 30)):                              # 226 + 30 = 256: the last slot of the bucket
+        ids = torch.randint(3, 32000, (2, S), generator=g)
+        mask = torch.ones(2, S, dtype=torch.long)
+        mask[1, :9] = 0                                                  # left padding on row 1
+        m.use_graph = False
+        eager = m.generate_ids(ids, mask, None, max_new_tokens=n_new, stop_on_eos=False)
+        m.use_graph = True
+        try:
+            graph = m.generate_ids(ids, mask, None, max_new_tokens=n_new, stop_on_eos=False)
+        finally:
+            m.use_graph = False
+        assert eager.cpu().tolist() == graph.cpu().tolist()
+        Wb = R.cast_weights(W, BF16)
+        want, margins = R.greedy_generate(R.embed_tokens(ids, Wb), mask, Wb, cfg.llama, n_new, return_margins=True)
+        got = eager.cpu()
+        for i in range(min(want.shape[1], got.shape[1])):
+            if got[:, i].tolist() != want[:, i].tolist():
+                assert float(margins[:, i].min()) < 0.08, f"S={S}: diverged at step {i}, margin {margins[:, i].min():.3f}"
+                break
+
+
 def test_generate_image_matches_reference(tiny_model, golden_dir):
     """Stated fp tolerance on the regressed visual embeddings: relative L2 error < 3e-2 vs the oracle's uncached
     loop (the reference algorithm) and vs the real reference output."""
