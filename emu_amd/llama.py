@@ -511,6 +511,14 @@ class GreedyState:
         self.ws = eng._workspace(B, 1)
         self.graph = None
 
+    def reset(self, first_ids: torch.Tensor, next_pos: torch.Tensor, S: int) -> None:
+        """Rewind the device-side state to the end of the prompt, in place (a captured graph stays valid)."""
+        self.cur.copy_(first_ids.to(torch.int32))
+        self.pos.copy_(next_pos.to(torch.int32))
+        self.slot.fill_(S)
+        self.ctx.fill_(S + 1)
+        self.step_idx.fill_(1)
+
     def step(self) -> None:
         e = self.eng
         check(lib().emu_llama_greedy_step(e.handle, self.B, self.cur.data_ptr(), self.pos.data_ptr(),
