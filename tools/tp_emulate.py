@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Per-rank decode cost of a TP shard on ONE GPU: rank 0's 1/tp slice of LLaMA-33B with a 1-rank RCCL communicator in the
+loop (the all-reduce launches are real, their cross-GPU latency is not).  Usage: python tools/tp_emulate.py [tp] [steps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emu_amd import synth, ops
+from emu_amd.conf.emu_conf import LlamaCfg
+from emu_amd.llama import EmuHipContext, LlamaEngine, GreedyState
+
+tp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+dev = torch.device("cuda", 0)
+real = EmuHipContext(dev, 0, 1)
+real.init_tp(lambda b: b, force=True)
+
+
+class ShardView:                      # the engine plans its shard from (tp_rank, tp_size); RCCL sees the 1-rank context
+    def __init__(self, ctx, size):
+        self.__dict__.update(ctx=ctx, tp_rank=0, tp_size=size)
+
+    def __getattr__(self, k):
+        return getattr(self.ctx, k)
+
+
+l = LlamaCfg()
+V = 32274
+eng = LlamaEngine(l, V, ShardView(real, tp))
+eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device=dev, dtype=torch.bfloat16))
+S = 770
+x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
+mask = torch.ones(1, S, dtype=torch.long)
+with torch.no_grad():
+    hidden, kstart, next_pos = eng.prefill(x, mask, eng.kv_capacity(S + steps + 24))
+    cur = ops.argmax(eng.logits(hidden[:, -1, :]), suppress_id=2)
+    out = torch.zeros(steps + 16, 1, device=dev, dtype=torch.int32)
+    for graph in (True, False):
+        st = GreedyState(eng, 1, cur, next_pos, S, kstart, out)
+        fn = st.step_graph if graph else st.step
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / steps * 1e3
+        print(f"tp={tp} shard on one GPU, {'hipGraph' if graph else 'eager'}: {ms:.3f} ms/token "
+              f"({eng.weight_bytes_per_token() / 1e9:.2f} GB of weights per token per rank)")
