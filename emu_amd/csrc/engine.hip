@@ -246,6 +246,8 @@ namespace {
 struct LlamaWs {
     bf16_t *hB, *xn, *qkv, *attn, *act, *vt;
     float* dec;
+    float* splitk;          // prefill only: K-slices of the GEMMs' tail round
+    size_t splitk_floats;
     size_t total;
 };
 LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
@@ -263,6 +265,8 @@ LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
     const size_t spad = (size_t)((m->s_max + 63) / 64) * 64;
     w.vt = (bf16_t*)take(T > 1 ? (size_t)Bn * HD * spad * 2 : 0);
     w.dec = (float*)take(decode_fused_ws_floats(Bn, c.heads_local, c.head_dim, m->s_max > 0 ? m->s_max : 1) * sizeof(float));
+    w.splitk_floats = M > 16 ? EMU_SPLITK_SCRATCH_FLOATS : 0;
+    w.splitk = (float*)take(w.splitk_floats * sizeof(float));
     w.total = off;
     return w;
 }
@@ -363,7 +367,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
         } else {                                     // 2..16 rows: norm once, skinny MFMA stream; more: GEMM
             TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
-            TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s));
+            TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
         }
         if (T == 1) {
             // RoPE + KV append + attention in one launch; context = slot + 1 is read on the device (graph replay)
@@ -382,7 +386,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, launch_flash_attn(f, s));
         }
         if (f8) TRY(cx, linear(w.attn, B(L8.wo), nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, L8.so));
-        else TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s));
+        else TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, nullptr, w.splitk, w.splitk_floats));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, w.hB, (size_t)M * H, s_));
         // ---- SwiGLU MLP
         if (f8) {
@@ -394,7 +398,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s));
         }
         if (f8) TRY(cx, linear(w.act, B(L8.wdown), nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, L8.sdown));
-        else TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s));
+        else TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, nullptr, w.splitk, w.splitk_floats));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)M * H, s_));
     }
     return 0;
@@ -465,7 +469,7 @@ VitWs vit_ws(const emu_vit* m, int Bn, void* base) {
     w.attn = (bf16_t*)take(M * c.heads * VIT_DP * 2);
     w.tmp = (bf16_t*)take(M * c.width * 2);
     w.h1 = (bf16_t*)take(M * (size_t)c.mlp_hidden * 2);
-    w.splitk_floats = (size_t)4 * M * c.width;            // K-slices of fc2 (M x width output, K = mlp_hidden): 63 tiles of 256x128
+    w.splitk_floats = EMU_SPLITK_SCRATCH_FLOATS;          // K-slices of fc2 (63 tiles of 256x128) and of fc1's tail round
     w.splitk = (float*)take(w.splitk_floats * sizeof(float));
     w.total = off;
     return w;
@@ -525,7 +529,7 @@ int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, voi
             TRY(cx, launch_layernorm(x, Bk.ln1w, Bk.ln1b, nullptr, w.tmp, M, C, c.ln_eps, s));
             ain = w.tmp;
         }
-        TRY(cx, linear(ain, Bk.wqkv, Bk.bqkv, nullptr, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, 0.f, EPI_NONE, s));
+        TRY(cx, linear(ain, Bk.wqkv, Bk.bqkv, nullptr, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
         TransposeVArgs tv{w.qkv + 2 * QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK, w.vt, Bn, Hh, N, VIT_DP, npad};
         TRY(cx, launch_transpose_v(tv, s));
         FlashArgs f{w.qkv, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
@@ -535,14 +539,14 @@ int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, voi
         TRY(cx, launch_flash_attn(f, s));
         if (c.prenorm) {
             // x = x + proj(attn);  x = x + fc2(gelu(fc1(LN2(x))))
-            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, x, nullptr, x, M, C, QK, QK, QK, C, C, 0.f, EPI_RESID, s));
+            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, x, nullptr, x, M, C, QK, QK, QK, C, C, 0.f, EPI_RESID, s, nullptr, w.splitk, w.splitk_floats));
             TRY(cx, launch_layernorm(x, Bk.ln2w, Bk.ln2b, nullptr, w.tmp, M, C, c.ln_eps, s));
-            TRY(cx, linear(w.tmp, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
+            TRY(cx, linear(w.tmp, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s, nullptr, w.splitk, w.splitk_floats));
             TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, x, nullptr, x, M, C, F, F, F, C, C, 0.f, EPI_RESID, s, nullptr, w.splitk, w.splitk_floats));
         } else {
-            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s));
+            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
             TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
-            TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s));
+            TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s, nullptr, w.splitk, w.splitk_floats));
             TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
             TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
         }

@@ -295,9 +295,21 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     const int wn = wtile / T::WM, wm = wtile % T::WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int xcd = b & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    // Workgroups [0, full_tiles) own whole tiles (XCD-aware bijective remap so the 8 L2s each see a compact set of
+    // tiles); the rest are K-slices of the tail tiles (wave-quantisation fix: a 2.13-round problem would otherwise pay
+    // for 3 rounds).  full_tiles == number of tiles and ksplit == 1 for an unsplit launch.
+    const int b = blockIdx.x;
+    int wg, ks = 0, nsl = 1;
+    if (b < a.full_tiles) {
+        const int nwg = a.full_tiles;
+        const int xcd = b & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    } else {
+        const int j = b - a.full_tiles;
+        wg = a.full_tiles + j / a.ksplit;
+        ks = j - (wg - a.full_tiles) * a.ksplit;
+        nsl = a.ksplit;
+    }
     const int tiles_m = (a.M + T::BMv - 1) / T::BMv;
     const int n0 = (wg / tiles_m) * T::BNv, m0 = (wg % tiles_m) * T::BMv;
 
@@ -328,9 +340,8 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     }
     // split-K: this workgroup owns K-tiles [kt0, kt0 + nk) of slice blockIdx.y
     const int nk_all = a.K / BK;
-    const int ks = blockIdx.y;
-    const int kt0 = (int)((long)ks * nk_all / a.ksplit);
-    const int nk = (int)((long)(ks + 1) * nk_all / a.ksplit) - kt0;
+    const int kt0 = (int)((long)ks * nk_all / nsl);
+    const int nk = (int)((long)(ks + 1) * nk_all / nsl) - kt0;
     auto issue = [&](int kt, int stage) {
         kt = kt < nk ? kt : nk - 1;                    // past-the-end tiles re-load the last one (keeps vmcnt counts uniform)
         const int k0 = (kt0 + kt) * BK;
@@ -444,11 +455,10 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (a.ksplit > 1) {                    // raw fp32 slice; splitk_reduce_kernel applies the epilogue
-                    float* dst = a.partial + ((size_t)ks * a.M + m) * a.N + nb;
-                    if (nb + 3 < a.N) *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
-                    else
-                        for (int e = 0; e < 4 && nb + e < a.N; ++e) dst[e] = v[e];
+                if (nsl > 1) {                         // raw fp32 slice tile; splitk_reduce_kernel applies the epilogue
+                    float* dst = a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * (T::BMv * T::BNv) +
+                                 (size_t)(m - m0) * T::BNv + (nb - n0);
+                    *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
                 } else {
                     store_quad<EPI>(a, m, nb, v);
                 }
@@ -471,22 +481,25 @@ using CfgL = TileCfg<2, 2, 2, 2, 2, 2>;  // 128 x 128, 2 k-groups x 4 waves, 2 s
 // measured and dropped (profiles/r01_gemm_tilecfg_sweep_MN.log): 4 waves of 128(n) x 64(m) on a 256 x 128 tile
 // (0.75 KB of LDS reads per MFMA instead of 1 KB): -5 % vs C; 4 waves of 128 x 128 on 256 x 256 (AGPR accumulators): -40 %
 
-// second launch of a split-K GEMM: sum the K-slices in slice order (deterministic) and apply the fused epilogue
-template <int EPI>
+// second launch of a split-K GEMM: sum the K-slices of every tail tile in slice order (deterministic) and apply the
+// fused epilogue.  SPLITK_RED_Y workgroups per tail tile (a handful of tail tiles must still fill the chip).
+constexpr int SPLITK_RED_Y = 16;
+template <int EPI, class T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
-    const int nq = (a.N + 3) >> 2;
-    const size_t total = (size_t)a.M * nq;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
-        const int m = (int)(q / nq), nb = (int)(q - (size_t)m * nq) * 4;
+    const int wg = a.full_tiles + blockIdx.x;
+    const int tiles_m = (a.M + T::BMv - 1) / T::BMv;
+    const int n0 = (wg / tiles_m) * T::BNv, m0 = (wg % tiles_m) * T::BMv;
+    const float* base = a.partial + (size_t)blockIdx.x * a.ksplit * (T::BMv * T::BNv);
+    constexpr int QN = T::BNv / 4;
+    constexpr int PER = T::BMv * QN / SPLITK_RED_Y;                   // quads per workgroup (grid.y chunks of a tile)
+    for (int q = blockIdx.y * PER + threadIdx.x; q < (blockIdx.y + 1) * PER; q += 256) {
+        const int lm = q / QN, lq = q - lm * QN;
+        const int m = m0 + lm, nb = n0 + lq * 4;
+        if (m >= a.M || nb >= a.N) continue;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < a.ksplit; ++ks) {
-            const float* src = a.partial + ((size_t)ks * a.M + m) * a.N + nb;
-            if (nb + 3 < a.N) {
-                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(src);
-                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-            } else {
-                for (int e = 0; e < 4 && nb + e < a.N; ++e) v[e] += src[e];
-            }
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * (T::BMv * T::BNv) + (size_t)lm * T::BNv + lq * 4);
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
         }
         store_quad<EPI>(a, m, nb, v);
     }
@@ -495,17 +508,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 float* g_splitk_scratch = nullptr;
 size_t g_splitk_floats = 0;
 
+// full_tiles whole-K workgroups followed by (tiles - full_tiles) * ksplit slice workgroups, one launch (+ the reduce)
 template <int EPI, bool CONV, class T>
-void launch_cfg(const GemmArgs& a, hipStream_t s, int ksplit = 1) {
+void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int ksplit = 1) {
     const int tiles = ((a.M + T::BMv - 1) / T::BMv) * ((a.N + T::BNv - 1) / T::BNv);
     GemmArgs b = a;
+    b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
-    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(tiles, ksplit), dim3(T::THREADS), 0, s, b);
-    if (ksplit > 1) {
-        const size_t quads = (size_t)a.M * ((a.N + 3) >> 2);
-        const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
-        hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3(grid), dim3(256), 0, s, b);
-    }
+    const int tail = tiles - b.full_tiles;
+    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+    if (tail > 0) hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }
 
 inline int tiles_of(const GemmArgs& a, int bn, int bm) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); }
@@ -514,21 +526,31 @@ template <int EPI, bool CONV>
 void launch_v2(const GemmArgs& a, hipStream_t s) {
     static const char* force = getenv("EMU_GEMM_CFG");      // A/B runs: force one configuration
     char cfg = force ? force[0] : 0;
-    // split-K: the 256x128 tile moves the fewest bytes per FLOP through L2 (the binding resource of these kernels), but
-    // a 2048 x 1280 output is only 80 of them; K-slices give every CU one workgroup.  Needs N % 4 == 0 (fp32 quads),
-    // a non-GLU epilogue, >= 16 K-tiles per slice and scratch for the slices.
+    // split-K, whole problem or tail only.  The 256x128 tile moves the fewest bytes per FLOP through L2 (the binding
+    // resource of these kernels) but runs one workgroup per CU, so a problem of T tiles costs ceil(T / 256) rounds: a
+    // 2048 x 1280 output is 80 tiles (0.31 round), the LLaMA qkv prefill 546 (2.13 -> 3 rounds).  The tiles beyond the
+    // last full round (all of them when T < 256) are cut into K-slices so they fill the CUs once more: fp32 slice tiles
+    // land in a scratch, a second launch sums them in order and applies the epilogue.  Needs N % 4 == 0, a non-GLU
+    // epilogue (the pair lives in one quad, fine, but GLU halves the output row -- kept simple), >= 8 K-tiles per slice.
     if (!cfg || cfg == 'S') {
         static const char* sk_env = getenv("EMU_GEMM_SPLITK");         // A/B: 0 disables
         GemmArgs b = a;
         if (!b.partial) { b.partial = g_splitk_scratch; b.partial_floats = g_splitk_floats; }
-        const int tc = tiles_of(a, 256, 128), nk = a.K / BK;
-        int ksplit = tc > 0 ? 256 / tc : 1;
-        if (ksplit > 4) ksplit = 4;
-        while (ksplit > 1 && nk / ksplit < 16) --ksplit;
+        const int tc = tiles_of(a, 256, 128), nk = a.K / BK, slots = 256;
+        const int full = (tc / slots) * slots, tail = tc - full;
+        int ksplit = tail > 0 ? slots / tail : 1;
+        if (ksplit > 8) ksplit = 8;
+        while (ksplit > 1 && nk / ksplit < (full ? 8 : 16)) --ksplit;
+        // Only the whole-problem case (fewer tiles than CUs) pays.  Slicing just the tail of a multi-round problem
+        // (546 tiles = 2.13 rounds: 512 whole tiles + 34 x 7 slices in the same launch) measured flat (331 vs 333 us on
+        // the LLaMA qkv prefill, ViT fc1 slightly worse): these kernels are bound by aggregate L2 bandwidth, not by
+        // rounds of workgroups -- a thin last round simply runs faster.  EMU_GEMM_SPLITK=2 enables the tail form (A/B).
+        const bool tail_ok = sk_env && atoi(sk_env) == 2 && tail * 2 <= slots && tc < 2048;
+        const bool want = ksplit > 1 && (full == 0 || tail_ok);
         const bool epi_ok = EPI != EPI_SWIGLU && EPI != EPI_GEGLU;
-        if (epi_ok && b.partial && ksplit > 1 && (a.N & 3) == 0 && (size_t)ksplit * a.M * a.N <= b.partial_floats &&
-            !(sk_env && atoi(sk_env) == 0)) {
-            launch_cfg<EPI, CONV, CfgC>(b, s, ksplit);
+        if (want && epi_ok && b.partial && (a.N & 3) == 0 &&
+            (size_t)tail * ksplit * (CfgC::BMv * CfgC::BNv) <= b.partial_floats && !(sk_env && atoi(sk_env) == 0)) {
+            launch_cfg<EPI, CONV, CfgC>(b, s, full, ksplit);
             return;
         }
         if (cfg == 'S') cfg = 0;

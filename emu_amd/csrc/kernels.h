@@ -49,9 +49,14 @@ struct GemmArgs {
     // launch sums them and applies the epilogue.  null = never split.
     float* partial = nullptr;
     size_t partial_floats = 0;
-    int ksplit = 1;         // set by launch_gemm
+    int ksplit = 1;         // set by launch_gemm: K-slices of the tail tiles
+    int full_tiles = 0;     // set by launch_gemm: tiles [0, full_tiles) run whole-K (workgroups [0, full_tiles)); every
+                            // later tile t is cut into ksplit slices (workgroup full_tiles + (t - full_tiles) * ksplit + ks)
+                            // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// scratch that always suffices: at most 256 slice tiles (one per CU) of 256 x 128 fp32
+constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)256 * 256 * 128;
 // process-wide default split-K scratch for callers that do not pass one (the C-ABI primitives); caller-owned memory
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
 

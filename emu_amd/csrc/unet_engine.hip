@@ -171,7 +171,7 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
     w.semb = (bf16_t*)take(Bn * c.temb_dim); w.temb_all = (bf16_t*)take((size_t)Bn * u->temb_total);
     w.add1 = (bf16_t*)take(Bn * c.temb_dim);
     w.gnws = (float*)take(gn_ws_floats(Bn, 2 * c.ch[2] > c.ch[1] + c.ch[0] ? 2 * c.ch[2] : c.ch[1] + c.ch[0], (int)hw[0]), 4);
-    w.splitk_floats = (size_t)4 * Bn * hw[2] * c.ch[2];
+    w.splitk_floats = EMU_SPLITK_SCRATCH_FLOATS;
     w.splitk = (float*)take(w.splitk_floats, 4);
     w.total = off;
     return w;

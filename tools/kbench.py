@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     a = ap.parse_args()
     cases = []
+    from emu_amd._lib import lib as _lib
+    _sk = torch.zeros(256 * 256 * 128, dtype=torch.float32, device="cuda")      # split-K scratch, as the engines carry
+    if not os.environ.get("EMU_KBENCH_NO_SCRATCH"):
+        _lib().emu_set_splitk_scratch(_sk.data_ptr(), _sk.numel() * 4)
 
     def gemv(name, M, N, K, epi=0, norm=False):
         # rotate over several weight copies so the 256 MB infinity cache cannot serve the "stream"
