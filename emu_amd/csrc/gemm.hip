@@ -270,17 +270,25 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
 // Tile configuration: WN x WM waves, each owning NF x MF 32x32 accumulators; NSTG-deep LDS ring of 64-wide k tiles.
 // KG > 1: KG groups of WN x WM waves split the four 16-wide k-steps of every tile between them (intra-workgroup split-K:
 // twice the waves per SIMD for the same tile, partial accumulators summed through LDS in the epilogue).
-template <int WN_, int WM_, int NF_, int MF_, int NSTG_, int KG_ = 1>
+template <int WN_, int WM_, int NF_, int MF_, int NSTG_, int KG_ = 1, int BK_ = 64>
 struct TileCfg {
-    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_, KG = KG_;
+    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_, KG = KG_, BKv = BK_;
     static constexpr int THREADS = WN * WM * KG * 64;
     static_assert(KG == 1 || KG == 2, "k-groups: 1 or 2");
+    static_assert(BKv == 64 || BKv == 32, "k tile: 64 (128-byte LDS rows) or 32 (64-byte rows, twice the ring depth)");
     static constexpr int BNv = WN * NF * 32, BMv = WM * MF * 32;
-    static constexpr int W_BYTES = BNv * 128, A_BYTES = BMv * 128, ST_BYTES = W_BYTES + A_BYTES;
-    static constexpr int NLW = (BNv * 8) / THREADS, NLA = (BMv * 8) / THREADS, LPT = NLW + NLA;   // LDS-DMA per thread per tile
-    static_assert((BNv * 8) % THREADS == 0 && (BMv * 8) % THREADS == 0, "tile rows must split evenly over the waves");
+    static constexpr int ROWB = BKv * 2;                                      // bytes per LDS row
+    static constexpr int SLOTS = ROWB / 16;                                   // 16-byte slots per row: 8 or 4
+    static constexpr int RPI = 64 / SLOTS;                                    // rows one wave LDS-DMA instruction fills: 8 or 16
+    static constexpr int W_BYTES = BNv * ROWB, A_BYTES = BMv * ROWB, ST_BYTES = W_BYTES + A_BYTES;
+    static constexpr int NLW = (BNv * SLOTS) / THREADS, NLA = (BMv * SLOTS) / THREADS, LPT = NLW + NLA;   // LDS-DMA per thread per tile
+    static_assert((BNv * SLOTS) % THREADS == 0 && (BMv * SLOTS) % THREADS == 0, "tile rows must split evenly over the waves");
     static_assert(NSTG * ST_BYTES <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static_assert((NSTG - 2) * LPT <= 63, "vmcnt field is 6 bits");
+    // conflict-free ds_read_b128 of MFMA fragments: 128-byte rows XOR the slot with (row >> 1) & 7, 64-byte rows with
+    // (row >> 2) & 3 (16 consecutive rows then cover all 64 banks exactly once)
+    __device__ static __forceinline__ int swz(int row) { return SLOTS == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+    __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
 };
 
 template <int EPI, bool CONV, class T>
@@ -320,13 +328,13 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     int pb[T::NLA], py[T::NLA], px[T::NLA], ac[T::NLA];
 #pragma unroll
     for (int i = 0; i < T::NLW; ++i) {
-        const int r = (i * NW + wave) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (i * NW + wave) * T::RPI + lane / T::SLOTS, c = (lane % T::SLOTS) ^ T::swz(r);
         int gn = n0 + r; gn = gn < a.N ? gn : a.N - 1;
         gW[i] = a.W + (size_t)gn * a.ldw + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < T::NLA; ++i) {
-        const int r = (i * NW + wave) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (i * NW + wave) * T::RPI + lane / T::SLOTS, c = (lane % T::SLOTS) ^ T::swz(r);
         int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
         gA[i] = a.A + (size_t)gm * a.lda + c * 8;
         ac[i] = c * 8;
@@ -339,12 +347,12 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
         }
     }
     // split-K: this workgroup owns K-tiles [kt0, kt0 + nk) of slice blockIdx.y
-    const int nk_all = a.K / BK;
+    const int nk_all = a.K / T::BKv;
     const int kt0 = (int)((long)ks * nk_all / nsl);
     const int nk = (int)((long)(ks + 1) * nk_all / nsl) - kt0;
     auto issue = [&](int kt, int stage) {
         kt = kt < nk ? kt : nk - 1;                    // past-the-end tiles re-load the last one (keeps vmcnt counts uniform)
-        const int k0 = (kt0 + kt) * BK;
+        const int k0 = (kt0 + kt) * T::BKv;
         char* base = smem + stage * T::ST_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
@@ -398,12 +406,12 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
             const int ch = kk * 2 + hi;
 #pragma unroll
             for (int i = 0; i < T::NF; ++i)
-                wf[buf][i] = *reinterpret_cast<const bf16x8_t*>(sW + lds_off((wn * T::NF + i) * 32 + l31, ch));
+                wf[buf][i] = *reinterpret_cast<const bf16x8_t*>(sW + T::off((wn * T::NF + i) * 32 + l31, ch));
 #pragma unroll
             for (int j = 0; j < T::MF; ++j)
-                af[buf][j] = *reinterpret_cast<const bf16x8_t*>(sA + lds_off((wm * T::MF + j) * 32 + l31, ch));
+                af[buf][j] = *reinterpret_cast<const bf16x8_t*>(sA + T::off((wm * T::MF + j) * 32 + l31, ch));
         };
-        constexpr int KSTEPS = 4 / T::KG;              // k-steps of this wave's k-group
+        constexpr int KSTEPS = (T::BKv / 16) / T::KG;  // k-steps of this wave's k-group
         const int kk0 = kg * KSTEPS;
         frags(kk0, 0);
 #pragma unroll
@@ -478,6 +486,9 @@ using CfgI = TileCfg<2, 2, 2, 1, 6>;     // 128(n) x 64(m), 4 waves, 6 stages (1
 using CfgJ = TileCfg<2, 2, 2, 2, 4>;     // 128 x 128, 4 waves, 4 stages (128 KiB): 3 tiles (96 KiB) in flight per CU
 using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves, 3 stages (72 KiB, 2 workgroups per CU)
 using CfgL = TileCfg<2, 2, 2, 2, 2, 2>;  // 128 x 128, 2 k-groups x 4 waves, 2 stages (64 KiB, 2 workgroups per CU)
+// 32-wide k tiles (BK_ = 32: 64-byte LDS rows, twice the ring depth) measured (profiles/r01_gemm_tilecfg_sweep_bk32.log):
+// 256 x 256 x 32, 4 stages: 887 TF/s at M = 1544 (C: 842) but 25 % row padding at M = 770 / 1025 makes it lose there;
+// 256 x 128 x 32 with 6 stages: below C everywhere.  Not dispatched.
 // measured and dropped (profiles/r01_gemm_tilecfg_sweep_MN.log): 4 waves of 128(n) x 64(m) on a 256 x 128 tile
 // (0.75 KB of LDS reads per MFMA instead of 1 KB): -5 % vs C; 4 waves of 128 x 128 on 256 x 256 (AGPR accumulators): -40 %
 
