@@ -114,7 +114,10 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(1.0f - p * e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x) on the hardware exp2 / rcp (1 ulp each; every use is followed by a bf16 rounding)
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // streaming (read-once) 16-byte load: weights are touched once per token, keep them out of L2
 __device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_nontemporal_load(p); }
