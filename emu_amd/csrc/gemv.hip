@@ -1,14 +1,20 @@
-// Decode-shape (M <= 8 rows) weight-streaming GEMV:  out[m, n] = epilogue( sum_k xeff[m, k] * W[n, k] )
+// Decode-shape (M <= 16 rows) weight streams:  out[m, n] = epilogue( sum_k xeff[m, k] * W[n, k] )
 //
-// HBM-bound: every weight byte is read exactly once per call with non-temporal 16-byte loads; x (a few
-// KB) is re-read from L1/L2.  One 256-thread workgroup owns R consecutive weight rows and splits K across
-// its 4 waves (thread t owns 16-byte vectors t, t+256, ...), so N/R workgroups (>> 256 CUs) stream
-// concurrently.  Optional fused prologue: LLaMA RMSNorm of x (fp32 variance, bf16 rounding points of the
-// reference kept: xeff = bf16(g * bf16(x * rsqrt(mean(x^2)+eps)))).  Fused epilogues: bias, residual add,
-// SwiGLU over interleaved (gate, up) row pairs.
+// HBM-bound: every weight byte is read exactly once per call (PMC: traffic / algorithmic = 1.0013) with non-temporal
+// loads; the activations (a few KB) come from L1/L2.  The family, dispatched by launch_gemv():
+//   gemv_kernel      1..8 rows.  One 256-thread workgroup owns R (16/8/4/2) consecutive weight rows and splits K across its
+//                    4 waves (thread t owns 16-byte vectors t, t+256, ...), N/R workgroups >> 256 CUs.  Inner product on
+//                    v_dot2c_f32_bf16 (weights consumed unpacked), wave reductions on DPP.  Optional fused prologue: LLaMA
+//                    RMSNorm of x (fp32 variance, the reference's bf16 rounding points: xeff = bf16(g * bf16(x * rinv))).
+//                    Fused epilogues: bias, residual add, SwiGLU over interleaved (gate, up) row pairs, SiLU, GELU.
+//   gemv_rt_kernel   M = 1, single HBM round trip per workgroup (all loads issued up front): down_proj, small shards.
+//   gemv_mfma_kernel 9..16 rows on v_mfma_f32_16x16x32_bf16.
+//   gemv_fp8_*       optional e4m3 weight stream (per-row scale).
+//   gemv_stream_kernel  LDS-DMA loader/consumer engine, opt-in (measured no faster).
 //
 // Replaces (reference call sites): LlamaDecoderLayer linears + RMSNorm reached from Emu2/emu/emu.py:133-138
-// and :213-229 at S=1, project_up/project_down emu.py:131,147.  Algorithmic bytes per call = 2*N*K.
+// and :213-229 at S=1 (greedy: 1 row; beam search: num_beams rows), project_up/project_down emu.py:131,147.
+// Algorithmic bytes per call = 2*N*K (fp8: N*K).
 #include <cstdlib>
 
 #include "common.h"
