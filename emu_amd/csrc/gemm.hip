@@ -551,7 +551,9 @@ void launch_v2(const GemmArgs& a, hipStream_t s) {
         const int full = (tc / slots) * slots, tail = tc - full;
         int ksplit = tail > 0 ? slots / tail : 1;
         if (ksplit > 8) ksplit = 8;
-        while (ksplit > 1 && nk / ksplit < (full ? 8 : 16)) --ksplit;
+        static const char* mk_env = getenv("EMU_GEMM_SPLITK_MINK");     // A/B: minimum K-tiles per slice
+        const int min_k = mk_env ? atoi(mk_env) : (full ? 8 : 16);
+        while (ksplit > 1 && nk / ksplit < min_k) --ksplit;
         // Only the whole-problem case (fewer tiles than CUs) pays.  Slicing just the tail of a multi-round problem
         // (546 tiles = 2.13 rounds: 512 whole tiles + 34 x 7 slices in the same launch) measured flat (331 vs 333 us on
         // the LLaMA qkv prefill, ViT fc1 slightly worse): these kernels are bound by aggregate L2 bandwidth, not by
