@@ -114,6 +114,9 @@ def main():
     gemv("tp8 gateup", 1, 4480, 6656, 2, True)
     gemv("tp8 down", 1, 6656, 2240, 1)
     # ---- prefill S=770 / ViT N=1025 / UNet
+    gemm("short-prompt qkv", 40, 19968, 6656)
+    gemm("short-prompt gateup", 40, 35840, 6656, 2)
+    gemm("short-prompt down", 40, 6656, 17920, 1)
     gemm("prefill qkv", 770, 19968, 6656)
     gemm("prefill o", 770, 6656, 6656, 1)
     gemm("prefill gateup", 770, 35840, 6656, 2)
