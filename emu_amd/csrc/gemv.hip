@@ -8,6 +8,7 @@
 //                    RMSNorm of x (fp32 variance, the reference's bf16 rounding points: xeff = bf16(g * bf16(x * rinv))).
 //                    Fused epilogues: bias, residual add, SwiGLU over interleaved (gate, up) row pairs, SiLU, GELU.
 //   gemv_rt_kernel   M = 1, single HBM round trip per workgroup (all loads issued up front): down_proj, small shards.
+//   gemv_wave_kernel M = 1, K <= 2560: one wave per 4 whole rows, no LDS / barrier (TP-shard o_proj / down_proj).
 //   gemv_mfma_kernel 9..16 rows on v_mfma_f32_16x16x32_bf16.
 //   gemv_fp8_*       optional e4m3 weight stream (per-row scale).
 //   gemv_stream_kernel  LDS-DMA loader/consumer engine, opt-in (measured no faster).
@@ -352,6 +353,84 @@ int launch_rt(const GemvArgs& a, hipStream_t s) {
 #undef EMU_RT_CASE
     EMU_CHECK_LAUNCH();
     return 0;
+}
+
+// Short rows (K <= 2560: the o_proj / down_proj of a tensor-parallel shard, K = 896 / 2240 at TP = 8): splitting such
+// a row over 256 threads leaves most lanes idle and pays two barriers for a cross-wave sum.  Here every wave owns RW whole
+// rows -- all loads up front, v_dot2c, one DPP wave reduction, lane 0 stores -- no LDS, no barrier: the launch is pure
+// latency, so the shortest dependency chain wins.
+template <int RW, int KITW, int EPI>
+__global__ __launch_bounds__(256) void gemv_wave_kernel(const GemvArgs a) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int KV = a.K >> 3;
+    const int n0 = (blockIdx.x * 4 + wave) * RW;
+    u32x4 xv[KITW], wv[KITW][RW];
+#pragma unroll
+    for (int it = 0; it < KITW; ++it) {
+        const int vi = lane + 64 * it;
+        const int vc = vi < KV ? vi : KV - 1;                         // clamped; the activation is zeroed instead
+        xv[it] = vi < KV ? ld16(a.x + vi * 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            int n = n0 + r;
+            n = n < a.N ? n : a.N - 1;
+            wv[it][r] = ld_stream(reinterpret_cast<const u32x4*>(a.W + (size_t)n * a.ldw + vc * 8));
+        }
+    }
+    float acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < KITW; ++it)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            float t = acc[r];
+            t = bf16_dot2(wv[it][r].x, xv[it].x, t);
+            t = bf16_dot2(wv[it][r].y, xv[it].y, t);
+            t = bf16_dot2(wv[it][r].z, xv[it].z, t);
+            t = bf16_dot2(wv[it][r].w, xv[it].w, t);
+            acc[r] = t;
+        }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int n = n0 + r;
+            if (n < a.N) {
+                float v = acc[r];
+                if (a.bias) v += bf2f(a.bias[n]);
+                v = bfround(v);
+                if constexpr (EPI == EPI_RESID) v = v + bf2f(a.res[n]);
+                a.out[n] = f2bf(v);
+            }
+        }
+    }
+}
+
+template <int RW, int KITW>
+int launch_wave(const GemvArgs& a, hipStream_t s) {
+    const dim3 grid((a.N + 4 * RW - 1) / (4 * RW)), block(256);
+    if (a.epi == EPI_RESID) hipLaunchKernelGGL((gemv_wave_kernel<RW, KITW, EPI_RESID>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemv_wave_kernel<RW, KITW, EPI_NONE>), grid, block, 0, s, a);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+// returns 1 when the shape is not covered
+int try_launch_wave(const GemvArgs& a, hipStream_t s) {
+    static const char* env = getenv("EMU_GEMV_WAVE");                  // A/B: 0 disables
+    if (env && atoi(env) == 0) return 1;
+    if (a.M != 1 || a.norm_w || a.wscale || (a.epi != EPI_NONE && a.epi != EPI_RESID)) return 1;
+    const int kitw = ((a.K >> 3) + 63) / 64;
+    if (kitw > 5 || a.N < 1024) return 1;                            // K <= 2560; tiny N stays on the block kernels
+    switch (kitw) {
+        case 1: return launch_wave<4, 1>(a, s);
+        case 2: return launch_wave<4, 2>(a, s);
+        case 3: return launch_wave<4, 3>(a, s);
+        case 4: return launch_wave<4, 4>(a, s);
+        default: return launch_wave<4, 5>(a, s);
+    }
 }
 
 // M = 1 dispatch onto the single-round-trip kernel; returns 1 when the shape is not covered.
@@ -1214,6 +1293,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
         return launch_gemv_mfma(a, s);
     if (a.M > 8) return -22;
     if (a.wscale && ((a.K & 15) || a.M > 2)) return -22;
+    { const int st = try_launch_wave(a, s); if (st != 1) return st; }
     { const int st = try_launch_rt(a, s); if (st != 1) return st; }
     if (a.wscale) {                                  // fp8 weight stream (decode, batch <= 2 built)
         // 16 weights per 16-byte load: K = 6656 is only 416 groups, so short rows run 2-wave blocks (3.25 trips per

@@ -98,6 +98,20 @@ def test_skinny_mfma_identity_asymmetric():
     assert float(out[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,K", [(6656, 896), (2050, 2240), (1030, 64), (4099, 2560), (1024, 520)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemv_short_rows_wave_kernel(N, K, epi):
+    """Short rows (K <= 2560, e.g. the o_proj / down_proj of a TP = 8 shard): one wave per 4 rows, no LDS; ragged N, K not a
+    multiple of 512 (partially filled last load), bias, residual."""
+    ops = _ops()
+    x, w = rnd(1, K, seed=51), rnd(N, K, seed=52, scale=0.05)
+    bias = rnd(N, seed=53) if epi == 0 else None
+    res = rnd(1, N, seed=54) if epi == 1 else None
+    got = ops.linear(x.cuda(), w.cuda(), bias=None if bias is None else bias.cuda(),
+                     res=None if res is None else res.cuda(), epi=epi)
+    close(got, ref_linear(x, w, bias, res, epi=epi), what=f"wave gemv N{N} K{K} epi{epi}")
+
+
 @pytest.mark.parametrize("M", [1, 4])
 @pytest.mark.parametrize("epi", [0, 2])
 def test_gemv_fused_rmsnorm(M, epi):
