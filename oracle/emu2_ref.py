@@ -396,13 +396,18 @@ def scatter_image_embeds(text_embeds: Tensor, input_ids: Tensor, image_embeds: T
 
 def emu_generate(input_ids: Tensor, attention_mask: Tensor, image: Optional[Tensor], W: Weights,
                  cfg: EmuCfg, max_new_tokens: int, min_len: int = 1, n_query: Optional[int] = None,
-                 return_margins: bool = False, num_beams: int = 1):
-    """EmuModel.generate at the token-id level (greedy or beam search), Emu2/emu/emu.py:184-229."""
+                 return_margins: bool = False, num_beams: int = 1, video: Optional[Tensor] = None):
+    """EmuModel.generate at the token-id level (greedy or beam search), Emu2/emu/emu.py:184-229; video frames are
+    encoded with v_query tokens each and land on the [gIMG] slots (:205-211)."""
     x = embed_tokens(input_ids, W)
     if image is not None:
         e = encode_image(image, W, cfg, n_query)
         e = F.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"])
         x = scatter_image_embeds(x, input_ids, e)
+    if video is not None:
+        e = encode_image(video, W, cfg, cfg.v_query)
+        e = F.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"])
+        x = scatter_image_embeds(x, input_ids, e, token_id=GIMG_ID)
     if num_beams > 1:
         return beam_search_generate(x, attention_mask, W, cfg.llama, num_beams, max_new_tokens, min_len,
                                     return_margin=return_margins)

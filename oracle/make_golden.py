@@ -77,8 +77,8 @@ def main():
     text1 = ["[<IMG_PLH>]describe the image in detail:"]
     text2 = ["a photo of", "an image of a very large dog that"]
 
-    def run_generate(text, image, n_new, num_beams=1):
-        exp = [x.replace("[<IMG_PLH>]", m.image_placeholder) for x in text]
+    def run_generate(text, image, n_new, num_beams=1, video=None):
+        exp = [x.replace("[<IMG_PLH>]", m.image_placeholder).replace("[<VID_PLH>]", m.video_placeholder) for x in text]
         enc_ = tok(exp, padding="longest", return_tensors="pt")
         # the reference returns decoded strings; capture ids by calling lm.generate the same way
         # (emu.py:184-229) through a thin hook on batch_decode
@@ -91,7 +91,7 @@ def main():
         tok.batch_decode = hook
         try:
             with torch.no_grad():
-                strs = m.generate(text=text, image=image, num_beams=num_beams, max_new_tokens=n_new)
+                strs = m.generate(text=text, image=image, video=video, num_beams=num_beams, max_new_tokens=n_new)
         finally:
             tok.batch_decode = orig
         return enc_.input_ids, enc_.attention_mask, captured["ids"], strs
@@ -115,6 +115,18 @@ def main():
     print("beam B=2:", beam2.tolist(), sb2)
     print("generate B=1:", new1.tolist(), s1)
     print("generate B=2:", new2.tolist(), s2)
+
+    # --- 3b. video frames ([gIMG] slots, v_query tokens per frame, emu.py:205-211): frames only, and an image + frames
+    vid = torch.randn(2, 3, v.image_size, v.image_size, generator=torch.Generator().manual_seed(303))
+    text4 = ["[<VID_PLH>][<VID_PLH>]what happens next?"]
+    text5 = ["[<IMG_PLH>]and then[<VID_PLH>][<VID_PLH>]compare them:"]
+    ids4, am4, new4, s4 = run_generate(text4, None, 6, video=vid)
+    ids5, am5, new5, s5 = run_generate(text5, img1, 6, video=vid)
+    np.savez(os.path.join(OUT, "generate_video_tiny.npz"), image=img1.numpy(), video=vid.numpy(),
+             ids4=ids4.numpy(), mask4=am4.numpy(), new4=new4.numpy(),
+             ids5=ids5.numpy(), mask5=am5.numpy(), new5=new5.numpy(), **meta)
+    print("generate video:", new4.tolist(), s4)
+    print("generate image+video:", new5.tolist(), s5)
 
     # --- 4. EmuModel.generate_image (emu.py:92-153), text-only and with an image prompt
     with torch.no_grad():

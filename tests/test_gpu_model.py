@@ -88,6 +88,26 @@ def test_generate_greedy_token_exact(tiny_model, golden_dir):
     assert new2.cpu().tolist() == z["new2"].tolist()
 
 
+def test_generate_video_frames_follow_reference(tiny_model, golden_dir):
+    """Video frames (v_query tokens per frame on the [gIMG] slots), alone and mixed with an image: ids of the REAL reference
+    (golden), followed up to the oracle's first near-tie of the top-2 logits."""
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_video_tiny.npz")
+    vid = _t(z["video"]).cuda()
+    for ids_k, mask_k, new_k, img in (("ids4", "mask4", "new4", None), ("ids5", "mask5", "new5", _t(z["image"]))):
+        got = m.generate_ids(_t(z[ids_k]), _t(z[mask_k]), None if img is None else img.cuda(), video=vid,
+                             max_new_tokens=6).cpu()
+        want = _t(z[new_k])
+        _, margins = R.emu_generate(_t(z[ids_k]), _t(z[mask_k]), img, R.bf16_round(W), cfg, max_new_tokens=6,
+                                    return_margins=True, video=_t(z["video"]))
+        for i in range(min(got.shape[1], want.shape[1])):
+            if got[:, i].tolist() != want[:, i].tolist():
+                assert float(margins[:, i].min()) < 0.08, f"{new_k}: diverged at step {i}, margin {margins[:, i].min():.3f}"
+                break
+        assert got[:, 0].tolist() == want[:, 0].tolist() or float(margins[:, 0].min()) < 0.08
+
+
 def test_generate_beam_search(tiny_model, golden_dir):
     """Beam search on the GPU engine (KV cache replicated per beam, re-ordered per step, M = B*beams rows per step).
     * ids equal the REAL reference's on the fixture whose pruning margins are >= 0.08 nat (3 beams, 6 tokens);

@@ -52,6 +52,20 @@ def test_generate_greedy_token_exact(golden_dir):
     assert float(m1.min()) > 0.05 and float(m2.min()) > 0.05, (m1, m2)
 
 
+def test_generate_video_token_exact(golden_dir):
+    """Video frames ([gIMG] slots, v_query tokens per frame) alone and mixed with an image: ids of the real reference."""
+    z = tiny.load(golden_dir, "generate_video_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    new4, m4 = R.emu_generate(_t(z["ids4"]), _t(z["mask4"]), None, W, cfg, max_new_tokens=6, return_margins=True,
+                              video=_t(z["video"]))
+    assert new4.tolist() == z["new4"].tolist()
+    new5, m5 = R.emu_generate(_t(z["ids5"]), _t(z["mask5"]), _t(z["image"]), W, cfg, max_new_tokens=6,
+                              return_margins=True, video=_t(z["video"]))
+    assert new5.tolist() == z["new5"].tolist()
+    print("video margins", m4.tolist(), m5.tolist())
+
+
 def test_generate_beam_search_token_exact(golden_dir):
     """The reference's default decoding (num_beams=5, max_new_tokens=10, length_penalty=-1): ids of the real reference."""
     z = tiny.load(golden_dir, "generate_tiny.npz")
