@@ -1,8 +1,11 @@
 """CPU restatement of the Emu1 caption path (BASELINE.json configs[0])  -- TEST INFRASTRUCTURE ONLY.
 
-**PARITY UNPINNED.**  ``Emu1/models`` cannot be imported here (needs timm, xformers, peft, a network fetch of the
-``t5-base`` config, and symbols removed from transformers 5.x), and the reference ships no fixtures for it.
-This file restates the algorithm from the reference sources:
+**Parity pinned for the vision side**: EVA-CLIP-g ``forward_features`` -> ``ln_visual`` -> ``CausalFormer`` reproduce outputs of
+the REAL ``Emu1/models`` modules (imported on CPU by oracle/make_golden_emu1.py behind import shims for timm / peft and
+two symbols newer transformers dropped; ``T5Config.from_pretrained("t5-base")`` answered offline with a t5-base-kind config
+at tiny width) to fp32 round-off: tests/golden/emu1_tiny.npz, tests/test_oracle_golden.py.  ``Emu.generate`` itself is
+restated from source (its LLaMA wrapper needs the 13B tokenizer directory): the id-level scatter + the LLaMA arithmetic of
+oracle/emu2_ref.py (pinned there) -- **that last step is unpinned**.  Sources:
 
 * ``Emu.generate``                 Emu1/models/modeling_emu.py:100-185  (ViT-g -> ln_visual -> CausalFormer -> scatter at
                                    the 32 <image> slots -> LLaMA generate, default num_beams=5, length_penalty=0)

@@ -1,0 +1,154 @@
+"""Freeze outputs of the REAL Emu1 reference modules into tests/golden/emu1_tiny.npz  -- TEST INFRASTRUCTURE ONLY.
+
+Run in the build container:  python -m oracle.make_golden_emu1
+
+``/root/reference/Emu1/models`` is imported on CPU with four small shims (nothing of the model arithmetic is touched):
+``timm.models.layers`` (three helpers eva_vit_model.py:11 imports), two head-pruning symbols that newer transformers
+removed from ``transformers.pytorch_utils`` and ``transformers.utils.model_parallel_utils`` (modeling_t5.py:37-51, unused
+in a forward), ``peft`` (prediction_mixin.py:1), and ``T5Config.from_pretrained("t5-base")`` (causal_former.py:25, a
+network fetch) answered with a T5Config of the t5-base *kind* (relu FFN, 32 buckets, max distance 128, eps 1e-6, d_kv 64)
+at tiny width.  The EVA-CLIP-g tower (``_build_vision_tower``, Emu-14B.json flags, pre-norm) and ``CausalFormer`` are
+built at the tiny sizes of tests/test_gpu_emu1.py, loaded with ``emu_amd.synth`` weights under the reference's own
+parameter names (strict), and ``visual.forward_features`` / ``ln_visual`` / ``cformer`` outputs are stored in fp32.
+The fixture pins oracle/emu1_ref.py (tests/test_oracle_golden.py) and the HIP engines (tests/test_gpu_emu1.py).
+"""
+import importlib.machinery
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emu_amd import synth  # noqa: E402
+from emu_amd.emu1 import T5DecoderCfg, cformer_param_shapes, emu1_vision_cfg  # noqa: E402
+
+REF = "/root/reference/Emu1"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+TINY = dict(image_size=56, width=176, layers=2, head_width=88, mlp_ratio=2.0, d_model=128, t5_layers=2, t5_heads=2,
+            d_ff=256, n_causal=8, out_dim=256, seed=4)
+
+
+def install_shims(t5_kwargs):
+    import transformers  # noqa: F401
+    import transformers.pytorch_utils as pu
+    from transformers.models.t5.configuration_t5 import T5Config
+
+    def _unused(*a, **k):
+        raise NotImplementedError("head pruning is not part of the forward pass")
+    for name in ("find_pruneable_heads_and_indices", "prune_linear_layer"):
+        if not hasattr(pu, name):
+            setattr(pu, name, _unused)
+    try:
+        import transformers.utils.model_parallel_utils  # noqa: F401
+    except Exception:
+        m = types.ModuleType("transformers.utils.model_parallel_utils")
+        m.assert_device_map = lambda *a, **k: None
+        m.get_device_map = lambda *a, **k: None
+        sys.modules["transformers.utils.model_parallel_utils"] = m
+    if "timm" not in sys.modules or not hasattr(sys.modules.get("timm.models.layers", None), "trunc_normal_"):
+        timm = types.ModuleType("timm")
+        timm.__spec__ = importlib.machinery.ModuleSpec("timm", None)
+        tm, tl, tl2 = types.ModuleType("timm.models"), types.ModuleType("timm.models.layers"), types.ModuleType("timm.layers")
+        for mod in (tl, tl2):
+            mod.to_2tuple = lambda x: x if isinstance(x, tuple) else (x, x)
+            mod.drop_path = lambda x, p=0.0, training=False: x
+            mod.trunc_normal_ = lambda t, std=1.0, **k: torch.nn.init.trunc_normal_(t, std=std)
+        sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl, "timm.layers": tl2})
+    try:
+        import peft  # noqa: F401
+    except Exception:
+        pf = types.ModuleType("peft")
+        pf.PeftModel = type("PeftModel", (), {})
+        sys.modules["peft"] = pf
+    # causal_former.py:25 fetches the t5-base config from the hub; answer with the same KIND of config at tiny width
+    def _t5_base_kind(cls, *a, **k):
+        cfg = T5Config(**t5_kwargs)
+        # generic PretrainedConfig defaults that transformers 4.31 (the reference's pin) provided and newer releases dropped
+        for name, val in (("add_cross_attention", False), ("is_decoder", False), ("use_cache", True),
+                          ("output_attentions", False), ("output_hidden_states", False), ("use_return_dict", True),
+                          ("tie_word_embeddings", True), ("chunk_size_feed_forward", 0), ("pruned_heads", {}),
+                          ("torchscript", False)):
+            try:
+                getattr(cfg, name)
+            except AttributeError:
+                setattr(cfg, name, val)
+        return cfg
+    T5Config.from_pretrained = classmethod(_t5_base_kind)
+    # ModuleUtilsMixin.get_head_mask (transformers 4.31) -- with head_mask=None it is just a list of Nones
+    from transformers.modeling_utils import PreTrainedModel
+    if not hasattr(PreTrainedModel, "get_head_mask"):
+        def get_head_mask(self, head_mask, num_hidden_layers, is_attention_chunked=False):
+            if head_mask is not None:
+                raise NotImplementedError("head masks are not used by the caption path")
+            return [None] * num_hidden_layers
+        PreTrainedModel.get_head_mask = get_head_mask
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def main():
+    t = TINY
+    t5_kwargs = dict(d_model=t["d_model"], d_kv=64, d_ff=t["d_ff"], num_layers=t["t5_layers"],
+                     num_decoder_layers=t["t5_layers"], num_heads=t["t5_heads"], relative_attention_num_buckets=32,
+                     relative_attention_max_distance=128, dropout_rate=0.0, layer_norm_epsilon=1e-6,
+                     feed_forward_proj="relu", vocab_size=32128)
+    install_shims(t5_kwargs)
+    from models.causal_former import CausalFormer
+    from models.model import CLIPVisionCfg as RefVisionCfg, _build_vision_tower
+    from models.transformer import LayerNorm
+
+    ref_json = json.load(open(os.path.join(REF, "models", "Emu-14B.json")))
+    vkw = dict(ref_json["vision_cfg"])
+    vkw.update(image_size=t["image_size"], width=t["width"], layers=t["layers"], head_width=t["head_width"],
+               mlp_ratio=t["mlp_ratio"], xattn=False)                 # xattn = xformers kernels; same math without them
+    visual = _build_vision_tower(embed_dim=ref_json["embed_dim"], vision_cfg=RefVisionCfg(**vkw)).eval().float()
+    ln_visual = LayerNorm(t["width"], eps=1e-6).eval().float()
+    cformer = CausalFormer(args=None, n_causal=t["n_causal"], vision_width=t["width"], output_dim=t["out_dim"]).eval().float()
+
+    # product-side names/shapes for the same modules (emu_amd/emu1.py, emu_amd/synth.py)
+    v = emu1_vision_cfg(image_size=t["image_size"], width=t["width"], layers=t["layers"], head_width=t["head_width"],
+                        mlp_ratio=t["mlp_ratio"])
+    t5 = T5DecoderCfg(d_model=t["d_model"], num_layers=t["t5_layers"], num_heads=t["t5_heads"], d_ff=t["d_ff"],
+                      n_causal=t["n_causal"])
+    shapes = synth.vit_param_shapes(v)
+    shapes["ln_visual.weight"] = (v.width,)
+    shapes["ln_visual.bias"] = (v.width,)
+    shapes.update(cformer_param_shapes(t5, v.width, t["out_dim"]))
+    W = synth.synth_state_dict(shapes, seed=t["seed"])
+
+    def load(module, prefix):
+        sd = module.state_dict()
+        mine = {k[len(prefix):]: val for k, val in W.items() if k.startswith(prefix)}
+        extra = sorted(set(mine) - set(sd))
+        assert not extra, f"{prefix}: product names unknown to the reference: {extra[:6]}"
+        for k in sd:
+            if k in mine:
+                assert tuple(sd[k].shape) == tuple(mine[k].shape), (prefix + k, tuple(sd[k].shape), tuple(mine[k].shape))
+        missing = sorted(k for k in sd if k not in mine)
+        module.load_state_dict({**{k: sd[k] for k in missing}, **mine}, strict=True)
+        return missing
+
+    miss_v = load(visual, "visual.")
+    load(ln_visual, "ln_visual.")
+    miss_c = load(cformer, "cformer.")
+    # parameters of the reference that the caption path never reads (classification head, final norm of the tower ...):
+    print("reference-only visual params (unused by forward_features):", miss_v)
+    print("reference-only cformer params:", miss_c)
+
+    image = torch.randn(2, 3, t["image_size"], t["image_size"], generator=torch.Generator().manual_seed(21))
+    with torch.no_grad():
+        feats = visual.forward_features(image)                       # modeling_emu.py:83 / :126
+        lnv = ln_visual(feats)
+        out = cformer(lnv)
+    meta = {"cfg_" + k: np.array(val) for k, val in t.items()}
+    os.makedirs(OUT, exist_ok=True)
+    np.savez(os.path.join(OUT, "emu1_tiny.npz"), image=image.numpy(), feats=feats.numpy(), ln_visual=lnv.numpy(),
+             cformer=out.numpy(), **meta)
+    print("feats", tuple(feats.shape), "cformer", tuple(out.shape), float(out.abs().mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,23 @@ def test_generate_video_token_exact(golden_dir):
     print("video margins", m4.tolist(), m5.tolist())
 
 
+def test_emu1_vit_g_and_causal_former_match_real_reference(golden_dir):
+    """Emu1 caption path up to the LLaMA input: EVA-CLIP-g forward_features (pre-norm) -> ln_visual -> CausalFormer (T5
+    decoder) against outputs of the REAL Emu1 modules (oracle/make_golden_emu1.py), fp32."""
+    from oracle import emu1_ref as E
+    z = tiny.load(golden_dir, "emu1_tiny.npz")
+    v, t5, out_dim, W, cfg = tiny.emu1_from(z)
+    img = _t(z["image"])
+    feats = E.vit_g_forward(img, W, cfg.vit)
+    assert feats.shape == tuple(z["feats"].shape)
+    assert float((feats - _t(z["feats"])).norm() / _t(z["feats"]).norm()) < 1e-5
+    lnv = torch.nn.functional.layer_norm(feats, (feats.shape[-1],), W["ln_visual.weight"], W["ln_visual.bias"], 1e-6)
+    assert float((lnv - _t(z["ln_visual"])).norm() / _t(z["ln_visual"]).norm()) < 1e-5
+    out = E.encode_image(img, W, cfg)
+    assert out.shape == tuple(z["cformer"].shape) == (2, 8, out_dim)
+    assert float((out - _t(z["cformer"])).norm() / _t(z["cformer"]).norm()) < 1e-5
+
+
 def test_generate_beam_search_token_exact(golden_dir):
     """The reference's default decoding (num_beams=5, max_new_tokens=10, length_penalty=-1): ids of the real reference."""
     z = tiny.load(golden_dir, "generate_tiny.npz")

@@ -38,3 +38,25 @@ def weights_from(z, dtype=torch.float32):
     v, l, vocab, seed, lmh = cfgs_from(z)
     W = synth.synth_state_dict(synth.emu_param_shapes(v, l, vocab), seed=seed, lm_head_scale=lmh)
     return v, l, vocab, {k: t.to(dtype) for k, t in W.items()}
+
+
+def emu1_from(z):
+    """Configs + synthetic weights of the Emu1 fixture (tests/golden/emu1_tiny.npz, oracle/make_golden_emu1.py)."""
+    from emu_amd.emu1 import T5DecoderCfg, cformer_param_shapes, emu1_vision_cfg
+    from oracle import emu1_ref as E
+    g = lambda k: z["cfg_" + k].item()
+    v = emu1_vision_cfg(image_size=g("image_size"), width=g("width"), layers=g("layers"), head_width=g("head_width"),
+                        mlp_ratio=g("mlp_ratio"))
+    t5 = T5DecoderCfg(d_model=g("d_model"), num_layers=g("t5_layers"), num_heads=g("t5_heads"), d_ff=g("d_ff"),
+                      n_causal=g("n_causal"))
+    shapes = synth.vit_param_shapes(v)
+    shapes["ln_visual.weight"] = (v.width,)
+    shapes["ln_visual.bias"] = (v.width,)
+    shapes.update(cformer_param_shapes(t5, v.width, g("out_dim")))
+    W = {k: t.float() for k, t in synth.synth_state_dict(shapes, seed=g("seed")).items()}
+    ocfg = E.Emu1Cfg(vit=R.VitCfg(image_size=g("image_size"), patch_size=14, width=g("width"), layers=g("layers"),
+                                  head_width=g("head_width"), mlp_hidden=v.mlp_hidden),
+                     t5=E.T5Cfg(d_model=g("d_model"), layers=g("t5_layers"), heads=g("t5_heads"), d_ff=g("d_ff"),
+                                n_causal=g("n_causal")),
+                     llama=R.LlamaCfg(hidden=g("out_dim"), heads=2, layers=1, ffn=64, vocab=64))
+    return v, t5, g("out_dim"), W, ocfg
