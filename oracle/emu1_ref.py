@@ -1,11 +1,12 @@
 """CPU restatement of the Emu1 caption path (BASELINE.json configs[0])  -- TEST INFRASTRUCTURE ONLY.
 
-**Parity pinned for the vision side**: EVA-CLIP-g ``forward_features`` -> ``ln_visual`` -> ``CausalFormer`` reproduce outputs of
-the REAL ``Emu1/models`` modules (imported on CPU by oracle/make_golden_emu1.py behind import shims for timm / peft and
-two symbols newer transformers dropped; ``T5Config.from_pretrained("t5-base")`` answered offline with a t5-base-kind config
-at tiny width) to fp32 round-off: tests/golden/emu1_tiny.npz, tests/test_oracle_golden.py.  ``Emu.generate`` itself is
-restated from source (its LLaMA wrapper needs the 13B tokenizer directory): the id-level scatter + the LLaMA arithmetic of
-oracle/emu2_ref.py (pinned there) -- **that last step is unpinned**.  Sources:
+**Parity pinned** against the REAL ``Emu1/models`` classes, imported on CPU by oracle/make_golden_emu1.py behind import shims
+(timm / peft stubs, two symbols and one mixin method newer transformers dropped, ``T5Config.from_pretrained("t5-base")``
+answered offline with a t5-base-kind config at tiny width, a temp ``./models/llama_config`` with the reference tokenizer):
+* EVA-CLIP-g ``forward_features`` -> ``ln_visual`` -> ``CausalFormer``: equal to fp32 round-off (tests/golden/emu1_tiny.npz);
+* ``Emu.generate`` of the real class run as inference.py runs it (whole model bf16): greedy ids and the default 5-beam
+  search (length_penalty 0) reproduced exactly, in fp32 and in bf16 arithmetic (tests/golden/emu1_generate_tiny.npz).
+Checked by tests/test_oracle_golden.py on any machine.  Sources restated:
 
 * ``Emu.generate``                 Emu1/models/modeling_emu.py:100-185  (ViT-g -> ln_visual -> CausalFormer -> scatter at
                                    the 32 <image> slots -> LLaMA generate, default num_beams=5, length_penalty=0)

@@ -148,6 +148,79 @@ def main():
     np.savez(os.path.join(OUT, "emu1_tiny.npz"), image=image.numpy(), feats=feats.numpy(), ln_visual=lnv.numpy(),
              cformer=out.numpy(), **meta)
     print("feats", tuple(feats.shape), "cformer", tuple(out.shape), float(out.abs().mean()))
+    generate_fixture(t, ref_json, vkw, W, image)
+
+
+def generate_fixture(t, ref_json, vkw, W_vis, image):
+    """Emu.generate (modeling_emu.py:100-185) of the REAL class at tiny sizes, exactly as inference.py drives it: whole
+    model in bf16, greedy and the default 5-beam search.  The LLaMA wrapper reads ./models/llama_config relative to the
+    working directory (modeling_llama.py:6,128), so a temp directory with the reference tokenizer files and a shrunken
+    config.json stands in for it."""
+    import argparse
+    import shutil
+    import tempfile
+    from emu_amd.emu1 import emu1_llama_cfg
+    from models.modeling_emu import Emu
+    lh, lf, lheads, ll = 256, 512, 2, 2
+    tmp = tempfile.mkdtemp(prefix="emu1_tiny_")
+    cfgdir = os.path.join(tmp, "models", "llama_config")
+    os.makedirs(cfgdir)
+    src = os.path.join(REF, "models", "llama_config")
+    for f in os.listdir(src):
+        if f != "config.json":
+            shutil.copy(os.path.join(src, f), cfgdir)
+    cfg = json.load(open(os.path.join(src, "config.json")))
+    cfg.update(hidden_size=lh, intermediate_size=lf, num_attention_heads=lheads, num_hidden_layers=ll)
+    json.dump(cfg, open(os.path.join(cfgdir, "config.json"), "w"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        args = argparse.Namespace(instruct=False, device=torch.device("cpu"))
+        mm = dict(ref_json["multimodal_cfg"]); mm["n_causal"] = t["n_causal"]
+        va = dict(ref_json["vladapter_cfg"]); va["n_causal"] = t["n_causal"]
+        emu = Emu(embed_dim=ref_json["embed_dim"], multimodal_cfg=mm, vision_cfg=vkw, vladapter_cfg=va,
+                  cast_dtype=torch.float, args=args).eval()
+    finally:
+        os.chdir(cwd)
+    emu.decoder.lm.config._attn_implementation = "eager"              # fp32-softmax eager attention = transformers 4.31
+    vocab = len(emu.decoder.tokenizer)
+    l = emu1_llama_cfg(hidden_size=lh, intermediate_size=lf, num_attention_heads=lheads, num_hidden_layers=ll)
+    W = dict(W_vis)
+    W.update(synth.synth_state_dict(synth.llama_param_shapes(l, vocab), seed=t["seed"], lm_head_scale=8.0))
+    sd = emu.state_dict()
+    extra = sorted(set(W) - set(sd))
+    assert not extra, f"product names unknown to the reference Emu: {extra[:6]}"
+    for k, val in W.items():
+        assert tuple(sd[k].shape) == tuple(val.shape), (k, tuple(sd[k].shape), tuple(val.shape))
+    print("reference-only Emu params:", sorted(k for k in sd if k not in W))
+    emu.load_state_dict({**sd, **W}, strict=True)
+    emu = emu.to(torch.bfloat16)                                      # inference.py runs the whole model in bf16
+    tok = emu.decoder.tokenizer
+    prompt = [emu.image_placeholder + "a photo of"]
+    captured = {}
+    orig = tok.batch_decode
+
+    def hook(ids, **kw):
+        captured["ids"] = ids.clone()
+        return orig(ids, **kw)
+    tok.batch_decode = hook
+    outs = {}
+    try:
+        for name, nb in (("greedy", 1), ("beam", 5)):
+            with torch.no_grad():
+                txt = emu.generate({"image": image[:1], "prompt": prompt}, num_beams=nb, max_new_tokens=6)
+            outs[name] = captured["ids"].numpy()
+            print(name, outs[name].tolist(), txt)
+    finally:
+        tok.batch_decode = orig
+    tok.padding_side = "left"
+    enc = tok(prompt, padding="longest", return_tensors="pt", add_special_tokens=True)
+    meta = {"cfg_" + k: np.array(val) for k, val in t.items()}
+    meta.update(cfg_vocab=np.array(vocab), cfg_lhidden=np.array(lh), cfg_lffn=np.array(lf), cfg_lheads=np.array(lheads),
+                cfg_llayers=np.array(ll))
+    np.savez(os.path.join(OUT, "emu1_generate_tiny.npz"), image=image[:1].numpy(), ids=enc.input_ids.numpy(),
+             mask=enc.attention_mask.numpy(), greedy=outs["greedy"], beam=outs["beam"], **meta)
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -80,6 +80,35 @@ def test_vit_g_and_causal_former_match_real_reference(golden_dir):
     assert rel_err(got, want) < 3e-2, rel_err(got, want)
 
 
+def test_emu1_generate_follows_real_reference(golden_dir):
+    """Emu.generate on the HIP engines against ids of the REAL Emu1 class (tests/golden/emu1_generate_tiny.npz): greedy
+    exact (the fixture's top-2 margins are > 0.06), default 5-beam search compared by sequence log-probability."""
+    from tests import tiny
+    from emu_amd.emu1 import Emu
+    from oracle import emu1_ref as E, emu2_ref as R
+    z = tiny.load(golden_dir, "emu1_generate_tiny.npz")
+    v, t5, l, vocab, W, cfg = tiny.emu1_generate_from(z)
+    m = Emu(v, l, t5, vocab=vocab, device="cuda")
+    m.load_state_dict(W, strict=True)
+    ids, mask, img = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]), torch.from_numpy(z["image"])
+    got = m.generate_ids(ids, mask, img.cuda(), num_beams=1, max_new_tokens=6)
+    assert got.cpu().tolist() == z["greedy"].tolist()
+    beam = m.generate_ids(ids, mask, img.cuda(), num_beams=5, max_new_tokens=6, length_penalty=0.0).cpu()
+    if beam.tolist() != z["beam"].tolist():                          # near-tie pruning under bf16: compare quality instead
+        Wb = R.bf16_round(W)
+
+        def seq_lp(seq):
+            x = R.embed_tokens(ids, Wb)
+            e = E.encode_image(img, Wb, cfg)
+            x = R.scatter_image_embeds(x, ids, e.reshape(-1, e.shape[-1]))
+            full = torch.cat([x, R.embed_tokens(seq[:, :-1], Wb)], dim=1)
+            am = torch.ones(1, full.shape[1], dtype=torch.long)
+            h = R.llama_model(full, am, Wb, cfg.llama)
+            lp = torch.log_softmax(torch.nn.functional.linear(h[:, ids.shape[1] - 1:], Wb["decoder.lm.lm_head.weight"]).float(), -1)
+            return float(lp[0, torch.arange(seq.shape[1]), seq[0]].sum())
+        assert seq_lp(beam) > seq_lp(torch.from_numpy(z["beam"])) - 0.15
+
+
 def test_emu1_generate_greedy_and_beam(tiny_emu1):
     """Emu.generate at the id level: greedy ids exact vs the oracle when its top-2 margins allow it; beam search (the
     reference default, 5 beams, length_penalty 0) returns a sequence of the right shape through the same engine path."""

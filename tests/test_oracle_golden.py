@@ -83,6 +83,22 @@ def test_emu1_vit_g_and_causal_former_match_real_reference(golden_dir):
     assert float((out - _t(z["cformer"])).norm() / _t(z["cformer"]).norm()) < 1e-5
 
 
+def test_emu1_generate_matches_real_reference(golden_dir):
+    """Emu.generate of the REAL Emu1 class (whole model in bf16, as inference.py runs it): greedy ids and the default
+    5-beam search (length_penalty 0), in fp32 and in bf16 arithmetic."""
+    from oracle import emu1_ref as E
+    z = tiny.load(golden_dir, "emu1_generate_tiny.npz")
+    v, t5, l, vocab, W, cfg = tiny.emu1_generate_from(z)
+    ids, mask, img = _t(z["ids"]), _t(z["mask"]), _t(z["image"])
+    for dt in (torch.float32, torch.bfloat16):
+        Wd = R.cast_weights(W, dt)
+        out, m = E.emu1_generate(ids, mask, img.to(dt), Wd, cfg, 6, num_beams=1, return_margins=True)
+        assert out.tolist() == z["greedy"].tolist()
+        assert float(m.min()) > 0.05, m
+        beam = E.emu1_generate(ids, mask, img.to(dt), Wd, cfg, 6, num_beams=5)
+        assert beam.tolist() == z["beam"].tolist()
+
+
 def test_generate_beam_search_token_exact(golden_dir):
     """The reference's default decoding (num_beams=5, max_new_tokens=10, length_penalty=-1): ids of the real reference."""
     z = tiny.load(golden_dir, "generate_tiny.npz")

@@ -60,3 +60,16 @@ def emu1_from(z):
                                 n_causal=g("n_causal")),
                      llama=R.LlamaCfg(hidden=g("out_dim"), heads=2, layers=1, ffn=64, vocab=64))
     return v, t5, g("out_dim"), W, ocfg
+
+
+def emu1_generate_from(z):
+    """Adds the tiny LLaMA of tests/golden/emu1_generate_tiny.npz to the Emu1 fixture weights."""
+    from emu_amd.emu1 import emu1_llama_cfg
+    g = lambda k: z["cfg_" + k].item()
+    v, t5, out_dim, W, ocfg = emu1_from(z)
+    l = emu1_llama_cfg(hidden_size=g("lhidden"), intermediate_size=g("lffn"), num_attention_heads=g("lheads"),
+                       num_hidden_layers=g("llayers"))
+    W.update({k: t.float() for k, t in synth.synth_state_dict(synth.llama_param_shapes(l, g("vocab")), seed=g("seed"),
+                                                             lm_head_scale=8.0).items()})
+    ocfg.llama = R.LlamaCfg(hidden=g("lhidden"), heads=g("lheads"), layers=g("llayers"), ffn=g("lffn"), vocab=g("vocab"))
+    return v, t5, l, g("vocab"), W, ocfg
