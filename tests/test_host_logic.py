@@ -142,3 +142,29 @@ def test_emu1_lora_merge_both_peft_layouts():
         merge_lora_state_dict({pre + "weight": W, pre + "lora_A.weight": A}, r=4, alpha=8.0)
     with pytest.raises(RuntimeError):
         merge_lora_state_dict({pre + "lora_A.weight": A, pre + "lora_B.weight": B}, r=4, alpha=8.0)
+
+
+def test_committed_bench_line_matches_the_contract():
+    """The bench line committed under profiles/ (the default `python bench.py` on an MI355X) carries every field of the
+    driver's contract, with the roofline / cpu_baseline objects and consistent arithmetic."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_bench_tp1_v*_full.json")),
+                   key=lambda p: int(os.path.basename(p).split("_v")[1].split("_")[0]))
+    assert files, "no committed full bench line"
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "tokens/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and d["config"]["valid"] is True and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is not None and 0.99 < r["traffic"] / r["bytes_per_launch"] < 1.05
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "tokens/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["denoise"]["roofline"]["bound"] == "mfma" and d["denoise"]["unit"] == "steps/s"
