@@ -343,26 +343,9 @@ class LlamaEngine:
         hid = torch.empty(B, H, device=dev, dtype=BF16)
         n = 0
         for step in range(max_new_tokens):
-            scores = self.logits(row).float()
-            if repetition_penalty != 1.0 and step > 0:
-                prev = out[:, :step]
-                g = torch.gather(scores, 1, prev)
-                g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
-                scores.scatter_(1, prev, g)
-            if step < min_len:
-                scores[:, eos_id] = -float("inf")
+            scores = process_logits(self.logits(row).float(), out[:, :step], step < min_len, eos_id, do_sample, temperature,
+                                    top_k, top_p, repetition_penalty)
             if do_sample:
-                if temperature is not None and temperature != 1.0:
-                    scores = scores / temperature
-                if top_k is not None and top_k > 0:
-                    kth = torch.topk(scores, min(top_k, scores.shape[-1]))[0][..., -1, None]
-                    scores = scores.masked_fill(scores < kth, -float("inf"))
-                if top_p is not None and top_p < 1.0:
-                    srt, idx = torch.sort(scores, descending=False)
-                    cum = srt.softmax(dim=-1).cumsum(dim=-1)
-                    remove = cum <= (1 - top_p)
-                    remove[..., -1:] = False
-                    scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
                 nxt = torch.multinomial(torch.softmax(scores, dim=-1), num_samples=1).squeeze(1)
             else:
                 nxt = scores.argmax(dim=-1)
@@ -478,6 +461,35 @@ class LlamaEngine:
             lp_rows = self.logits(hid).float().view(B, nb, V)
         out_len = int(seq_len[:, 0].max().item())
         return sequences[:, 0, :out_len]
+
+
+def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: bool, eos_id: int, do_sample: bool,
+                   temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
+                   repetition_penalty: float = 1.0) -> torch.Tensor:
+    """transformers' logits pipeline for ``generate(inputs_embeds=...)`` in its order: RepetitionPenaltyLogitsProcessor over
+    the ids generated so far (with inputs_embeds the prompt contributes no ids), MinLengthLogitsProcessor (EOS -> -inf),
+    then -- only when sampling -- TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper.  ``scores`` [B, V] fp32,
+    ``generated`` [B, n] int64.  Pure torch: pinned against the library's own processors in tests/test_host_logic.py."""
+    if repetition_penalty != 1.0 and generated.shape[1] > 0:
+        g = torch.gather(scores, 1, generated)
+        g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
+        scores = scores.scatter(1, generated, g)
+    if suppress_eos:
+        scores = scores.clone()
+        scores[:, eos_id] = -float("inf")
+    if do_sample:
+        if temperature is not None and temperature != 1.0:
+            scores = scores / temperature
+        if top_k is not None and top_k > 0:
+            kth = torch.topk(scores, min(top_k, scores.shape[-1]))[0][..., -1, None]
+            scores = scores.masked_fill(scores < kth, -float("inf"))
+        if top_p is not None and top_p < 1.0:
+            srt, idx = torch.sort(scores, descending=False)
+            cum = srt.softmax(dim=-1).cumsum(dim=-1)
+            remove = cum <= (1 - top_p)
+            remove[..., -1:] = False
+            scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
+    return scores
 
 
 def apply_eos_padding(ids: torch.Tensor, eos_id: int, pad_id: int) -> torch.Tensor:

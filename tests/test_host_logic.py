@@ -168,3 +168,38 @@ def test_committed_bench_line_matches_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "tokens/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["denoise"]["roofline"]["bound"] == "mfma" and d["denoise"]["unit"] == "steps/s"
+
+
+def test_logits_processing_matches_transformers_processors():
+    """The sampling path's logits pipeline (repetition penalty -> min length -> temperature -> top-k -> top-p) against
+    transformers' own LogitsProcessor / LogitsWarper classes, element for element."""
+    from transformers.generation.logits_process import (MinLengthLogitsProcessor, RepetitionPenaltyLogitsProcessor,
+                                                        TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+    from emu_amd.llama import process_logits
+    g = torch.Generator().manual_seed(5)
+    B, V, eos = 3, 500, 2
+    for trial in range(6):
+        scores = torch.randn(B, V, generator=g) * 3
+        n_gen = [0, 1, 4, 9, 2, 7][trial]
+        gen = torch.randint(3, V, (B, n_gen), generator=g)
+        temp, tk, tp, rp = [(0.7, 40, 0.9, 1.3), (1.0, None, 0.8, 1.0), (1.5, 5, None, 2.0), (0.3, 500, 0.5, 1.1),
+                            (None, None, None, 1.2), (2.0, 1, 0.99, 1.0)][trial]
+        min_len = 3
+        want = scores.clone()
+        ids = gen                                               # with inputs_embeds the id sequence starts empty
+        if rp != 1.0 and n_gen > 0:
+            want = RepetitionPenaltyLogitsProcessor(rp)(ids, want)
+        want = MinLengthLogitsProcessor(min_len, eos)(ids, want)
+        if temp is not None and temp != 1.0:
+            want = TemperatureLogitsWarper(temp)(ids, want)
+        if tk:
+            want = TopKLogitsWarper(tk)(ids, want)
+        if tp is not None and tp < 1.0:
+            want = TopPLogitsWarper(tp)(ids, want)
+        got = process_logits(scores.clone(), gen, n_gen < min_len, eos, True, temp, tk, tp, rp)
+        assert torch.equal(torch.isinf(got), torch.isinf(want)), trial
+        fin = ~torch.isinf(want)
+        assert torch.allclose(got[fin], want[fin], rtol=0, atol=0), trial
+    # greedy: warpers are not applied
+    s0 = torch.randn(2, 50, generator=g)
+    assert torch.equal(process_logits(s0.clone(), torch.zeros(2, 0, dtype=torch.long), False, eos, False, 0.5, 3, 0.5, 1.0), s0)
