@@ -51,6 +51,7 @@ _PROTOS = {
     "emu_allreduce_bf16": (i32, [vp, vp, sz, vp]),
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_set_splitk_scratch": (None, [vp, sz]),
+    "emu_gemm_force_config": (None, [i32]),
     "emu_gemv_stream_giveups": (C.c_uint, []),
     "emu_gemv_stream_engine": (None, [i32]),
     "emu_quantize_fp8_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, vp]),

@@ -55,10 +55,14 @@ struct GemmArgs {
                             // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// the 256x256 ping-pong tile (gemm256.hip), dispatched by launch_gemm; tiles [0, full_tiles) whole-K, the rest in ksplit slices
+int launch_gemm256(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit);
 // scratch that always suffices: at most 256 slice tiles (one per CU) of 256 x 128 fp32
 constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)256 * 256 * 128;
 // process-wide default split-K scratch for callers that do not pass one (the C-ABI primitives); caller-owned memory
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
+// test / bench hook: pin the tile configuration ('B', 'C', 'K', 'S', 'P'; 0 = heuristic)
+void emu_gemm_force_config_set(int cfg);
 
 // ---- row-wise / elementwise (elementwise.hip)
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);

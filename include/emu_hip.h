@@ -47,6 +47,11 @@ int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);   /* 
  * applies the epilogue.  Caller-owned device memory, >= 4 * M * N * 4 bytes for the shapes that should split; NULL / 0
  * (the default) never splits.  One stream at a time may use it.  The UNet engine carries its own inside its workspace. */
 void emu_set_splitk_scratch(void* ptr, size_t bytes);
+/* Test / bench hook: pin the tile configuration of every following GEMM / conv launch of this process.  0 (default) =
+ * the shape heuristic; 'B' 128x128, 'C' 256(n)x128(m), 'K' 128x64 with two k-groups, 'S' 256x128 K-sliced,
+ * 'P' 256x256 ping-pong (K % 64 == 0, else the heuristic).  The parity tests walk every configuration over the
+ * bench's true shapes with it (tests/test_gpu_ops.py); production code never calls it. */
+void emu_gemm_force_config(int cfg);
 
 /* Diagnostic of the LDS-DMA weight-streaming GEMV engine (decode rows, K % 512 == 0, >= 16 MiB of weights): number of
  * bounded ring hand-off spins that expired since the library was loaded.  Non-zero means a launch gave up instead of

@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""A/B of the GEMM tile configurations at the bench's true shapes: correctness of every forced configuration against a
+torch fp32 reference (and bit-equality between the unsplit configurations, whose k order is identical), repeat-run
+determinism (race screen), and HIP-event timing on random data.
+
+    python tools/gemm_ab.py [--cfgs 0BCSP] [--iters 20] [--filter prefill] [--no-check]
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emu_amd import ops  # noqa: E402
+from emu_amd._lib import lib  # noqa: E402
+
+BF16 = torch.bfloat16
+MFMA = 2.5e15
+
+
+def bfr(t):
+    return t.to(BF16).float()
+
+
+def ref_linear(x, w, bias, res, epi):
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    y = bfr(y)
+    if epi == 1:
+        y = bfr(y + res.float())
+    elif epi == 2:
+        y = bfr(bfr(F.silu(y[:, 0::2])) * y[:, 1::2])
+    elif epi == 3:
+        y = bfr(F.silu(y))
+    elif epi == 4:
+        y = bfr(F.gelu(y))
+    elif epi == 5:
+        y = bfr(y[:, 0::2] * bfr(F.gelu(y[:, 1::2])))
+    return y
+
+
+def timeit(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfgs", default="0BCSP")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--no-check", action="store_true")
+    a = ap.parse_args()
+    L = lib()
+    sk = torch.zeros(256 * 256 * 128, dtype=torch.float32, device="cuda")
+    L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
+    g = torch.Generator(device="cuda").manual_seed(0)
+
+    def r(*shape, scale=1.0):
+        return (torch.randn(*shape, device="cuda", generator=g) * scale).to(BF16)
+
+    gemms = [
+        ("tiny-ragged", 300, 320, 640, 1), ("tiny-odd", 257, 1000, 192, 0), ("one-ktile", 512, 512, 64, 0),
+        ("two-ktile", 256, 256, 128, 2), ("three-ktile", 258, 300, 192, 5),
+        ("prefill qkv", 770, 19968, 6656, 0), ("prefill o", 770, 6656, 6656, 1),
+        ("prefill gateup", 770, 35840, 6656, 2), ("prefill down", 770, 6656, 17920, 1),
+        ("prefill1544 qkv", 1544, 19968, 6656, 0), ("prefill1544 gateup", 1544, 35840, 6656, 2),
+        ("prefill1544 down", 1544, 6656, 17920, 1),
+        ("vit qkv", 1025, 6144, 1792, 0), ("vit proj", 1025, 1792, 2048, 1), ("vit fc1", 1025, 15360, 1792, 4),
+        ("vit fc2", 1025, 1792, 15360, 1),
+        ("unet32 attn-out", 2048, 1280, 1280, 1), ("unet32 qkv", 2048, 3840, 1280, 0),
+        ("unet32 geglu", 2048, 10240, 1280, 5), ("unet32 ff-out", 2048, 1280, 5120, 1),
+        ("unet64 qkv", 8192, 1920, 640, 0), ("unet64 attn-out", 8192, 640, 640, 1),
+        ("unet64 geglu", 8192, 5120, 640, 5), ("unet64 ff-out", 8192, 640, 2560, 1),
+        ("square4096", 4096, 4096, 4096, 0), ("square8192", 8192, 8192, 8192, 0),
+    ]
+    convs = [("conv lvl2", 2, 32, 1280, 1280, 1), ("conv lvl2 cat", 2, 32, 2560, 1280, 1), ("conv lvl1", 2, 64, 640, 640, 1),
+             ("conv lvl1 cat", 2, 64, 1280, 640, 1), ("conv lvl0", 2, 128, 320, 320, 1), ("conv lvl0 cat", 2, 128, 960, 320, 1),
+             ("conv up", 2, 32, 1280, 1280, 3), ("conv down", 2, 64, 640, 640, 2)]
+    cfgs = [0 if c == "0" else ord(c) for c in a.cfgs]
+    print(f"{'case':40s} " + " ".join(f"{('auto' if c == 0 else chr(c)):>14s}" for c in cfgs))
+    bad = 0
+    for name, M, N, K, epi in gemms:
+        if a.filter and a.filter not in name:
+            continue
+        x, w = r(M, K), r(N, K, scale=0.02)
+        bias = r(N) if epi in (0, 1, 4) else None
+        res = r(M, N) if epi == 1 else None
+        want = None if a.no_check else ref_linear(x, w, bias, res, epi)
+        cells, outs = [], {}
+        for c in cfgs:
+            L.emu_gemm_force_config(c)
+            fn = lambda: ops.linear(x, w, bias=bias, res=res, epi=epi)
+            t = timeit(fn, a.iters if M * N * K > 1e9 else 3)
+            tag = ""
+            if want is not None:
+                got = fn().float()
+                err = (got - want).abs()
+                tol = 1e-2 * float(want.abs().max()) + 2e-2 * want.abs()
+                nbad = int((err > tol).sum())
+                rep = fn().float()
+                if not torch.equal(rep, got):
+                    tag += "!NONDET"
+                    bad += 1
+                if nbad:
+                    tag += f"!BAD{nbad}"
+                    bad += 1
+                outs[c] = got
+            cells.append(f"{2.0 * M * N * K / t / 1e12:7.0f}TF{tag:>5s}")
+        eq = ""
+        if ord("B") in outs and ord("P") in outs:
+            eq = " P==B" if torch.equal(outs[ord("B")], outs[ord("P")]) else " P!=B"
+        print(f"{name + f' M{M} N{N} K{K} e{epi}':40s} " + " ".join(f"{c:>14s}" for c in cells) + eq, flush=True)
+    for name, B, H, Cin, Cout, mode in convs:
+        if a.filter and a.filter not in name:
+            continue
+        x, w = r(B, H, H, Cin), r(Cout, 3, 3, Cin, scale=0.02)
+        Ho = H if mode == 1 else (H // 2 if mode == 2 else 2 * H)
+        want = None
+        if not a.no_check:
+            xi = x.float().permute(0, 3, 1, 2)
+            if mode == 3:
+                xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+            want = bfr(F.conv2d(xi, w.float().permute(0, 3, 1, 2), stride=2 if mode == 2 else 1, padding=1)).permute(0, 2, 3, 1)
+        cells = []
+        for c in cfgs:
+            L.emu_gemm_force_config(c)
+            fn = lambda: ops.conv3x3_nhwc(x, w, mode=mode)
+            t = timeit(fn, a.iters)
+            tag = ""
+            if want is not None:
+                got = fn().float().reshape(want.shape)
+                err = (got - want).abs()
+                tol = 1e-2 * float(want.abs().max()) + 2e-2 * want.abs()
+                nbad = int((err > tol).sum())
+                if nbad:
+                    tag = f"!BAD{nbad}"
+                    bad += 1
+            cells.append(f"{2.0 * B * Ho * Ho * Cout * 9 * Cin / t / 1e12:7.0f}TF{tag:>5s}")
+        print(f"{name + f' {H}^2 {Cin}->{Cout} m{mode}':40s} " + " ".join(f"{c:>14s}" for c in cells), flush=True)
+    L.emu_gemm_force_config(0)
+    print("FAILURES:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
