@@ -318,7 +318,8 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
 }  // namespace
 
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
-void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg; }
+void emu_gemm256_variant_set(int v);
+void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; emu_gemm256_variant_set(cfg >> 8); }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7)) return -22;

@@ -39,7 +39,9 @@ template <int EPI>
 __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, float (&v)[4]) {
     // 8-byte accesses need every row start 8-byte aligned: ldc (and ldres) % 4 == 0; other strides (a [M, 32274] logits
     // buffer) take the scalar path below
-    const bool full = (nb + 3) < a.N && ((a.ldc | (EPI == EPI_RESID ? a.ldres : 0)) & 3) == 0;
+    // (GLU epilogues store one 4-byte pair per quad: an even ldc is enough, and launch_gemm requires it)
+    constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
+    const bool full = (nb + 3) < a.N && (GLU || ((a.ldc | (EPI == EPI_RESID ? a.ldres : 0)) & 3) == 0);
     if (full) {
         if (a.bias) {
             const u32x2 bv = *reinterpret_cast<const u32x2*>(a.bias + nb);
@@ -94,9 +96,12 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, flo
         }
     }
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) {
-        if (nb + 1 < a.N) {
-            const float o0 = (EPI == EPI_SWIGLU) ? bfround(silu(v[0])) * v[1] : v[0] * bfround(gelu_erf(v[1]));
-            a.C[(size_t)m * a.ldc + (nb >> 1)] = f2bf(o0);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            if (nb + e + 1 < a.N) {
+                const float o = (EPI == EPI_SWIGLU) ? bfround(silu(v[e])) * v[e + 1] : v[e] * bfround(gelu_erf(v[e + 1]));
+                a.C[(size_t)m * a.ldc + ((nb + e) >> 1)] = f2bf(o);
+            }
         }
     } else {
 #pragma unroll

@@ -3,7 +3,10 @@
 torch fp32 reference (and bit-equality between the unsplit configurations, whose k order is identical), repeat-run
 determinism (race screen), and HIP-event timing on random data.
 
-    python tools/gemm_ab.py [--cfgs 0BCSP] [--iters 20] [--filter prefill] [--no-check]
+    python tools/gemm_ab.py [--cfgs 0,B,C,S,P,P1] [--iters 20] [--filter prefill] [--no-check]
+
+A configuration is a letter of emu_gemm_force_config ("0" = heuristic) optionally followed by the number of a schedule
+variant / timing ablation of the 256x256 tile (gemm256.hip; variants >= 2 are timing-only, their results are not checked).
 """
 import argparse
 import os
@@ -57,7 +60,7 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfgs", default="0BCSP")
+    ap.add_argument("--cfgs", default="0,B,C,S,P")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--filter", default="")
     ap.add_argument("--no-check", action="store_true")
@@ -84,12 +87,14 @@ def main():
         ("unet64 qkv", 8192, 1920, 640, 0), ("unet64 attn-out", 8192, 640, 640, 1),
         ("unet64 geglu", 8192, 5120, 640, 5), ("unet64 ff-out", 8192, 640, 2560, 1),
         ("square4096", 4096, 4096, 4096, 0), ("square8192", 8192, 8192, 8192, 0),
+        ("clean1536 gateup", 1536, 35840, 6656, 0), ("clean2048 geglu", 2048, 10240, 1280, 0),
     ]
     convs = [("conv lvl2", 2, 32, 1280, 1280, 1), ("conv lvl2 cat", 2, 32, 2560, 1280, 1), ("conv lvl1", 2, 64, 640, 640, 1),
              ("conv lvl1 cat", 2, 64, 1280, 640, 1), ("conv lvl0", 2, 128, 320, 320, 1), ("conv lvl0 cat", 2, 128, 960, 320, 1),
              ("conv up", 2, 32, 1280, 1280, 3), ("conv down", 2, 64, 640, 640, 2)]
-    cfgs = [0 if c == "0" else ord(c) for c in a.cfgs]
-    print(f"{'case':40s} " + " ".join(f"{('auto' if c == 0 else chr(c)):>14s}" for c in cfgs))
+    names = a.cfgs.split(",")
+    cfgs = [0 if c == "0" else (ord(c[0]) | (int(c[1:] or 0) << 8)) for c in names]
+    print(f"{'case':40s} " + " ".join(f"{('auto' if c == '0' else c):>14s}" for c in names))
     bad = 0
     for name, M, N, K, epi in gemms:
         if a.filter and a.filter not in name:
@@ -104,7 +109,7 @@ def main():
             fn = lambda: ops.linear(x, w, bias=bias, res=res, epi=epi)
             t = timeit(fn, a.iters if M * N * K > 1e9 else 3)
             tag = ""
-            if want is not None:
+            if want is not None and (c >> 8) in (0, 1, 7, 11, 12, 13):
                 got = fn().float()
                 err = (got - want).abs()
                 tol = 1e-2 * float(want.abs().max()) + 2e-2 * want.abs()
@@ -119,8 +124,9 @@ def main():
                 outs[c] = got
             cells.append(f"{2.0 * M * N * K / t / 1e12:7.0f}TF{tag:>5s}")
         eq = ""
-        if ord("B") in outs and ord("P") in outs:
-            eq = " P==B" if torch.equal(outs[ord("B")], outs[ord("P")]) else " P!=B"
+        for c, nm in zip(cfgs, names):
+            if nm[0] == "P" and c in outs and ord("B") in outs:
+                eq += f" {nm}==B" if torch.equal(outs[ord("B")], outs[c]) else f" {nm}!=B"
         print(f"{name + f' M{M} N{N} K{K} e{epi}':40s} " + " ".join(f"{c:>14s}" for c in cells) + eq, flush=True)
     for name, B, H, Cin, Cout, mode in convs:
         if a.filter and a.filter not in name:
@@ -139,7 +145,7 @@ def main():
             fn = lambda: ops.conv3x3_nhwc(x, w, mode=mode)
             t = timeit(fn, a.iters)
             tag = ""
-            if want is not None:
+            if want is not None and (c >> 8) in (0, 1, 7, 11, 12, 13):
                 got = fn().float().reshape(want.shape)
                 err = (got - want).abs()
                 tol = 1e-2 * float(want.abs().max()) + 2e-2 * want.abs()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Run ONE kernel a few times (for rocprofv3 --pmc passes): python tools/one_op.py gemm M N K [epi] | gemv M N K | conv B H Cin Cout"""
+"""Run ONE kernel a few times (for rocprofv3 --pmc passes): python tools/one_op.py gemm M N K [epi] | gemv M N K | conv B H Cin Cout
+EMU_ONE_OP_CFG=P7 pins a GEMM tile configuration / schedule variant (emu_gemm_force_config, as tools/gemm_ab.py)."""
 import os
 import sys
 
@@ -8,7 +9,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emu_amd import ops  # noqa: E402
 
+from emu_amd._lib import lib  # noqa: E402
+
 kind = sys.argv[1]
+cfg = os.environ.get("EMU_ONE_OP_CFG", "")
+if cfg:
+    lib().emu_gemm_force_config(ord(cfg[0]) | (int(cfg[1:] or 0) << 8))
 a = [int(x) for x in sys.argv[2:]]
 r = lambda *s, scale=1.0: (torch.randn(*s, device="cuda") * scale).to(torch.bfloat16)
 if kind in ("gemm", "gemv"):
