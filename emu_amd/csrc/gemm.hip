@@ -269,14 +269,37 @@ int pick_ksplit(const GemmArgs& a, int tiles, int tile_elems, int min_k) {
     return ksplit;
 }
 
+// Does the 256x256 ping-pong tile (gemm256.hip) take this problem?  0 = no, 1 = whole-K workgroups, >= 2 = K-slices.
+// From tools/gemm_ab.py on MI355X (profiles/r02_gemm_ab_v8_dispatch.log): the tile wins wherever it fills most of a round
+// of CUs with enough k tiles to amortise its pipeline fill and 64K-element epilogue -- LLaMA prefill qkv / gate-up
+// (+30-60 % over the 128x128 / 256x128 tiles), every S >= 1024 shape, ViT fc1, the UNet's 64^2 / 128^2 levels -- and, cut
+// into K-slices, the few-tile long-K problems (prefill o / down +20-40 %, the 32^2-level convs +10 %).  It loses where a
+// round is badly quantised (320 tiles = 1.25 rounds), on short-K few-tile GEMMs (ViT qkv / proj, the UNet's K = 1280
+// projections) and on thin prompts (M < 192).
+template <int EPI>
+int pick_pp(const GemmArgs& a) {
+    if (!gemm256_ok(a) || a.M < 192) return 0;
+    const int tp = gemm256_tiles(a), nk = a.K / BK;
+    if (tp >= 180) {
+        const int rounds = (tp + 255) / 256;
+        return (nk >= 8 && tp * 10 >= rounds * 256 * 7) ? 1 : 0;
+    }
+    const int ks = pick_ksplit<EPI>(a, tp, (int)EMU_GEMM256_SLICE_FLOATS, 16);
+    if (ks >= 2 && tp * ks >= 150) return ks;
+    return (tp >= 150 && nk >= 32) ? 1 : 0;
+}
+
 template <int EPI, bool CONV>
 int launch_v2(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
     int cfg = g_force_cfg;
     const bool k64 = (a.K & 63) == 0;
-    if ((cfg == 'P' || cfg == 'S') && !k64) cfg = 0;
+    if (cfg == 'S' && !k64) cfg = 0;
+    if ((cfg == 'P' || cfg == 'Q') && !gemm256_ok(a)) cfg = 0;
     if (!cfg) {
+        const int pp = pick_pp<EPI>(a);
+        if (pp) return pp > 1 ? launch_gemm256(a, s, 0, pp) : launch_gemm256(a, s, -1, 1);
         // The 256x128 tile moves the fewest bytes per FLOP through L2 of the lock-step tiles (the binding resource of
         // these kernels) but runs one workgroup per CU: a 2048 x 1280 output is only 80 tiles (0.31 round).  Problems
         // with fewer tiles than CUs are cut into K-slices so they fill the CUs once: fp32 slice tiles land in a
@@ -290,14 +313,15 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
         else if (tc >= 1024) cfg = 'C';
         else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step) +1.5 % over 128x128
-        else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: LLaMA o/down prefill, ViT qkv
+        else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: ViT qkv
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
         else cfg = 'K';
     }
     switch (cfg) {
+        case 'Q': return launch_gemm256(a, s, -1, 1);  // 256x256 ping-pong, never K-sliced (A/B)
         case 'P': {                                   // 256x256 ping-pong, K-sliced when it has under half a round of tiles
-            const int tp = tiles_of(a, 256, 256);
-            const int ksplit = tp <= 128 ? pick_ksplit<EPI>(a, tp, 256 * 256, 8) : 0;
+            const int tp = gemm256_tiles(a);
+            const int ksplit = tp <= 128 ? pick_ksplit<EPI>(a, tp, (int)EMU_GEMM256_SLICE_FLOATS, 8) : 0;
             return ksplit ? launch_gemm256(a, s, 0, ksplit) : launch_gemm256(a, s, -1, 1);
         }
         case 'S': {
@@ -318,8 +342,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
 }  // namespace
 
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
-void emu_gemm256_variant_set(int v);
-void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; emu_gemm256_variant_set(cfg >> 8); }
+void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7)) return -22;

@@ -55,10 +55,14 @@ struct GemmArgs {
                             // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
-// the 256x256 ping-pong tile (gemm256.hip), dispatched by launch_gemm; tiles [0, full_tiles) whole-K, the rest in ksplit slices
+// the 256x256 ping-pong tile (gemm256.hip), dispatched by launch_gemm; tiles [0, full_tiles) whole-K, the rest in ksplit
+// K-slices of EMU_GEMM256_SLICE_FLOATS fp32 each in a.partial (full_tiles < 0: no slicing)
 int launch_gemm256(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit);
-// scratch that always suffices: at most 256 slice tiles (one per CU) of 256 x 128 fp32
-constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)256 * 256 * 128;
+int gemm256_tiles(const GemmArgs& a);           // workgroups of a whole-K launch (the last row of tiles carries M % 256 <= 32)
+bool gemm256_ok(const GemmArgs& a);             // K % 64 == 0 and operands within reach of 32-bit descriptor offsets
+constexpr size_t EMU_GEMM256_SLICE_FLOATS = 288 * 256;
+// scratch that always suffices: at most 256 slices (one per CU) of the largest tile (256 x 256 + 32 remainder rows, fp32)
+constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)256 * 288 * 256;
 // process-wide default split-K scratch for callers that do not pass one (the C-ABI primitives); caller-owned memory
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
 // test / bench hook: pin the tile configuration ('B', 'C', 'K', 'S', 'P'; 0 = heuristic)

@@ -43,7 +43,7 @@ def main():
     a = ap.parse_args()
     cases = []
     from emu_amd._lib import lib as _lib
-    _sk = torch.zeros(256 * 256 * 128, dtype=torch.float32, device="cuda")      # split-K scratch, as the engines carry
+    _sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")      # split-K scratch, as the engines carry
     if not os.environ.get("EMU_KBENCH_NO_SCRATCH"):
         _lib().emu_set_splitk_scratch(_sk.data_ptr(), _sk.numel() * 4)
 
