@@ -76,8 +76,6 @@ int emu_version(void) { return 1; }
 
 void emu_set_splitk_scratch(void* ptr, size_t bytes) { emu_gemm_set_splitk_scratch(reinterpret_cast<float*>(ptr), bytes / sizeof(float)); }
 void emu_gemm_force_config(int cfg) { emu_gemm_force_config_set(cfg); }
-unsigned int emu_gemv_stream_giveups(void) { return emu_gemv_stream_giveups_read(); }
-void emu_gemv_stream_engine(int enable) { emu_gemv_stream_engine_set(enable); }
 
 int emu_profile_gemv(int enable) {
     g_prof.on = enable != 0;

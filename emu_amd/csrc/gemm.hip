@@ -312,7 +312,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
         // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
         else if (tc >= 1024) cfg = 'C';
-        else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step) +1.5 % over 128x128
+        else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step): 256x128 29.4, 128x128 29.4, 256x256 29.8 ms
         else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: ViT qkv
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
         else cfg = 'K';

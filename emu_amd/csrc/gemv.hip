@@ -11,13 +11,10 @@
 //   gemv_wave_kernel M = 1, K <= 2560: one wave per 4 whole rows, no LDS / barrier (TP-shard o_proj / down_proj).
 //   gemv_mfma_kernel 9..16 rows on v_mfma_f32_16x16x32_bf16.
 //   gemv_fp8_*       optional e4m3 weight stream (per-row scale).
-//   gemv_stream_kernel  LDS-DMA loader/consumer engine, opt-in (measured no faster).
 //
 // Replaces (reference call sites): LlamaDecoderLayer linears + RMSNorm reached from Emu2/emu/emu.py:133-138
 // and :213-229 at S=1 (greedy: 1 row; beam search: num_beams rows), project_up/project_down emu.py:131,147.
 // Algorithmic bytes per call = 2*N*K (fp8: N*K).
-#include <cstdlib>
-
 #include "common.h"
 #include <type_traits>
 #include "kernels.h"
@@ -419,8 +416,6 @@ int launch_wave(const GemvArgs& a, hipStream_t s) {
 
 // returns 1 when the shape is not covered
 int try_launch_wave(const GemvArgs& a, hipStream_t s) {
-    static const char* env = getenv("EMU_GEMV_WAVE");                  // A/B: 0 disables
-    if (env && atoi(env) == 0) return 1;
     if (a.M != 1 || a.norm_w || a.wscale || (a.epi != EPI_NONE && a.epi != EPI_RESID)) return 1;
     const int kitw = ((a.K >> 3) + 63) / 64;
     if (kitw > 5 || a.N < 1024) return 1;                            // K <= 2560; tiny N stays on the block kernels
@@ -435,31 +430,20 @@ int try_launch_wave(const GemvArgs& a, hipStream_t s) {
 
 // M = 1 dispatch onto the single-round-trip kernel; returns 1 when the shape is not covered.
 int try_launch_rt(const GemvArgs& a, hipStream_t s) {
-    static const char* env = getenv("EMU_GEMV_RT");                   // A/B: 0 disables, R value overrides rows/block
-    const int mode = env ? atoi(env) : -1;
-    if (mode == 0 || a.M != 1) return 1;
+    if (a.M != 1) return 1;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return 1;
     const int kit = ((a.K >> 3) + 255) / 256;
     const bool f8 = a.wscale != nullptr;
     if (f8 && (a.epi == EPI_SILU || a.epi == EPI_GELU)) return 1;
-    if (mode < 0) {
-        // measured (tools/kbench.py, profiles/r01_gemv_variants.log): one round trip wins for matrices small enough
-        // that latency, not bandwidth, sets the time (TP shards, tiny models) and for long rows without the RMSNorm
-        // prologue (down_proj: 6.3 vs 5.85 TB/s); big fused-norm matrices amortise the prologue better over 8 rows
-        const size_t bytes = (size_t)a.N * a.K * (f8 ? 1 : 2);
-        const bool small = bytes < ((size_t)(f8 ? 32 : 64) << 20);
-        const bool long_rows = !f8 && kit >= 5 && a.norm_w == nullptr;
-        if (!small && !long_rows) return 1;
-    }
-    if (kit <= 4) {
-        if (f8) return mode == 4 ? launch_rt<4, 4, true>(a, s) : launch_rt<8, 4, true>(a, s);
-        if (mode == 8) return launch_rt<8, 4, false>(a, s);
-        return mode == 2 ? launch_rt<2, 4, false>(a, s) : launch_rt<4, 4, false>(a, s);
-    }
-    if (kit <= 9) {
-        if (f8) return mode == 2 ? launch_rt<2, 9, true>(a, s) : launch_rt<4, 9, true>(a, s);
-        return launch_rt<2, 9, false>(a, s);
-    }
+    // measured (tools/kbench.py, profiles/r01_gemv_variants.log): one round trip wins for matrices small enough
+    // that latency, not bandwidth, sets the time (TP shards, tiny models) and for long rows without the RMSNorm
+    // prologue (down_proj: 6.3 vs 5.85 TB/s); big fused-norm matrices amortise the prologue better over 8 rows
+    const size_t bytes = (size_t)a.N * a.K * (f8 ? 1 : 2);
+    const bool small = bytes < ((size_t)(f8 ? 32 : 64) << 20);
+    const bool long_rows = !f8 && kit >= 5 && a.norm_w == nullptr;
+    if (!small && !long_rows) return 1;
+    if (kit <= 4) return f8 ? launch_rt<8, 4, true>(a, s) : launch_rt<4, 4, false>(a, s);
+    if (kit <= 9) return f8 ? launch_rt<4, 9, true>(a, s) : launch_rt<2, 9, false>(a, s);
     return 1;
 }
 
@@ -590,13 +574,7 @@ int launch_gemv_mfma(const GemvArgs& a, hipStream_t s) {
     // Row groups per workgroup (each activation fragment, re-read from L2, then serves RG weight fragments): measured
     // flat at M = 5 (RG 1 / 2 / 4: 69.5 / 71.7 / 82.9 us on qkv), so the activation re-read is not what holds the kernel
     // at 3.8 TB/s -- the 64-byte-per-row fragment loads are; RG = 1 keeps the most workgroups in flight.
-    static const char* env = getenv("EMU_GEMV_MFMA_RG");               // A/B
-    int rg = env ? atoi(env) : 1;
-    switch (rg) {
-        case 4: return launch_gemv_mfma_rg<4>(a, s);
-        case 2: return launch_gemv_mfma_rg<2>(a, s);
-        default: return launch_gemv_mfma_rg<1>(a, s);
-    }
+    return launch_gemv_mfma_rg<1>(a, s);
 }
 
 // fp8 (OCP e4m3fn) weight stream: half the HBM bytes per token.  One 16-byte load = 16 weights of one row; the per-row
@@ -916,11 +894,10 @@ int launch_epi(const GemvArgs& a, hipStream_t s) {
 template <int R, int MB>
 int launch_norm(const GemvArgs& a, hipStream_t s) {
     // the preload-everything form only for the single-row decode case (register budget: PRE*R*4 VGPRs)
-    static const bool no_pre = getenv("EMU_GEMV_NOPRE") != nullptr;
     // measured: the preload form wins only for plain streams (o_proj); with the RMSNorm prologue it loses 20 %
     // (clamped tail chunks + lower occupancy), so those keep the rolling loop.
     if constexpr (MB == 1 && R <= 4) {
-        if (!no_pre && !a.norm_w && (a.K >> 3) <= 1024) return launch_epi<R, MB, false, 4>(a, s);
+        if (!a.norm_w && (a.K >> 3) <= 1024) return launch_epi<R, MB, false, 4>(a, s);
     }
     return a.norm_w ? launch_epi<R, MB, true, 0>(a, s) : launch_epi<R, MB, false, 0>(a, s);
 }
@@ -956,339 +933,13 @@ int emu_gemv_rows_per_block_multi(int N) {
     return R;
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// LDS-DMA weight-streaming engine (decode, M = 1, bf16).  One persistent 4-wave workgroup per CU: wave 0 is a LOADER
-// that streams this CU's contiguous slice of W through an 8-slot LDS ring with `global_load_lds ... nt` (16 B per
-// lane, 1 KiB per instruction, no VGPR staging) and never waits on arithmetic -- three chunks stay in flight behind
-// the one being retired (counted s_waitcnt vmcnt(N)); waves 1-3 are CONSUMERS that first build the (RMS-normalised)
-// activation vector in LDS, then retire chunks with v_dot2c_f32_bf16 straight out of LDS.  Ring hand-off is two
-// monotonic LDS counters per slot (ready / done), so the HBM queue of every CU stays full from the first instruction
-// of the launch to the last chunk, independent of block scheduling rounds.  Rows are whole KiB (K % 512 == 0) and a
-// row is cut into C equal-ish chunks of <= 13 KiB; partial sums are combined in a fixed order in the epilogue.
-namespace {
-constexpr int ST_MAXSLOT = 12;
-constexpr int ST_MAXKIB = 13;
-constexpr int ST_DEPTH = 3;                         // chunks left in flight while the oldest is awaited
-constexpr int ST_SPIN_LIMIT = 1 << 21;
-
-__device__ unsigned int g_stream_giveups = 0;       // a bounded spin expired (protocol bug): results are invalid
-
-struct StreamGeom {
-    int C;            // chunks per row
-    int kc_base;      // KiB per chunk (the first `extra` chunks carry one more)
-    int extra;
-    int slot_bytes;
-    int part_floats;
-    int unit;         // rows are dealt to workgroups in units of 1 (2 for SwiGLU pairs)
-    int nl, nslot;    // loader waves (consumers = 4 - nl), ring slots
-    int debug;        // 1: loader free-runs, consumers idle (bandwidth probe); 2: consumers skip the arithmetic
-};
-
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-    switch (n) {
-#define EMU_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        EMU_VM(0) EMU_VM(3) EMU_VM(6) EMU_VM(9) EMU_VM(12) EMU_VM(15) EMU_VM(18) EMU_VM(21) EMU_VM(24) EMU_VM(27)
-        EMU_VM(30) EMU_VM(33) EMU_VM(36) EMU_VM(39)
-#undef EMU_VM
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-__device__ __forceinline__ bool spin_ge(volatile unsigned int* f, unsigned int target) {
-    int n = 0;
-    while (*f < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > ST_SPIN_LIMIT) return false;
-    }
-    asm volatile("" ::: "memory");
-    return true;
-}
-// LDS flag accesses of the LOADER wave go through inline asm: the compiler's waitcnt pass treats every LDS access it
-// can see as possibly aliasing an in-flight global_load_lds and drains the DMA queue (s_waitcnt vmcnt(0)) in front of
-// it, which would serialise the stream to one chunk in flight.
-__device__ __forceinline__ unsigned int lds_addr(const volatile void* p) {
-    return (unsigned int)(unsigned long)(__attribute__((address_space(3))) const volatile void*)p;
-}
-__device__ __forceinline__ unsigned int lds_load_u32(unsigned int addr) {
-    unsigned int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_store_u32(unsigned int addr, unsigned int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ bool spin_ge_asm(unsigned int addr, unsigned int target) {
-    int n = 0;
-    while (lds_load_u32(addr) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++n > ST_SPIN_LIMIT) return false;
-    }
-    return true;
-}
-__device__ __forceinline__ float dot2(unsigned int w, unsigned int x, float acc) {
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
-}
-
-template <bool NORM, int EPI>
-__global__ __launch_bounds__(256, 1) void gemv_stream_kernel(const GemvArgs a, const StreamGeom g) {
-    extern __shared__ __align__(1024) unsigned char smem[];
-    unsigned char* ring = smem;
-    unsigned char* xs = smem + g.nslot * g.slot_bytes;                      // bf16 activation vector, K elements
-    float* part = reinterpret_cast<float*>(xs + (size_t)a.K * 2);
-    volatile unsigned int* ready = reinterpret_cast<volatile unsigned int*>(part + g.part_floats);
-    volatile unsigned int* done = ready + ST_MAXSLOT;
-    volatile float* ss_part = reinterpret_cast<volatile float*>(done + ST_MAXSLOT);
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int NL = g.nl, NC = 4 - g.nl;                                     // loader waves 0..NL-1, consumers after
-    const int units = a.N / g.unit;
-    const int base = units / (int)gridDim.x, rem = units % (int)gridDim.x;
-    const int bid = blockIdx.x;
-    const int r0 = (bid * base + (bid < rem ? bid : rem)) * g.unit;
-    const int nrows = (base + (bid < rem ? 1 : 0)) * g.unit;
-    const int nchunks = nrows * g.C;
-    const size_t row_bytes = (size_t)a.K * 2;
-    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.W) + (size_t)r0 * row_bytes;
-
-    auto chunk_kib = [&](int c) { return g.kc_base + (c < g.extra ? 1 : 0); };
-    auto chunk_off = [&](int c) { return (c * g.kc_base + (c < g.extra ? c : g.extra)) * 1024; };
-    auto issue = [&](int q) {                       // loader: DMA chunk q into its ring slot
-        const int row = q / g.C, c = q - row * g.C;
-        const unsigned char* src = wbase + (size_t)row * row_bytes + chunk_off(c) + lane * 16;
-        unsigned char* dst = ring + (q % g.nslot) * g.slot_bytes;
-        const int kc = chunk_kib(c);
-        for (int i = 0; i < kc; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-    };
-
-    // loader wave l owns chunks l, l + NL, ...; `issued` / `published` count its own chunks
-    const int mine = wave < NL ? (nchunks - wave + NL - 1) / NL : 0;
-    int issued = 0;
-    if (wave < NL) {
-        const int pre = mine < ST_DEPTH ? mine : ST_DEPTH;                  // slots are free at launch: no waits
-        for (; issued < pre; ++issued) issue(wave + issued * NL);
-    } else {
-        const int ct = tid - 64 * NL, nct = 64 * NC;                        // consumer threads build x in LDS
-        if (ct < 2 * ST_MAXSLOT) ready[ct] = 0;                             // ready[] and done[] are contiguous
-        if constexpr (NORM) {
-            float ss = 0.f;
-            for (int vi = ct; vi < (a.K >> 3); vi += nct) {
-                float f[8];
-                unpack8(ld16(a.x + vi * 8), f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-            }
-            ss = wave_sum(ss);
-            if (lane == 0) ss_part[wave - NL] = ss;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // A: flags + ss partials visible
-    if (wave >= NL) {
-        const int ct = tid - 64 * NL, nct = 64 * NC;
-        float rinv = 1.f;
-        if constexpr (NORM) {
-            float t = 0.f;
-            for (int i = 0; i < NC; ++i) t += ss_part[i];
-            rinv = rsqrtf(t / (float)a.K + a.eps);
-        }
-        for (int vi = ct; vi < (a.K >> 3); vi += nct) {
-            u32x4 v = ld16(a.x + vi * 8);
-            if constexpr (NORM) {
-                float f[8], gw[8];
-                unpack8(v, f);
-                unpack8(ld16(a.norm_w + vi * 8), gw);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = bfround(gw[j] * bfround(f[j] * rinv));
-                v = pack8(f);
-            }
-            *reinterpret_cast<u32x4*>(xs + (size_t)vi * 16) = v;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // B: x resident in LDS
-
-    bool ok = true;
-    if (wave < NL) {
-        int published = 0;
-        const int keep = ST_DEPTH * g.kc_base;                              // loads of the DEPTH newest chunks >= keep
-        const unsigned int ready_a = lds_addr(ready), done_a = lds_addr(done);
-        while (published < mine && ok) {
-            if (issued < mine) {
-                const int q = wave + issued * NL;
-                const int s = q % g.nslot, gen = q / g.nslot;
-                if (gen > 0 && g.debug != 1) ok = spin_ge_asm(done_a + 4 * s, (unsigned)gen);   // previous tenant retired
-                issue(q);
-                ++issued;
-                if (issued - published > ST_DEPTH) {
-                    wait_vmcnt_dyn(keep);
-                    const int qp = wave + published * NL;
-                    lds_store_u32(ready_a + 4 * (qp % g.nslot), (unsigned)(qp / g.nslot + 1));
-                    ++published;
-                }
-            } else {
-                wait_vmcnt_dyn(0);
-                for (; published < mine; ++published) {
-                    const int qp = wave + published * NL;
-                    lds_store_u32(ready_a + 4 * (qp % g.nslot), (unsigned)(qp / g.nslot + 1));
-                }
-            }
-        }
-        wait_vmcnt_dyn(0);
-    } else {
-        for (int q = wave - NL; q < nchunks && ok && g.debug != 1; q += NC) {
-            const int s = q % g.nslot, gen = q / g.nslot;
-            const int row = q / g.C, c = q - row * g.C;
-            ok = spin_ge(&ready[s], (unsigned)(gen + 1));
-            const u32x4* wp = reinterpret_cast<const u32x4*>(ring + s * g.slot_bytes) + lane;
-            const u32x4* xp = reinterpret_cast<const u32x4*>(xs + chunk_off(c)) + lane;
-            const int kc = g.debug == 2 ? 0 : chunk_kib(c);
-            float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 4
-            for (int i = 0; i < kc; ++i) {
-                const u32x4 w = wp[i * 64], xv = xp[i * 64];
-                acc0 = dot2(w.x, xv.x, acc0);
-                acc1 = dot2(w.y, xv.y, acc1);
-                acc0 = dot2(w.z, xv.z, acc0);
-                acc1 = dot2(w.w, xv.w, acc1);
-            }
-            const float v = wave_sum(acc0 + acc1);
-            asm volatile("" ::: "memory");
-            if (lane == 0) {
-                part[q] = v;
-                done[s] = (unsigned)(gen + 1);                               // slot free for chunk q + nslot
-            }
-        }
-    }
-    if (!ok && lane == 0) atomicAdd(&g_stream_giveups, 1u);
-    __syncthreads();
-
-    // epilogue: every thread finishes rows of this workgroup (fixed-order combine of the C partial sums)
-    if constexpr (EPI == EPI_SWIGLU) {
-        for (int j = tid; j < nrows / 2; j += 256) {
-            float gt = 0.f, up = 0.f;
-            for (int c = 0; c < g.C; ++c) { gt += part[(2 * j) * g.C + c]; up += part[(2 * j + 1) * g.C + c]; }
-            const int n = r0 + 2 * j;
-            if (a.bias) { gt += bf2f(a.bias[n]); up += bf2f(a.bias[n + 1]); }
-            gt = bfround(gt); up = bfround(up);
-            a.out[n >> 1] = f2bf(bfround(silu(gt)) * up);
-        }
-    } else {
-        for (int r = tid; r < nrows; r += 256) {
-            float v = 0.f;
-            for (int c = 0; c < g.C; ++c) v += part[r * g.C + c];
-            const int n = r0 + r;
-            if (a.bias) v += bf2f(a.bias[n]);
-            v = bfround(v);
-            if constexpr (EPI == EPI_RESID) v = v + bf2f(a.res[n]);
-            a.out[n] = f2bf(v);
-        }
-    }
-}
-
-// Off by default: measured on MI355X the engine tops out at the same ~5.6-5.9 TB/s as the block kernels even with the
-// consumers idle (two loader waves; one loader wave: 4.2 TB/s), see DESIGN.md section 4.  Kept as a selectable path.
-int g_stream_engine = -1;
-bool stream_engine_enabled() {
-    if (g_stream_engine < 0) {
-        const char* env = getenv("EMU_GEMV_STREAM");
-        g_stream_engine = env ? (atoi(env) != 0) : 0;
-    }
-    return g_stream_engine != 0;
-}
-
-int stream_cu_count() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return v;
-    }();
-    return n;
-}
-
-// Shapes the engine takes; everything else stays on gemv_kernel.
-bool stream_applicable(const GemvArgs& a) {
-    if (!stream_engine_enabled()) return false;
-    if (a.M != 1 || a.wscale || (a.K & 511) || a.ldw != a.K) return false;
-    if (a.epi != EPI_NONE && a.epi != EPI_RESID && a.epi != EPI_SWIGLU) return false;
-    const int ncu = stream_cu_count();
-    if (ncu < 1 || a.N < 8 * ncu) return false;                             // >= 8 rows per CU
-    if ((size_t)a.N * a.K * 2 < ((size_t)16 << 20)) return false;           // small matrices are launch-latency work
-    const int row_kib = a.K >> 9;
-    const int C = (row_kib + ST_MAXKIB - 1) / ST_MAXKIB;
-    const int kc_base = row_kib / C;
-    if ((kc_base * ST_DEPTH) % 3 != 0 || kc_base * ST_DEPTH > 39) return false;
-    if ((ST_DEPTH + 1) * (kc_base + 1) > 63) return false;                  // vmcnt is a 6-bit counter
-    return true;
-}
-
-template <bool NORM, int EPI>
-int launch_stream_t(const GemvArgs& a, const StreamGeom& g, size_t lds, int grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_stream_kernel<NORM, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemv_stream_kernel<NORM, EPI>), dim3(grid), dim3(256), lds, s, a, g);
-    EMU_CHECK_LAUNCH();
-    return 0;
-}
-
-int launch_stream(const GemvArgs& a, hipStream_t s) {
-    const int ncu = stream_cu_count();
-    StreamGeom g;
-    const int row_kib = a.K >> 9;
-    g.C = (row_kib + ST_MAXKIB - 1) / ST_MAXKIB;
-    g.kc_base = row_kib / g.C;
-    g.extra = row_kib % g.C;
-    g.slot_bytes = (g.kc_base + (g.extra ? 1 : 0)) * 1024;
-    g.unit = a.epi == EPI_SWIGLU ? 2 : 1;
-    static const char* dbg = getenv("EMU_ST_DEBUG");
-    g.debug = dbg ? atoi(dbg) : 0;
-    const int units = a.N / g.unit;
-    g.part_floats = ((units + ncu - 1) / ncu) * g.unit * g.C;
-    static const char* nl_env = getenv("EMU_ST_NL");
-    g.nl = nl_env ? atoi(nl_env) : 2;
-    if (g.nl < 1 || g.nl > 3) return -22;
-    const size_t fixed = (size_t)a.K * 2 + (size_t)g.part_floats * 4 + 2 * ST_MAXSLOT * 4 + 16;
-    g.nslot = (int)((160 * 1024 - fixed) / g.slot_bytes);                   // the ring takes what LDS is left
-    if (g.nslot > ST_MAXSLOT) g.nslot = ST_MAXSLOT;
-    if (g.nslot < g.nl * (ST_DEPTH + 1) + 1) return -22;
-    const size_t lds = (size_t)g.nslot * g.slot_bytes + fixed;
-    const bool norm = a.norm_w != nullptr;
-#define EMU_ST_CASE(E)                                                                                               \
-    case E: return norm ? launch_stream_t<true, E>(a, g, lds, ncu, s) : launch_stream_t<false, E>(a, g, lds, ncu, s);
-    switch (a.epi) {
-        EMU_ST_CASE(EPI_NONE)
-        EMU_ST_CASE(EPI_RESID)
-        EMU_ST_CASE(EPI_SWIGLU)
-        default: return -22;
-    }
-#undef EMU_ST_CASE
-}
-}  // namespace
-
-void emu_gemv_stream_engine_set(int enable) { g_stream_engine = enable ? 1 : 0; }
-
-unsigned int emu_gemv_stream_giveups_read() {
-    unsigned int v = 0;
-    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_stream_giveups), sizeof v);
-    return v;
-}
-
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.M < 1 || a.M > 16 || (a.K & 7) || a.N < 1) return -22;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return -22;
     // 9..16 rows: the 16x16x32 MFMA stream.  Up to 8 rows the v_dot2c block kernel is faster (M = 2: 6.4 vs 4.1 TB/s,
     // M = 5: 4.5 vs 3.9, M = 8: 3.7 vs 3.5; tools/kbench.py --filter rows): its row-contiguous 1 KiB loads use HBM better
-    // than the MFMA fragment's 64 bytes per row.  EMU_GEMV_MFMA=1 forces the MFMA kernel for every M >= 2 (A/B).
-    static const char* mf_env = getenv("EMU_GEMV_MFMA");
-    const bool mf_all = mf_env && atoi(mf_env) == 1;
-    if ((a.M > 8 || (mf_all && a.M >= 2)) && !a.wscale && !a.norm_w && (a.K & 31) == 0 && (a.ldw & 7) == 0 &&
+    // than the MFMA fragment's 64 bytes per row.
+    if (a.M > 8 && !a.wscale && !a.norm_w && (a.K & 31) == 0 && (a.ldw & 7) == 0 &&
         (a.ldx & 7) == 0)
         return launch_gemv_mfma(a, s);
     if (a.M > 8) return -22;
@@ -1298,27 +949,14 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.wscale) {                                  // fp8 weight stream (decode, batch <= 2 built)
         // 16 weights per 16-byte load: K = 6656 is only 416 groups, so short rows run 2-wave blocks (3.25 trips per
         // lane, like the bf16 kernel) and long rows (down_proj, K = 17920) 4-wave blocks
-        static const char* f8 = getenv("EMU_GEMV_FP8_NW");
-        const int nw = f8 ? atoi(f8) : 2;
-        static const char* v8 = getenv("EMU_GEMV_FP8_V8");               // A/B: 8-byte weight loads, R rows per block
-        const int v8r = v8 ? atoi(v8) : (a.K <= 8192 ? 8 : 0);   // 8-byte loads keep 3.25 trips per lane at K = 6656
-        if (v8r == 16) return a.M <= 1 ? launch_fp8v8<16, 1, 4>(a, s) : launch_fp8v8<16, 2, 4>(a, s);
-        if (v8r == 8) return a.M <= 1 ? launch_fp8v8<8, 1, 4>(a, s) : launch_fp8v8<8, 2, 4>(a, s);
-        if (v8r == 32) return a.M <= 1 ? launch_fp8v8<32, 1, 4>(a, s) : launch_fp8v8<32, 2, 4>(a, s);
+        if (a.K <= 8192) return a.M <= 1 ? launch_fp8v8<8, 1, 4>(a, s) : launch_fp8v8<8, 2, 4>(a, s);   // 8-byte loads: 3.25 trips per lane at K = 6656
         const bool small = (a.N + 7) / 8 < 512;
-        if (a.M <= 1) {
-            if (small) return launch_fp8<4, 1, 2>(a, s);
-            return nw == 2 ? launch_fp8<8, 1, 2>(a, s) : nw == 1 ? launch_fp8<8, 1, 1>(a, s) : launch_fp8<8, 1, 4>(a, s);
-        }
-        if (small) return launch_fp8<4, 2, 2>(a, s);
-        return nw == 2 ? launch_fp8<8, 2, 2>(a, s) : nw == 1 ? launch_fp8<8, 2, 1>(a, s) : launch_fp8<8, 2, 4>(a, s);
+        if (a.M <= 1) return small ? launch_fp8<4, 1, 2>(a, s) : launch_fp8<8, 1, 2>(a, s);
+        return small ? launch_fp8<4, 2, 2>(a, s) : launch_fp8<8, 2, 2>(a, s);
     }
-    if (stream_applicable(a)) return launch_stream(a, s);
-    static const char* force_r = getenv("EMU_GEMV_R");     // A/B runs
     int R = a.rows_per_block > 0 ? a.rows_per_block
-                                 : (force_r ? atoi(force_r)
-                                            : (a.M > 1 ? emu_gemv_rows_per_block_multi(a.N)
-                                                       : emu_gemv_rows_per_block(a.N, a.K, a.norm_w != nullptr)));
+                                 : (a.M > 1 ? emu_gemv_rows_per_block_multi(a.N)
+                                            : emu_gemv_rows_per_block(a.N, a.K, a.norm_w != nullptr));
     if (a.M > 1 && R > 8) R = 8;                   // 16 rows per workgroup only pays at M = 1 (accumulator registers)
     switch (R) {
         case 2: return launch_mb<2>(a, s);

@@ -22,9 +22,6 @@ struct GemvArgs {
     const float* wscale;    // non-null: W holds OCP fp8 e4m3 bytes [N, ldw] with one fp32 scale per row (K % 16 == 0)
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
-// LDS-DMA streaming engine diagnostics: number of bounded ring spins that expired since load (must stay 0)
-unsigned int emu_gemv_stream_giveups_read();
-void emu_gemv_stream_engine_set(int enable);
 
 // Implicit-GEMM 3x3 convolution over an NHWC activation: A is [B, Hin, Win, Cin], the GEMM row m is the output
 // pixel (b, yo, xo), K = 9*Cin ordered (ky, kx, ci) -- weights repacked to [Cout, 3, 3, Cin].  Cin % 64 == 0.

@@ -32,11 +32,15 @@ class EmuVisualGenerationPipelineOutput:
 
 class EmuVisualGeneration:
     def __init__(self, multimodal_encoder, unet: UNetEngine, vae: VaeDecoder, eva_size=EVA_IMAGE_SIZE,
-                 eva_mean=OPENAI_DATASET_MEAN, eva_std=OPENAI_DATASET_STD, **kwargs):
+                 eva_mean=OPENAI_DATASET_MEAN, eva_std=OPENAI_DATASET_STD, safety_checker=None, **kwargs):
+        """``safety_checker``: optional callable ``(images float32 [N, H, W, 3] in [0, 1]) -> (images, [bool] * N)`` run on
+        the decoded images, the hook for the reference's StableDiffusionSafetyChecker stage (diffusion.py:154-166,236-249;
+        a CLIP classifier outside the hot path, not rebuilt here).  None = no filter: ``nsfw_content_detected`` is None and
+        nothing is blacked out -- a checkpoint that carries ``safety_checker.*`` weights triggers a warning at load."""
         self.multimodal_encoder = multimodal_encoder
         self.unet = unet
         self.vae = vae
-        self.safety_checker = None
+        self.safety_checker = safety_checker
         self.vae_scale_factor = 2 ** (len(vae.cfg.block_out_channels) - 1)
         self.transform = lambda img: image_transform(img, eva_size, eva_mean, eva_std)
         self.negative_prompt = {}                   # "" / "[NULL_IMAGE]" -> embeds, computed once (diffusion.py:197-210)
@@ -117,7 +121,11 @@ class EmuVisualGeneration:
         latents = self.generate_latents(prompt_embeds, height, width, num_inference_steps, guidance_scale, crop_info,
                                         original_size)
         images = self.decode_latents(latents)
-        return EmuVisualGenerationPipelineOutput(image=self.numpy_to_pil(images)[0], nsfw_content_detected=None)
+        nsfw = None
+        if self.safety_checker is not None:                          # diffusion.py:154-166 (run_safety_checker)
+            images, flags = self.safety_checker(images)
+            nsfw = bool(flags[0]) if flags is not None else None
+        return EmuVisualGenerationPipelineOutput(image=self.numpy_to_pil(images)[0], nsfw_content_detected=nsfw)
 
     __call__ = forward
 
@@ -150,7 +158,13 @@ class EmuVisualGeneration:
         return cls(multimodal_encoder=enc, unet=unet, vae=vae, **kwargs)
 
     def load_state_dict(self, state_dict, strict: bool = True):
-        """Pipeline checkpoint keys: ``multimodal_encoder.*``, ``unet.*``, ``vae.*`` (``safety_checker.*`` ignored)."""
+        """Pipeline checkpoint keys: ``multimodal_encoder.*``, ``unet.*``, ``vae.*``.  ``safety_checker.*`` weights are
+        not consumed (see ``__init__``): their presence without a ``safety_checker`` hook is reported once."""
+        if self.safety_checker is None and any(k.startswith("safety_checker.") for k in state_dict):
+            import warnings
+            warnings.warn("EmuVisualGeneration: the checkpoint's safety_checker.* weights are discarded and NO NSFW filter "
+                          "runs (nsfw_content_detected stays None, flagged images are not blacked out as in the "
+                          "reference pipeline); pass safety_checker=<callable> to restore the stage", stacklevel=2)
         enc_items = ((k[len("multimodal_encoder."):], v) for k, v in state_dict.items() if k.startswith("multimodal_encoder."))
         self.multimodal_encoder.load_weights(enc_items, strict=strict)
         self.unet.load_state_dict(((k, v) for k, v in state_dict.items()), prefix="unet.", strict=strict)

@@ -193,6 +193,16 @@ class EmuModel:
                  skip_special_tokens=True, **kwargs):
         if penalty_alpha is not None:
             raise NotImplementedError("contrastive search (penalty_alpha) is not built")
+        # the reference forwards **kwargs to transformers' generate (emu.py:175,228); the options this engine honours
+        # are mapped, anything else is refused rather than silently ignored
+        if "min_new_tokens" in kwargs:
+            min_len = max(int(min_len), int(kwargs.pop("min_new_tokens")))
+        if "min_length" in kwargs:
+            min_len = max(int(min_len), int(kwargs.pop("min_length")))
+        kwargs.pop("use_cache", None)                   # always cached
+        if kwargs:
+            raise TypeError(f"EmuModel.generate: unsupported generation options {sorted(kwargs)} "
+                            "(the HIP engine implements greedy / beam / sampling with the arguments of the signature)")
         tok = self.decoder.tokenizer
         text = [t.replace(image_placeholder, self.image_placeholder).replace(video_placeholder, self.video_placeholder)
                 for t in text]
@@ -233,8 +243,13 @@ class EmuModel:
         text = [t.replace(placeholder, self.image_placeholder) for t in text]
         inputs = tok(text, padding="longest", return_tensors="pt")
         if not bool(inputs.attention_mask.all()):
-            # the reference re-pads every iteration and calls lm.model without position_ids;
-            # rows of different length are therefore run one by one, which is what un-padded rows compute.
+            # the reference re-pads every iteration and calls lm.model without position_ids, so
+            # its left-padded rows see RoPE positions shifted by their pad count; rows of different length are run one
+            # by one here, which is what the same rows compute un-padded (= the reference at batch size 1).
+            import warnings
+            warnings.warn("generate_image: prompts of different token lengths are computed one by one (as at batch size 1); "
+                          "the reference's batched call shifts the RoPE positions of its left-padded rows and returns "
+                          "different embeddings for them", stacklevel=2)
             outs = []
             for i, t in enumerate(text):
                 one = tok([t], return_tensors="pt").input_ids

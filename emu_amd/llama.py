@@ -18,6 +18,7 @@ from .conf.emu_conf import LlamaCfg
 from .tp import ShardPlan
 
 BF16 = torch.bfloat16
+EOS_POLL = 16          # greedy decode: steps between two host looks at the emitted ids (early stop on EOS)
 _LAYER_KEYS = ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
                "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight",
                "input_layernorm.weight", "post_attention_layernorm.weight")
@@ -61,7 +62,7 @@ class EmuHipContext:
             check(lib().emu_tp_init(self.handle, buf), "emu_tp_init", self.handle)
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
-        check(lib().emu_allreduce_bf16(self.handle, t.data_ptr(), t.numel(), ops.stream()), "emu_allreduce_bf16", self.handle)
+        check(lib().emu_allreduce_bf16(self.handle, t.data_ptr(), t.numel(), ops.stream(self.device)), "emu_allreduce_bf16", self.handle)
         return t
 
     def __del__(self):
@@ -86,7 +87,7 @@ class LlamaEngine:
         self.handle = h
         self._keep: Dict[str, torch.Tensor] = {}          # packed weights (owned here, pointers held by the lib)
         self._pending: Dict[int, Dict[str, torch.Tensor]] = {}
-        self.layers_loaded = 0
+        self.layers_loaded = set()          # indices of the packed layers (a reload must not count twice)
         self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta, self.device)
         self.embed = self.final_norm = self.lm_head = None
         self.kcache = self.vcache = None
@@ -135,7 +136,7 @@ class LlamaEngine:
         check(lib().emu_llama_set_layer(self.handle, i, p["wqkv"].data_ptr(), p["wo"].data_ptr(), p["wgu"].data_ptr(),
                                         p["wdown"].data_ptr(), p["ln1"].data_ptr(), p["ln2"].data_ptr()),
               "emu_llama_set_layer")
-        self.layers_loaded += 1
+        self.layers_loaded.add(i)
 
     def load_weights(self, items: Iterable[Tuple[str, torch.Tensor]], prefix: str = "decoder.lm.") -> None:
         for name, t in items:
@@ -144,7 +145,7 @@ class LlamaEngine:
 
     @property
     def ready(self) -> bool:
-        return (self.layers_loaded == self.cfg.num_hidden_layers and self.embed is not None
+        return (len(self.layers_loaded) == self.cfg.num_hidden_layers and self.embed is not None
                 and self.final_norm is not None and self.lm_head is not None)
 
     def weight_bytes_per_token(self) -> int:
@@ -231,13 +232,13 @@ class LlamaEngine:
         assert hidden.is_contiguous() and hidden.dtype == BF16 and hidden.shape == (B * T, self.cfg.hidden_size)
         ws = self._workspace(B, T)
         check(lib().emu_llama_forward(self.handle, hidden.data_ptr(), B, T, pos.data_ptr(), slot.data_ptr(),
-                                      ops._p(kstart), ops._p(ctx_dev), ctx, ws.data_ptr(), ws.numel(), ops.stream()),
+                                      ops._p(kstart), ops._p(ctx_dev), ctx, ws.data_ptr(), ws.numel(), ops.stream(self.device)),
               "emu_llama_forward", self.ctx.handle)
         return hidden
 
     def final_norm_rows(self, hidden: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(hidden)
-        check(lib().emu_llama_final_norm(self.handle, hidden.data_ptr(), out.data_ptr(), hidden.shape[0], ops.stream()),
+        check(lib().emu_llama_final_norm(self.handle, hidden.data_ptr(), out.data_ptr(), hidden.shape[0], ops.stream(self.device)),
               "emu_llama_final_norm")
         return out
 
@@ -248,7 +249,7 @@ class LlamaEngine:
             out = torch.empty(M, self.vocab, device=self.device, dtype=BF16)
         ws = self._workspace(max(M, 1), 1)
         check(lib().emu_llama_logits(self.handle, hidden_rows.data_ptr(), hidden_rows.stride(0), M, out.data_ptr(),
-                                     out.stride(0), ws.data_ptr(), ws.numel(), ops.stream()),
+                                     out.stride(0), ws.data_ptr(), ws.numel(), ops.stream(self.device)),
               "emu_llama_logits", self.ctx.handle)
         return out
 
@@ -317,6 +318,11 @@ class LlamaEngine:
                     st.step_graph()
                 else:
                     st.step()
+                # the reference's loop ends when every row has emitted EOS (transformers' stopping criteria): look at the
+                # device-side ids every EOS_POLL steps (one small host read; the launches in between stay queued ahead)
+                if stop_on_eos and (i + 1) % EOS_POLL == 0 and i + 1 < steps:
+                    if bool((out_ids[: i + 2] == eos_id).any(dim=0).all()):
+                        break
         ids = out_ids.t().to(torch.int64)                       # [B, max_new]
         if not stop_on_eos:
             return ids
@@ -537,7 +543,7 @@ class GreedyState:
                                           self.slot.data_ptr(), self.kstart.data_ptr(), self.ctx.data_ptr(),
                                           self.step_idx.data_ptr(), self.out_ids.data_ptr(), e.s_max,
                                           self.hidden.data_ptr(), self.logits.data_ptr(), self.logits.stride(0),
-                                          self.ws.data_ptr(), self.ws.numel(), ops.stream()),
+                                          self.ws.data_ptr(), self.ws.numel(), ops.stream(self.device)),
               "emu_llama_greedy_step", e.ctx.handle)
 
     def step_graph(self) -> None:

@@ -15,8 +15,18 @@ EPI_NONE, EPI_RESID, EPI_SWIGLU, EPI_SILU, EPI_GELU, EPI_GEGLU = range(6)
 BF16 = torch.bfloat16
 
 
-def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream(ref=None) -> int:
+    """HIP stream handle for one library call: torch's current stream of the device that holds ``ref`` (a tensor or a
+    torch.device; None = the current device).  The library launches on that stream without touching the HIP device
+    state, so when ``ref`` lives on another GPU than the calling thread's current device, the current device is
+    switched to it first (one process drives one GPU in this design; this keeps a stray ``device='cuda:1'`` correct
+    instead of enqueueing device-1 work on a device-0 stream)."""
+    if ref is None:
+        return torch.cuda.current_stream().cuda_stream
+    dev = ref.device if isinstance(ref, torch.Tensor) else torch.device(ref)
+    if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _p(t: Optional[torch.Tensor]) -> int:
@@ -46,7 +56,7 @@ def linear(x, w, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = 
         _req(res, "res")
     check(lib().emu_linear_bf16(_p(x), _p(w), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K,
                                 x.stride(0), w.stride(0), res.stride(0) if res is not None else 0,
-                                out.stride(0), float(eps), int(epi), stream()), "emu_linear_bf16")
+                                out.stride(0), float(eps), int(epi), stream(x)), "emu_linear_bf16")
     return out
 
 
@@ -58,7 +68,7 @@ def quantize_fp8_rows(w):
     N, K = w.shape
     q = torch.empty(N, K, device=w.device, dtype=torch.uint8)
     sc = torch.empty(N, device=w.device, dtype=torch.float32)
-    check(lib().emu_quantize_fp8_rows(_p(w), w.stride(0), _p(q), q.stride(0), _p(sc), N, K, stream()),
+    check(lib().emu_quantize_fp8_rows(_p(w), w.stride(0), _p(q), q.stride(0), _p(sc), N, K, stream(w)),
           "emu_quantize_fp8_rows")
     return q, sc
 
@@ -77,7 +87,7 @@ def linear_fp8w(x, w8, wscale, bias=None, res=None, norm_w=None, eps: float = 0.
         _req(res, "res")
     check(lib().emu_linear_fp8w_bf16(_p(x), _p(w8), _p(wscale), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K,
                                      x.stride(0), w8.stride(0), res.stride(0) if res is not None else 0,
-                                     out.stride(0), float(eps), int(epi), stream()), "emu_linear_fp8w_bf16")
+                                     out.stride(0), float(eps), int(epi), stream(x)), "emu_linear_fp8w_bf16")
     return out
 
 
@@ -86,7 +96,7 @@ def rmsnorm(x, w, eps: float, out=None):
     rows, cols = x.shape
     if out is None:
         out = torch.empty_like(x)
-    check(lib().emu_rmsnorm_bf16(_p(x), _p(w), _p(out), rows, cols, x.stride(0), out.stride(0), float(eps), stream()),
+    check(lib().emu_rmsnorm_bf16(_p(x), _p(w), _p(out), rows, cols, x.stride(0), out.stride(0), float(eps), stream(x)),
           "emu_rmsnorm_bf16")
     return out
 
@@ -97,7 +107,7 @@ def layernorm(x, w, b, eps: float, res=None, out=None):
     rows, cols = x.shape
     if out is None:
         out = torch.empty_like(x)
-    check(lib().emu_layernorm_bf16(_p(x), _p(w), _p(b), _p(res), _p(out), rows, cols, float(eps), stream()),
+    check(lib().emu_layernorm_bf16(_p(x), _p(w), _p(b), _p(res), _p(out), rows, cols, float(eps), stream(x)),
           "emu_layernorm_bf16")
     return out
 
@@ -107,7 +117,7 @@ def embed_gather(ids, table, out=None):
     n = ids.numel()
     if out is None:
         out = torch.empty(n, table.shape[1], device=table.device, dtype=BF16)
-    check(lib().emu_embed_gather_bf16(_p(ids), _p(table), _p(out), n, table.shape[1], table.shape[0], stream()),
+    check(lib().emu_embed_gather_bf16(_p(ids), _p(table), _p(out), n, table.shape[1], table.shape[0], stream(table)),
           "emu_embed_gather_bf16")
     return out
 
@@ -115,7 +125,7 @@ def embed_gather(ids, table, out=None):
 def scatter_rows(src, dst_rows, out):
     _req(src, "src"); _req(dst_rows, "dst_rows", torch.int32); _req(out, "out")
     assert src.is_contiguous() and out.is_contiguous() and src.shape[0] == dst_rows.numel()
-    check(lib().emu_scatter_rows_bf16(_p(src), _p(dst_rows), _p(out), src.shape[0], src.shape[1], stream()),
+    check(lib().emu_scatter_rows_bf16(_p(src), _p(dst_rows), _p(out), src.shape[0], src.shape[1], stream(src)),
           "emu_scatter_rows_bf16")
     return out
 
@@ -126,7 +136,7 @@ def argmax(logits, vocab: Optional[int] = None, suppress_id: int = -1, out=None)
     vocab = logits.shape[1] if vocab is None else vocab
     if out is None:
         out = torch.empty(rows, device=logits.device, dtype=torch.int32)
-    check(lib().emu_argmax_bf16(_p(logits), logits.stride(0), rows, vocab, suppress_id, _p(out), stream()),
+    check(lib().emu_argmax_bf16(_p(logits), logits.stride(0), rows, vocab, suppress_id, _p(out), stream(logits)),
           "emu_argmax_bf16")
     return out
 
@@ -138,7 +148,7 @@ def avgpool_tokens(x, grid: int, stride: int):
     B, _, Cc = x.shape
     go = grid // stride
     out = torch.empty(B, go * go, Cc, device=x.device, dtype=BF16)
-    check(lib().emu_avgpool_tokens_bf16(_p(x), _p(out), B, grid, Cc, stride, stream()), "emu_avgpool_tokens_bf16")
+    check(lib().emu_avgpool_tokens_bf16(_p(x), _p(out), B, grid, Cc, stride, stream(x)), "emu_avgpool_tokens_bf16")
     return out
 
 
@@ -148,14 +158,14 @@ def rope_kv_append(qkv, cos, sin, pos, slot, kcache, vcache, B: int, T: int, H: 
     assert qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
     S_max = kcache.shape[-2]
     check(lib().emu_rope_kv_append_bf16(_p(qkv), _p(cos), _p(sin), _p(pos), _p(slot), _p(kcache), _p(vcache),
-                                        B, T, H, D, S_max, stream()), "emu_rope_kv_append_bf16")
+                                        B, T, H, D, S_max, stream(qkv)), "emu_rope_kv_append_bf16")
 
 
 def transpose_v(v, B: int, H: int, S: int, D: int, sb: int, sh: int, ss: int, S_pad: Optional[int] = None):
     _req(v, "v")
     S_pad = (S + 63) // 64 * 64 if S_pad is None else S_pad
     vt = torch.empty(B, H, D, S_pad, device=v.device, dtype=BF16)
-    check(lib().emu_transpose_v_bf16(_p(v), sb, sh, ss, _p(vt), B, H, S, D, S_pad, stream()), "emu_transpose_v_bf16")
+    check(lib().emu_transpose_v_bf16(_p(v), sb, sh, ss, _p(vt), B, H, S, D, S_pad, stream(v)), "emu_transpose_v_bf16")
     return vt
 
 
@@ -169,7 +179,7 @@ def flash_attn(q, k, v, causal: bool, scale: float, kstart=None):
     check(lib().emu_flash_attn_bf16(_p(q), q.stride(0), q.stride(2), q.stride(1),
                                     _p(k), k.stride(0), k.stride(2), k.stride(1), _p(vt),
                                     _p(o), o.stride(0), o.stride(2), o.stride(1), _p(kstart),
-                                    B, H, Sq, Sk, vt.shape[-1], D, int(causal), float(scale), stream()),
+                                    B, H, Sq, Sk, vt.shape[-1], D, int(causal), float(scale), stream(q)),
           "emu_flash_attn_bf16")
     return o
 
@@ -184,7 +194,7 @@ def decode_attn(q, kcache, vcache, ctx: int, scale: float, kstart=None, ctx_dev=
     o = torch.empty(B, H, D, device=q.device, dtype=BF16)
     check(lib().emu_decode_attn_bf16(_p(q), q.stride(0), q.stride(1), _p(kcache), _p(vcache), _p(o), o.stride(0),
                                      o.stride(1), _p(kstart), _p(ctx_dev), ctx, ctx_max, _p(ws), B, H, D, S_max,
-                                     float(scale), stream()), "emu_decode_attn_bf16")
+                                     float(scale), stream(q)), "emu_decode_attn_bf16")
     return o
 
 
@@ -199,7 +209,7 @@ def groupnorm_nhwc(x, gamma, beta, groups: int, eps: float, silu: bool = False):
     ws = torch.empty(lib().emu_groupnorm_ws_bytes(B, HW, Cc), device=x.device, dtype=torch.uint8)
     y = torch.empty_like(x)
     check(lib().emu_groupnorm_nhwc_bf16(_p(x), _p(gamma), _p(beta), _p(y), _p(ws), B, HW, Cc, groups, float(eps), int(silu),
-                                        stream()), "emu_groupnorm_nhwc_bf16")
+                                        stream(x)), "emu_groupnorm_nhwc_bf16")
     return y
 
 
@@ -212,7 +222,7 @@ def conv3x3_nhwc(x, w, bias=None, bias2=None, res=None, mode: int = CONV_3X3):
     Ho, Wo = (H, W) if mode == CONV_3X3 else (((H + 1) // 2, (W + 1) // 2) if mode == CONV_3X3_S2 else (2 * H, 2 * W))
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=BF16)
     check(lib().emu_conv3x3_nhwc_bf16(_p(x), _p(w), _p(bias), _p(bias2), bias2.stride(0) if bias2 is not None else 0, _p(res),
-                                      _p(y), B, H, W, Cin, Cout, mode, stream()), "emu_conv3x3_nhwc_bf16")
+                                      _p(y), B, H, W, Cin, Cout, mode, stream(x)), "emu_conv3x3_nhwc_bf16")
     return y
 
 
@@ -224,5 +234,5 @@ def softmax_rows_(x, scale: float = 1.0, bias=None):
         _req(bias, "bias")
         assert bias.shape == x.shape
     check(lib().emu_softmax_rows_bf16(_p(x), _p(bias), x.shape[0], x.shape[1], x.stride(0),
-                                      bias.stride(0) if bias is not None else 0, float(scale), stream()), "emu_softmax_rows_bf16")
+                                      bias.stride(0) if bias is not None else 0, float(scale), stream(x)), "emu_softmax_rows_bf16")
     return x

@@ -317,7 +317,7 @@ class UNetEngine:
             self._graph = None
         ws = self._workspace(8, 8)
         check(lib().emu_unet_set_context(self.handle, pe.data_ptr(), n, add_in.data_ptr(), add_in.shape[1],
-                                         self._cache.data_ptr(), self._cache.numel(), ws.data_ptr(), ws.numel(), ops.stream()),
+                                         self._cache.data_ptr(), self._cache.numel(), ws.data_ptr(), ws.numel(), ops.stream(self.device)),
               "emu_unet_set_context", self.ctx.handle)
 
     # ------------------------------------------------------------------ compute
@@ -330,7 +330,7 @@ class UNetEngine:
         eps = torch.empty(2 * H * W, Cc, device=self.device, dtype=BF16)
         st = torch.tensor([step_index], device=self.device, dtype=torch.int32)
         check(lib().emu_unet_forward(self.handle, x.data_ptr(), H, W, self.temb_table.data_ptr(), self.sigmas.data_ptr(),
-                                     st.data_ptr(), eps.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream()),
+                                     st.data_ptr(), eps.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream(self.device)),
               "emu_unet_forward", self.ctx.handle)
         return eps.view(2, H, W, Cc).permute(0, 3, 1, 2).contiguous()
 
@@ -339,7 +339,7 @@ class UNetEngine:
         _, _, H, W = latents.shape
         ws = self._workspace(H, W)
         check(lib().emu_unet_step(self.handle, latents.data_ptr(), H, W, self.temb_table.data_ptr(), self.sigmas.data_ptr(),
-                                  self.step_dev.data_ptr(), float(guidance), ws.data_ptr(), ws.numel(), ops.stream()),
+                                  self.step_dev.data_ptr(), float(guidance), ws.data_ptr(), ws.numel(), ops.stream(self.device)),
               "emu_unet_step", self.ctx.handle)
 
     @torch.no_grad()

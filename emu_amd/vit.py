@@ -39,7 +39,7 @@ class VitEngine:
         self._keep: Dict[str, torch.Tensor] = {}
         self._pending: Dict[int, Dict[str, torch.Tensor]] = {}
         self._stem: Dict[str, torch.Tensor] = {}
-        self.blocks_loaded = 0
+        self.blocks_loaded = set()          # indices of the packed blocks (a reload must not count twice)
         self._ws = None
 
     def _dev(self, t):
@@ -70,7 +70,7 @@ class VitEngine:
 
     @property
     def ready(self) -> bool:
-        return self.blocks_loaded == self.cfg.layers and "wpatch" in self._keep
+        return len(self.blocks_loaded) == self.cfg.layers and "wpatch" in self._keep
 
     def _pack_stem(self):
         c = self.cfg
@@ -108,7 +108,7 @@ class VitEngine:
             self._keep[f"{i}.{k}"] = v
         order = ("wqkv", "bqkv", "wproj", "bproj", "ln1w", "ln1b", "fc1w", "fc1b", "fc2w", "fc2b", "ln2w", "ln2b")
         check(lib().emu_vit_set_block(self.handle, i, *[p[k].data_ptr() for k in order]), "emu_vit_set_block")
-        self.blocks_loaded += 1
+        self.blocks_loaded.add(i)
 
     @torch.no_grad()
     def forward(self, image: torch.Tensor) -> torch.Tensor:
@@ -129,7 +129,7 @@ class VitEngine:
             self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
         out = torch.empty(B, c.tokens, c.width, device=self.device, dtype=BF16)
         check(lib().emu_vit_forward(self.handle, img.data_ptr(), int(img.dtype == torch.float32), B, out.data_ptr(),
-                                    self._ws.data_ptr(), self._ws.numel(), ops.stream()), "emu_vit_forward",
+                                    self._ws.data_ptr(), self._ws.numel(), ops.stream(self.device)), "emu_vit_forward",
               self.ctx.handle)
         return out
 

@@ -54,13 +54,6 @@ void emu_set_splitk_scratch(void* ptr, size_t bytes);
  * bench's true shapes with it (tests/test_gpu_ops.py); production code never calls it. */
 void emu_gemm_force_config(int cfg);
 
-/* Diagnostic of the LDS-DMA weight-streaming GEMV engine (decode rows, K % 512 == 0, >= 16 MiB of weights): number of
- * bounded ring hand-off spins that expired since the library was loaded.  Non-zero means a launch gave up instead of
- * hanging the GPU and its output is invalid; the parity tests assert it stays 0. */
-unsigned int emu_gemv_stream_giveups(void);
-/* Select the LDS-DMA engine for the shapes it covers (default 0 = block kernels; env EMU_GEMV_STREAM=1 also enables). */
-void emu_gemv_stream_engine(int enable);
-
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while
  * enabled (eager launches only, not inside stream capture).  read: sum of launch durations (ms), algorithmic
  * weight bytes (2*N*K per launch) and launch count since the last enable. */

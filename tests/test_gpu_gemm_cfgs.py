@@ -1,0 +1,124 @@
+"""Every GEMM / conv tile configuration at the shapes that carry the benchmark (LLaMA prefill S = 770 / 1544, ViT N = 1025,
+the UNet's 32^2 / 64^2 / 128^2 levels), pinned one by one with emu_gemm_force_config and compared with a torch fp32
+reference on the GPU (the reference op itself: F.linear / F.conv2d, then the reference's bf16 rounding points).
+The shape heuristic only ever picks a subset of (configuration, shape) pairs; this walks the full product so a
+tile-specific addressing bug cannot hide behind the dispatch.  Run on an MI355X with `-m gpu`."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+CFGS = ["B", "C", "S", "K", "P", "Q", "0"]
+
+
+def bfr(t):
+    return t.to(BF16).float()
+
+
+def ref_linear(x, w, bias, res, epi):
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    y = bfr(y)
+    if epi == 1:
+        y = bfr(y + res.float())
+    elif epi == 2:
+        y = bfr(bfr(F.silu(y[:, 0::2])) * y[:, 1::2])
+    elif epi == 3:
+        y = bfr(F.silu(y))
+    elif epi == 4:
+        y = bfr(F.gelu(y))
+    elif epi == 5:
+        y = bfr(y[:, 0::2] * bfr(F.gelu(y[:, 1::2])))
+    return y
+
+
+@pytest.fixture()
+def force():
+    from emu_amd._lib import lib
+    L = lib()
+    sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")     # split-K scratch, as the engines carry
+    L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
+    yield lambda c: L.emu_gemm_force_config(0 if c == "0" else ord(c))
+    L.emu_gemm_force_config(0)
+    L.emu_set_splitk_scratch(0, 0)
+
+
+def check(got, want, what):
+    got, want = got.float(), want.float()
+    tol = 1e-2 * float(want.abs().max()) + 2e-2 * want.abs()
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float((got - want).abs().max())}"
+
+
+def rnd(*shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(BF16)
+
+
+# (M, N, K, epilogues): the bench's true shapes (N cut where it only multiplies identical tiles)
+SHAPES = [
+    (770, 19968 // 4, 6656, (0,)), (770, 6656, 6656, (1,)), (770, 35840 // 4, 6656, (2,)), (770, 6656, 17920, (1,)),
+    (1544, 6656, 6656, (0, 1, 2, 3, 4, 5)), (1025, 6144, 1792, (0,)), (1025, 1792, 2048, (1,)), (1025, 15360, 1792, (4,)),
+    (1025, 1792, 15360, (1,)), (2048, 1280, 1280, (0, 1)), (2048, 10240, 1280, (5,)), (2048, 1280, 5120, (1,)),
+    (8192, 1920, 640, (0,)), (8192, 5120, 640, (5,)), (8192, 640, 2560, (1,)), (800, 512, 1536, (0, 1, 2, 3, 4, 5)),
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("M,N,K,epis", SHAPES)
+def test_gemm_true_shapes_every_config(force, cfg, M, N, K, epis):
+    from emu_amd import ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.02)
+    for epi in epis:
+        bias = rnd(N, seed=3) if epi in (0, 1, 4) else None
+        res = rnd(M, N, seed=4) if epi == 1 else None
+        want = ref_linear(x, w, bias, res, epi)
+        force(cfg)
+        got = ops.linear(x, w, bias=bias, res=res, epi=epi)
+        rep = ops.linear(x, w, bias=bias, res=res, epi=epi)
+        assert torch.equal(got, rep), f"cfg {cfg} M{M} N{N} K{K} epi{epi}: repeat launch differs"
+        check(got, want, f"cfg {cfg} M{M} N{N} K{K} epi{epi}")
+
+
+def test_unsplit_configs_are_bit_identical(force):
+    """128x128, 256x128 and the 256x256 ping-pong tile accumulate every output in the same k order: equal bits."""
+    from emu_amd import ops
+    x, w, bias = rnd(770, 6656, seed=5), rnd(1536, 6656, seed=6, scale=0.02), rnd(1536, seed=7)
+    outs = []
+    for cfg in "BCQ":
+        force(cfg)
+        outs.append(ops.linear(x, w, bias=bias))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+@pytest.mark.parametrize("B,H,Cin,Cout,mode", [(2, 128, 320, 320, 1), (2, 32, 1280, 1280, 1), (2, 32, 2560, 1280, 1),
+                                              (2, 64, 640, 640, 2), (2, 32, 1280, 1280, 3), (1, 24, 64, 96, 1),
+                                              (3, 17, 128, 200, 2)])
+def test_conv_true_shapes_every_config(force, cfg, B, H, Cin, Cout, mode):
+    from emu_amd import ops
+    x, w = rnd(B, H, H, Cin, seed=11), rnd(Cout, 3, 3, Cin, seed=12, scale=0.02)
+    bias, b2 = rnd(Cout, seed=13), rnd(B, Cout, seed=14)
+    xi = x.float().permute(0, 3, 1, 2)
+    if mode == 3:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xi, w.float().permute(0, 3, 1, 2), bias.float(), stride=2 if mode == 2 else 1, padding=1)
+    want = bfr(bfr(y) + b2.float()[:, :, None, None]).permute(0, 2, 3, 1)
+    force(cfg)
+    got = ops.conv3x3_nhwc(x, w, bias=bias, bias2=b2, mode=mode)
+    check(got.reshape(want.shape), want, f"conv cfg {cfg} {H}^2 {Cin}->{Cout} mode {mode}")
+
+
+def test_logits_rows_with_unaligned_stride(force):
+    """More than 16 rows onto a [M, 32274] buffer (stride % 4 == 2: Emu2-Chat's vocabulary; 4 prompts x 5 beams): the
+    GEMM epilogue falls back to scalar stores instead of rejecting the launch."""
+    from emu_amd import ops
+    M, N, K = 20, 32274, 512
+    x, w = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.05)
+    for cfg in "0BK":
+        force(cfg)
+        out = torch.zeros(M, N, dtype=BF16, device="cuda")
+        ops.linear(x, w, out=out)
+        check(out, ref_linear(x, w, None, None, 0), f"logits cfg {cfg}")
