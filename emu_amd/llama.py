@@ -543,7 +543,7 @@ class GreedyState:
                                           self.slot.data_ptr(), self.kstart.data_ptr(), self.ctx.data_ptr(),
                                           self.step_idx.data_ptr(), self.out_ids.data_ptr(), e.s_max,
                                           self.hidden.data_ptr(), self.logits.data_ptr(), self.logits.stride(0),
-                                          self.ws.data_ptr(), self.ws.numel(), ops.stream(self.device)),
+                                          self.ws.data_ptr(), self.ws.numel(), ops.stream(e.device)),
               "emu_llama_greedy_step", e.ctx.handle)
 
     def step_graph(self) -> None:
