@@ -46,7 +46,21 @@ def parse():
     p.add_argument("--no-beam", action="store_true", help="skip the extra 5-beam leg (the reference's default decoding mode)")
     p.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weight decode leg (never the headline value)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--no-legs", action="store_true", help="skip the extra BASELINE-config legs (S=1544 prefill, generate_image, "
+                                                          "VAE decode, any-to-image)")
+    p.add_argument("--pmc-mode", type=int, default=0, metavar="N", help="profiling aid for rocprofv3 --pmc passes: after the "
+                   "prefill run exactly N eager decode steps and print the algorithmic bytes of every GEMV launch of the process")
     return p.parse_args()
+
+
+def gemv_source_hash():
+    """sha256 over the sources of the kernel the roofline object describes: a PMC traffic ratio is only quoted when it was
+    measured on exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemv.hip", "common.h", "kernels.h"):
+        h.update(open(os.path.join(ROOT, "emu_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def log(*a):
@@ -163,12 +177,93 @@ def denoise_leg(ctx, dev, steps, world, dist):
         dt = float(tt.item())
     per_gpu = steps / dt
     finite = bool(torch.isfinite(lat.float()).all())
+    denoise_leg.engine = eng
     return {"metric": "diffusion denoise steps/sec (UNet fwd CFG batch 2 + guidance + Euler step, 1024x1024, 64 ctx tokens)",
             "value": per_gpu * world, "unit": "steps/s", "per_gpu": per_gpu, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "scaling": "replicas only (independent images per GPU)", "launch": "hipGraph replay", "finite_output": finite,
             "roofline": {"bound": "mfma", "achieved": UNET_FLOPS_PER_STEP * per_gpu / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": UNET_FLOPS_PER_STEP * per_gpu / MFMA_BF16_PEAK,
                          "flops_per_step": UNET_FLOPS_PER_STEP}}
+
+
+def config_legs(m, lm, ctx, dev, vcfg, lcfg, img, unet_eng):
+    """Timed legs for the other BASELINE.json configs (reported next to the headline, never as `value`):
+    configs[2] few-shot prefill (4 images + 512 tokens, S = 1544), configs[3]/[4] the visual-embedding regression
+    `generate_image` (prompt + [IMG] prefill, then n_query - 1 = 63 KV-cached steps through project_down / project_up:
+    every step streams all decoder weights), the VAE decode, and the any-to-image chain end to end
+    (generate_image for the prompt and for the negative prompt -> 50 denoise steps -> VAE decode)."""
+    from emu_amd import synth
+    from emu_amd.constants import IMAGE_TOKEN_ID, IMG_END_TOKEN_ID, IMG_TOKEN_ID
+    from emu_amd.vae import VaeCfg, VaeDecoder, vae_decoder_param_shapes
+    out = {}
+
+    def timed(fn, reps=2):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize(); dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return best, r
+
+    with torch.no_grad():
+        # ---- configs[2]: 4 images + 512-token prompt, S = 512 + 4 * 258 = 1544
+        g = torch.Generator().manual_seed(2)
+        text_ids = torch.randint(3, 32000, (512,), generator=g)
+        block = torch.tensor([IMG_TOKEN_ID] + [IMAGE_TOKEN_ID] * vcfg.n_query + [IMG_END_TOKEN_ID])
+        parts = []
+        for i in range(4):
+            parts += [text_ids[i * 128:(i + 1) * 128], block]
+        ids = torch.cat(parts)[None]
+        S = ids.shape[1]
+        imgs = img.expand(4, -1, -1, -1).contiguous()
+        t_vit, _ = timed(lambda: m.encode_image(imgs), reps=1)
+        x = m._prompt_embeds(ids, imgs, vcfg.n_query)
+        mask = torch.ones(1, S, dtype=torch.long)
+        s_max = lm.kv_capacity(S + 8)
+        t_pf, _ = timed(lambda: lm.prefill(x.view(1, S, -1), mask, s_max))
+        fl = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
+                                       + 2 * S * S * lcfg.hidden_size)
+        out["prefill_fewshot_S1544"] = {"config": "BASELINE.json configs[2]: 4 images + 512-token prompt", "S": S,
+                                        "prefill_ms": t_pf * 1e3, "tflops": fl / t_pf / 1e12, "mfma_frac": fl / t_pf / MFMA_BF16_PEAK,
+                                        "vit_encode_4_images_ms": t_vit * 1e3}
+        # ---- generate_image (Emu2-Gen: n_query 64), 20-token prompt: S0 + 1 prefill + 63 cached steps
+        nq_saved = m.n_query
+        m.n_query = 64
+        try:
+            pid = torch.randint(3, 32000, (1, 20), generator=g)
+            t_gi, emb = timed(lambda: m.generate_image_ids(pid))
+            wb = lm.weight_bytes_per_token() - 2 * lm.lm_head.numel()              # no lm_head in the regression loop
+            out["generate_image"] = {"config": "emu.py:92-153, KV-cached: 21-token prefill + 63 steps (project_down -> project_up "
+                                               "-> 60 layers), 64 visual embeddings out", "ms": t_gi * 1e3,
+                                     "ms_per_step": t_gi * 1e3 / 64, "weight_stream_GBps": 63 * wb / t_gi / 1e9,
+                                     "frac_of_hbm_peak": 63 * wb / t_gi / HBM_PEAK, "finite": bool(torch.isfinite(emb.float()).all())}
+            # ---- VAE decode + any-to-image end to end
+            vcfg_ = VaeCfg()
+            vae = VaeDecoder(vcfg_, ctx)
+            vae.load_state_dict(synth.synth_state_dict(vae_decoder_param_shapes(vcfg_), seed=1), strict=True)
+            z = torch.randn(1, 4, 128, 128, device=dev).to(torch.bfloat16)
+            t_vae, _ = timed(lambda: vae.decode_latents(z))
+            out["vae_decode"] = {"config": "AutoencoderKL.decode, latents [1,4,128,128] -> 1024x1024", "ms": t_vae * 1e3}
+            if unet_eng is not None:
+                neg = torch.randint(3, 32000, (1, 1), generator=g)
+
+                def chain():
+                    cond = m.generate_image_ids(pid)
+                    unc = m.generate_image_ids(neg)
+                    prompt = torch.cat([cond, unc], dim=0).to(torch.bfloat16)
+                    sch = unet_eng.set_timesteps(50)
+                    unet_eng.set_context(prompt, 1024, 1024)
+                    lat = (torch.randn(1, 4, 128, 128, device=dev) * sch.init_noise_sigma).to(torch.bfloat16).contiguous()
+                    lat = unet_eng.denoise(lat, 3.0, use_graph=True)
+                    return vae.decode_latents(lat)
+                t_e2e, image = timed(chain)
+                out["any_to_image_e2e"] = {"config": "BASELINE.json configs[4] at TP=1, bf16: generate_image (prompt) + generate_image "
+                                                     "(negative prompt, uncached here) -> 50-step CFG denoise (hipGraph) -> VAE decode, "
+                                                     "1024x1024", "ms": t_e2e * 1e3, "finite": bool(torch.isfinite(image.float()).all())}
+        finally:
+            m.n_query = nq_saved
+    return out
 
 
 def main():
@@ -264,6 +359,19 @@ def main():
     out_ids = torch.zeros(total + 1, 1, device=dev, dtype=torch.int32)
     out_ids[0] = cur
     st = GreedyState(lm, 1, cur, next_pos, S, kstart, out_ids)
+    if a.pmc_mode:
+        # everything up to here launched no M <= 8 GEMV except the logits row above; count from now
+        check(lib().emu_profile_gemv(1), "emu_profile_gemv")
+        with torch.no_grad():
+            for _ in range(a.pmc_mode):
+                st.step()
+        torch.cuda.synchronize()
+        ms, wb, nl = C.c_double(), C.c_double(), C.c_long()
+        check(lib().emu_profile_gemv_read(C.byref(ms), C.byref(wb), C.byref(nl)), "emu_profile_gemv_read")
+        if rank == 0:
+            print(json.dumps({"pmc_mode_steps": a.pmc_mode, "gemv_launches": nl.value, "gemv_algorithmic_bytes": wb.value,
+                              "gemv_ms": ms.value}), flush=True)
+        return
     use_graph = not a.no_graph
     def make_stepper(state, graph):
         box = {"fn": state.step_graph if graph else state.step, "n": 0}
@@ -394,17 +502,30 @@ def main():
     if not a.no_denoise:
         denoise = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None)
 
+    legs = None
+    if not a.no_legs and world == 1:
+        try:
+            legs = config_legs(m, lm, ctx, dev, vcfg, lcfg, img, getattr(denoise_leg, "engine", None))
+        except Exception as e:                                  # never lose the headline to an extra leg
+            legs = {"note": f"legs failed: {type(e).__name__}: {e}"}
+
     # HBM traffic of the GEMV launches comes from PMC counters (FETCH_SIZE), which a timing run cannot collect itself:
     # the committed pass over THIS command (profiles/r01_gemv_pmc_traffic.json, gfx950-corrected) gives traffic /
     # algorithmic bytes for the same kernels; traffic = that ratio x this run's algorithmic bytes per launch
     traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_pmc_traffic.json")))
-        ratio = float(pmc["all_gemv_launches"]["traffic_over_algorithmic"])
-        traffic = ratio * bytes_per_launch
-        traffic_src = f"profiles/r01_gemv_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE pass over bench.py, traffic/algorithmic = {ratio:.4f}"
-    except Exception:
-        pass
+        here = os.path.dirname(os.path.abspath(__file__))
+        pmc = json.load(open(os.path.join(here, "profiles", "r02_gemv_pmc_traffic.json")))
+        if pmc.get("source_sha256") != gemv_source_hash():
+            traffic_src = ("profiles/r02_gemv_pmc_traffic.json is STALE (taken on other kernel sources: re-run tools/pmc_traffic.sh); "
+                           "traffic not reported")
+        else:
+            ratio = float(pmc["all_gemv_launches"]["traffic_over_algorithmic"])
+            traffic = ratio * bytes_per_launch
+            traffic_src = ("profiles/r02_gemv_pmc_traffic.json (same kernel sources, sha256 checked): rocprofv3 --pmc FETCH_SIZE "
+                           f"pass over `bench.py --pmc-mode`, gfx950-corrected; traffic / algorithmic = {ratio:.4f}")
+    except Exception as e:
+        traffic_src = f"no PMC pass available ({type(e).__name__})"
 
     if rank == 0:
         prefill_flops = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
@@ -438,6 +559,8 @@ def main():
             res["beam_search_5"] = beam
         if denoise is not None:
             res["denoise"] = denoise
+        if legs is not None:
+            res["legs"] = legs
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.cpu_seconds, S, VOCAB_EMU2_CHAT)

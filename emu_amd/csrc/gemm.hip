@@ -354,7 +354,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         if (g.mode == CONV_3X3 && (g.Hout != g.Hin || g.Wout != g.Win)) return -22;
         if (g.mode == CONV_3X3_S2 && (g.Hout != (g.Hin + 1) / 2 || g.Wout != (g.Win + 1) / 2)) return -22;
         if (g.mode == CONV_3X3_UP2 && (g.Hout != 2 * g.Hin || g.Wout != 2 * g.Win)) return -22;
-        if (g.Hout > 1023 || g.Wout > 1023 || a.M / (g.Hout * g.Wout) > 2047) return -22;     // packed pixel coordinates
         switch (a.epi) {
             case EPI_NONE:  return launch_v2<EPI_NONE, true>(a, s);
             case EPI_RESID: return launch_v2<EPI_RESID, true>(a, s);

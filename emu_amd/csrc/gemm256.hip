@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const uint32_t sck = (uint32_t)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);       // bytes
     const uint32_t vP = (uint32_t)(n0 + srow) * (uint32_t)a.ldw * 2u + sck;
     const uint32_t vQ = (uint32_t)(m0 + (srow >> 5) * 64 + (srow & 31)) * (uint32_t)a.lda * 2u + sck;     // plain GEMM
-    uint32_t qpix[2][2];                             // CONV: output pixel (b << 20 | y << 10 | x) of every Q piece's row
+    uint32_t qpix[2][2];                             // CONV: output pixel (b << 22 | y << 11 | x) of every Q piece's row
     if constexpr (CONV) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 const int hw = a.conv.Hout * a.conv.Wout;
                 const int pb = gm / hw, rr = gm - pb * hw;
                 const int py = rr / a.conv.Wout, px = rr - py * a.conv.Wout;
-                qpix[s][i] = (uint32_t)((pb << 20) | (py << 10) | px);
+                qpix[s][i] = (uint32_t)((pb << 22) | (py << 11) | px);
             }
     }
     const uint32_t w_bytes = (uint32_t)a.N * (uint32_t)a.ldw * 2u;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
                 const int ky = tap / 3, kx = tap - ky * 3;
                 const uint32_t o = qpix[S][i];
-                const int pb = o >> 20, py = (o >> 10) & 1023, px = o & 1023;
+                const int pb = o >> 22, py = (o >> 11) & 2047, px = o & 2047;
                 int yi, xi;
                 const bool ok = conv_tap(a.conv, py, px, ky, kx, yi, xi);
                 const uint32_t off = (uint32_t)((((pb * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin) * 2) + sck;
@@ -372,6 +372,8 @@ int gemm256_tiles(const GemmArgs& a) {
 // operand extents the 32-bit descriptor offsets can address, k tiles of 64
 bool gemm256_ok(const GemmArgs& a) {
     if (a.K & 63) return false;
+    if (a.conv.mode != CONV_NONE && (a.conv.Hout > 2047 || a.conv.Wout > 2047 || a.M / (a.conv.Hout * a.conv.Wout) > 1023))
+        return false;                                  // packed pixel coordinates of the gather
     const size_t wb = (size_t)a.N * a.ldw * 2;
     const size_t ab = a.conv.mode != CONV_NONE
                           ? (size_t)(a.M / (a.conv.Hout * a.conv.Wout)) * a.conv.Hin * a.conv.Win * a.conv.Cin * 2

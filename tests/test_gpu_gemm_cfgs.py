@@ -96,7 +96,7 @@ def test_unsplit_configs_are_bit_identical(force):
 @pytest.mark.parametrize("cfg", CFGS)
 @pytest.mark.parametrize("B,H,Cin,Cout,mode", [(2, 128, 320, 320, 1), (2, 32, 1280, 1280, 1), (2, 32, 2560, 1280, 1),
                                               (2, 64, 640, 640, 2), (2, 32, 1280, 1280, 3), (1, 24, 64, 96, 1),
-                                              (3, 17, 128, 200, 2)])
+                                              (3, 17, 128, 200, 2), (1, 1100, 64, 64, 1)])
 def test_conv_true_shapes_every_config(force, cfg, B, H, Cin, Cout, mode):
     from emu_amd import ops
     x, w = rnd(B, H, H, Cin, seed=11), rnd(Cout, 3, 3, Cin, seed=12, scale=0.02)
