@@ -54,6 +54,7 @@ _PROTOS = {
     "emu_gemm_force_config": (None, [i32]),
     "emu_quantize_fp8_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, vp]),
     "emu_linear_fp8w_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "emu_linear_fp8_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "emu_softmax_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),

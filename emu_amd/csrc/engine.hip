@@ -161,6 +161,14 @@ int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, con
     if (!wscale) return -22;
     return linear(B(A), B(W8), B(bias), B(res), B(norm_w), B(C), M, N, K, lda, ldw, ldres, ldc, eps, epi, S(s), wscale);
 }
+int emu_linear_fp8_bf16(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias,
+                        const void* res, void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, int epi,
+                        emu_stream_t s) {
+    if (!A8 || !W8 || !a_scale || !w_scale || !C) return -22;
+    GemmArgs g{B(A8), B(W8), B(bias), B(res), B(C), M, N, K, lda, ldw, ldres, ldc, epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+    g.a_scale = a_scale; g.w_scale = w_scale;
+    return launch_gemm_fp8(g, S(s));
+}
 int emu_quantize_fp8_rows(const void* w, int ldw, void* q, int ldq, float* scale, int N, int K, emu_stream_t s) {
     if (!w || !q || !scale) return -22;
     return launch_quant_fp8_rows(B(w), ldw, reinterpret_cast<uint8_t*>(q), ldq, scale, N, K, S(s));

@@ -344,6 +344,17 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
 void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; }
 
+int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    if (a.M < 1 || a.N < 1 || !a.a_scale || !a.w_scale || (a.lda & 15) || (a.ldw & 15) || a.conv.mode != CONV_NONE) return -22;
+    if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
+    if (!gemm256_ok(a)) return -22;
+    if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
+    const int tp = gemm256_tiles(a);
+    const int ks = tp <= 128 && a.epi != EPI_SWIGLU && a.epi != EPI_GEGLU ? pick_ksplit<EPI_NONE>(a, tp, (int)EMU_GEMM256_SLICE_FLOATS, 8) : 0;
+    return ks >= 2 ? launch_gemm256(a, s, 0, ks) : launch_gemm256(a, s, -1, 1);
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7)) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;

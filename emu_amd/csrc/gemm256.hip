@@ -70,7 +70,10 @@ __host__ __device__ inline int pp_tiles_m(int M, bool allow_ext, int& ext_rows) 
 
 constexpr uint32_t OOB = 0x80000000u;    // beyond num_records of the descriptors below: the load returns zeros
 
-template <int EPI, bool CONV>
+// F8: both operands are OCP fp8 e4m3 bytes (a k tile is still 128 bytes per row = 128 elements), the MFMA is the gfx950
+// block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 rate), and the per-row scales of the
+// two operands (a.a_scale[m] * a.w_scale[n]) multiply the fp32 sums ahead of the epilogue.
+template <int EPI, bool CONV, bool F8>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * QXB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,10 +95,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         nsl = a.ksplit;
     }
     int ext_rows;
-    const int tiles_m = pp_tiles_m(a.M, !CONV, ext_rows);
+    constexpr uint32_t ESZ = F8 ? 1u : 2u;                          // bytes per element
+    const int tiles_m = pp_tiles_m(a.M, !CONV && !F8, ext_rows);
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
-    const bool ext = !CONV && ext_rows > 0 && tm == tiles_m - 1;  // this workgroup also owns rows m0 + 256 .. M - 1
+    const bool ext = !CONV && !F8 && ext_rows > 0 && tm == tiles_m - 1;  // this workgroup also owns rows m0 + 256 .. M - 1
 
     // ---- LDS-DMA sources.  Instruction i (0, 1) of a unit fills LDS rows r = i*64 + srow, srow = wave*8 + lane/8, slot
     // lane%8 <- global chunk slot ^ ((r >> 1) & 7).  P unit s: row r holds weight row n0 + (r >> 6)*128 + s*64 + (r & 63);
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     // of a ragged tile read zeros (no clamping).
     const int srow = wave * 8 + (lane >> 3);
     const uint32_t sck = (uint32_t)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);       // bytes
-    const uint32_t vP = (uint32_t)(n0 + srow) * (uint32_t)a.ldw * 2u + sck;
-    const uint32_t vQ = (uint32_t)(m0 + (srow >> 5) * 64 + (srow & 31)) * (uint32_t)a.lda * 2u + sck;     // plain GEMM
+    const uint32_t vP = (uint32_t)(n0 + srow) * (uint32_t)a.ldw * ESZ + sck;
+    const uint32_t vQ = (uint32_t)(m0 + (srow >> 5) * 64 + (srow & 31)) * (uint32_t)a.lda * ESZ + sck;     // plain GEMM
     uint32_t qpix[2][2];                             // CONV: output pixel (b << 22 | y << 11 | x) of every Q piece's row
     if constexpr (CONV) {
 #pragma unroll
@@ -122,15 +126,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 qpix[s][i] = (uint32_t)((pb << 22) | (py << 11) | px);
             }
     }
-    const uint32_t w_bytes = (uint32_t)a.N * (uint32_t)a.ldw * 2u;
-    const uint32_t a_bytes = CONV ? 0x7fffffffu : (uint32_t)a.M * (uint32_t)a.lda * 2u;
+    const uint32_t w_bytes = (uint32_t)a.N * (uint32_t)a.ldw * ESZ;
+    const uint32_t a_bytes = CONV ? 0x7fffffffu : (uint32_t)a.M * (uint32_t)a.lda * ESZ;
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a_bytes, 0x00020000);
     auto dma = [&](const __amdgpu_buffer_rsrc_t& r, uint32_t voff, int soff, char* lds_wave_base) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
     };
 
-    const int nk_all = a.K >> 6;
+    const int nk_all = F8 ? a.K >> 7 : a.K >> 6;                      // k tiles of 128 bytes per row
     const int kt0 = (int)((long)ks * nk_all / nsl);
     const int nk = (int)((long)(ks + 1) * nk_all / nsl) - kt0;
 
@@ -142,9 +146,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if constexpr (U == U_P0 || U == U_P1) {
-                dma(rW, vP, k0 * 2 + (i * 128 + S * 64) * a.ldw * 2, base + i * 8192);
+                dma(rW, vP, ((kt0 + tau) << 7) + (i * 128 + S * 64) * a.ldw * (int)ESZ, base + i * 8192);
             } else if constexpr (!CONV) {
-                dma(rA, vQ, k0 * 2 + (i * 128 + S * 32) * a.lda * 2, base + i * 8192);
+                dma(rA, vQ, ((kt0 + tau) << 7) + (i * 128 + S * 32) * a.lda * (int)ESZ, base + i * 8192);
             } else {
                 // implicit-GEMM gather: a 64-wide k tile lies inside one filter tap (Cin % 64 == 0)
                 const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
@@ -168,7 +172,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     // ---- fragment reads: lane (l31, hi) reads row base + l31, chunk (2*kk + hi) ^ swizzle(row), swizzle = (l31 >> 1) & 7
     int lp[4];                                      // P units: wave row wr owns LDS rows wr*64 .. +63
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) lp[kk] = l31 * 128 + ((((kk << 1) | hi) ^ ((l31 >> 1) & 7)) << 4) + wr * 8192;
+    for (int kk = 0; kk < 4; ++kk) {
+        // bf16: k step kk (16 wide) = chunk 2*kk + hi.  fp8: k step kk >> 1 (64 wide) = 32 bytes per lane = chunks
+        // 4*(kk >> 1) + 2*hi + (kk & 1): pieces 2s, 2s+1 of a fragment form one MFMA operand
+        const int chunk = F8 ? ((kk >> 1) << 2) | (hi << 1) | (kk & 1) : (kk << 1) | hi;
+        lp[kk] = l31 * 128 + ((chunk ^ ((l31 >> 1) & 7)) << 4) + wr * 8192;
+    }
     bf16x8_t pg[2][2][4], q0f[4], q1f[4], qxf[4];   // [P sub-tile][n fragment][k step]
     auto read_p = [&](bf16x8_t (&d)[2][4], const char* ub) {
 #pragma unroll
@@ -206,13 +215,31 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     }
     auto mma = [&](int y, const bf16x8_t (&q)[4]) {
         if (qv[y] && pv[0]) {                          // pv[1] implies pv[0]; an invalid second half only wastes MFMAs
+            if constexpr (!F8) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+                    for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[x][y][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pg[x][i][kk], q[kk], acc[x][y][i], 0, 0, 0);
+                        for (int i = 0; i < 2; ++i)
+                            acc[x][y][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pg[x][i][kk], q[kk], acc[x][y][i], 0, 0, 0);
+            } else {
+                typedef int v4i_t __attribute__((ext_vector_type(4)));
+                typedef int v8i_t __attribute__((ext_vector_type(8)));
+                auto op = [](const bf16x8_t& lo, const bf16x8_t& hi_) {
+                    return __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi_), 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const v8i_t qb = op(q[2 * st], q[2 * st + 1]);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[x][y][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                op(pg[x][i][2 * st], pg[x][i][2 * st + 1]), qb, acc[x][y][i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+            }
         }
     };
     auto mma_x = [&](auto xc, auto ic) {               // remainder rows x this wave's wc-th weight fragment
@@ -286,6 +313,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 
     // ---- epilogue: accumulator (x, y, i): rows n = n0 + wr*128 + x*64 + i*32 + 8*g + 4*hi + e, column m = .. + l31
     auto emit = [&](int m, int nb, float (&v)[4]) {
+        if constexpr (F8) {
+            if (nsl == 1) {                            // K-sliced: pp_reduce_kernel scales the summed slices
+                const float sa = a.a_scale[m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= sa * a.w_scale[nb + e < a.N ? nb + e : a.N - 1];
+            }
+        }
         if (nsl > 1) {                                 // raw fp32 slice tile; pp_reduce_kernel applies the epilogue
             float* dst = a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * SLICE + (size_t)(m - m0) * 256 + (nb - n0);
             *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -331,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 template <int EPI>
 __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
     int ext_rows;
-    const int tiles_m = pp_tiles_m(a.M, a.conv.mode == CONV_NONE, ext_rows);
+    const int tiles_m = pp_tiles_m(a.M, a.conv.mode == CONV_NONE && !a.a_scale, ext_rows);
     const int wg = a.full_tiles + blockIdx.x;
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
@@ -347,18 +381,22 @@ __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
             const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * SLICE + (size_t)lm * 256 + lq * 4);
             v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
         }
+        if (a.a_scale) {
+            const float sa = a.a_scale[m];
+            for (int e = 0; e < 4; ++e) v[e] *= sa * a.w_scale[nb + e < a.N ? nb + e : a.N - 1];
+        }
         store_quad<EPI>(a, m, nb, v);
     }
 }
 
-template <int EPI, bool CONV>
+template <int EPI, bool CONV, bool F8 = false>
 void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     const int tiles = gemm256_tiles(a);
     GemmArgs b = a;
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
     if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }
 
@@ -366,11 +404,15 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
 
 int gemm256_tiles(const GemmArgs& a) {
     int ext_rows;
-    return pp_tiles_m(a.M, a.conv.mode == CONV_NONE, ext_rows) * ((a.N + 255) / 256);
+    return pp_tiles_m(a.M, a.conv.mode == CONV_NONE && !a.a_scale, ext_rows) * ((a.N + 255) / 256);
 }
 
 // operand extents the 32-bit descriptor offsets can address, k tiles of 64
 bool gemm256_ok(const GemmArgs& a) {
+    if (a.a_scale) {                                   // fp8 operands: k tiles of 128 elements, plain GEMM only
+        if ((a.K & 127) || a.conv.mode != CONV_NONE || !a.w_scale) return false;
+        return (size_t)a.N * a.ldw < 0x7fffffffull && (size_t)a.M * a.lda < 0x7fffffffull;
+    }
     if (a.K & 63) return false;
     if (a.conv.mode != CONV_NONE && (a.conv.Hout > 2047 || a.conv.Wout > 2047 || a.M / (a.conv.Hout * a.conv.Wout) > 1023))
         return false;                                  // packed pixel coordinates of the gather
@@ -385,7 +427,16 @@ bool gemm256_ok(const GemmArgs& a) {
 // EMU_GEMM256_SLICE_FLOATS each in a.partial, summed by a second launch).  full_tiles < 0: no slicing.
 int launch_gemm256(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     if (!gemm256_ok(a)) return -22;
-    if (a.conv.mode != CONV_NONE) {
+    if (a.a_scale) {
+        switch (a.epi) {
+            case EPI_NONE:   launch_pp<EPI_NONE, false, true>(a, s, full_tiles, ksplit); break;
+            case EPI_RESID:  launch_pp<EPI_RESID, false, true>(a, s, full_tiles, ksplit); break;
+            case EPI_SWIGLU: launch_pp<EPI_SWIGLU, false, true>(a, s, full_tiles, ksplit); break;
+            case EPI_GELU:   launch_pp<EPI_GELU, false, true>(a, s, full_tiles, ksplit); break;
+            case EPI_GEGLU:  launch_pp<EPI_GEGLU, false, true>(a, s, full_tiles, ksplit); break;
+            default: return -22;
+        }
+    } else if (a.conv.mode != CONV_NONE) {
         switch (a.epi) {
             case EPI_NONE:  launch_pp<EPI_NONE, true>(a, s, full_tiles, ksplit); break;
             case EPI_RESID: launch_pp<EPI_RESID, true>(a, s, full_tiles, ksplit); break;

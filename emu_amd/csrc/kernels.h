@@ -47,11 +47,17 @@ struct GemmArgs {
     float* partial = nullptr;
     size_t partial_floats = 0;
     int ksplit = 1;         // set by launch_gemm: K-slices of the tail tiles
+    // fp8 GEMM (launch_gemm_fp8): A and W hold OCP e4m3 bytes (lda / ldw in elements = bytes), one fp32 scale per
+    // activation row / weight row; the fp32 sum is multiplied by a_scale[m] * w_scale[n] ahead of the epilogue
+    const float* a_scale = nullptr;
+    const float* w_scale = nullptr;
     int full_tiles = 0;     // set by launch_gemm: tiles [0, full_tiles) run whole-K (workgroups [0, full_tiles)); every
                             // later tile t is cut into ksplit slices (workgroup full_tiles + (t - full_tiles) * ksplit + ks)
                             // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// fp8 x fp8 -> bf16 on the block-scaled MFMA (256x256 ping-pong tile only): K % 128 == 0, a.a_scale / a.w_scale set
+int launch_gemm_fp8(const GemmArgs& a, hipStream_t s);
 // the 256x256 ping-pong tile (gemm256.hip), dispatched by launch_gemm; tiles [0, full_tiles) whole-K, the rest in ksplit
 // K-slices of EMU_GEMM256_SLICE_FLOATS fp32 each in a.partial (full_tiles < 0: no slicing)
 int launch_gemm256(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit);

@@ -73,6 +73,25 @@ def quantize_fp8_rows(w):
     return q, sc
 
 
+def linear_fp8(x8, xscale, w8, wscale, bias=None, res=None, epi: int = EPI_NONE, out=None):
+    """fp8 x fp8 GEMM (both operands from ``quantize_fp8_rows``) -> bf16; see emu_linear_fp8_bf16."""
+    _req(x8, "x8", torch.uint8); _req(w8, "w8", torch.uint8)
+    _req(xscale, "xscale", torch.float32); _req(wscale, "wscale", torch.float32)
+    assert x8.dim() == 2 and w8.dim() == 2 and x8.shape[1] == w8.shape[1], (x8.shape, w8.shape)
+    M, K = x8.shape
+    N = w8.shape[0]
+    n_out = N // 2 if epi in (EPI_SWIGLU, EPI_GEGLU) else N
+    if out is None:
+        out = torch.empty(M, n_out, device=x8.device, dtype=BF16)
+    _req(out, "out")
+    if res is not None:
+        _req(res, "res")
+    check(lib().emu_linear_fp8_bf16(_p(x8), _p(xscale), _p(w8), _p(wscale), _p(bias), _p(res), _p(out), M, N, K, x8.stride(0),
+                                    w8.stride(0), res.stride(0) if res is not None else 0, out.stride(0), int(epi), stream(x8)),
+          "emu_linear_fp8_bf16")
+    return out
+
+
 def linear_fp8w(x, w8, wscale, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = EPI_NONE, out=None):
     """``linear`` over an fp8 weight stream (decode rows only, M <= 2); see emu_linear_fp8w_bf16."""
     _req(x, "x"); _req(w8, "w8", torch.uint8); _req(wscale, "wscale", torch.float32)

@@ -73,6 +73,14 @@ int emu_linear_bf16(const void* A, const void* W, const void* bias, const void* 
  * epi in {NONE, RESID, SWIGLU}.  out = epi(bf16((sum_k fp8(W8[n,k]) * x[k]) * wscale[n] + bias[n])) */
 int emu_quantize_fp8_rows(const void* w_bf16, int ldw, void* q_fp8, int ldq, float* scale, int N, int K,
                           emu_stream_t s);   /* scale[n] = amax_n / 448 (1 if the row is zero); q = rne_e4m3fn(w / scale) */
+/* fp8 x fp8 GEMM on the block-scaled matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16 MFMA rate) for
+ * the MFMA-bound shapes of BASELINE configs[4] ("fp8 MFMA weights"): A8 [M, lda] and W8 [N, ldw] hold OCP e4m3fn bytes
+ * (both from emu_quantize_fp8_rows: one fp32 scale per row), K % 128 == 0, lda / ldw % 16 == 0.
+ *   C[m, n] = epi(bf16(a_scale[m] * w_scale[n] * sum_k fp8(A8[m,k]) * fp8(W8[n,k]) + bias[n]))   (fp32 accumulation)
+ * epi in {NONE, RESID, SWIGLU, GELU, GEGLU}.  Not a reference feature (the reference computes in bf16). */
+int emu_linear_fp8_bf16(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias,
+                        const void* res, void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, int epi,
+                        emu_stream_t s);
 int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, const void* bias, const void* res,
                          const void* norm_w, void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc,
                          float eps, int epi, emu_stream_t s);

@@ -211,3 +211,58 @@ def test_fp8_greedy_graph_equals_eager_and_tracks_oracle(tiny_fp8, golden_dir):
             break
     bf16_ids = m.generate_ids(ids, mask, None, max_new_tokens=n_new, stop_on_eos=False)
     assert bf16_ids.cpu().tolist() == z["new2"].tolist()                    # switching back restores the bf16 stream
+
+
+# ------------------------------------------------------------------------------------------------ fp8 x fp8 MFMA GEMM
+@pytest.mark.parametrize("M,N,K,epi", [(770, 2560, 6656, 0), (770, 1024, 17920, 1), (1025, 1536, 1792, 4), (2048, 2560, 1280, 5),
+                                       (300, 520, 384, 0), (256, 256, 128, 2), (1544, 4096, 6656, 2), (64, 512, 256, 1)])
+def test_fp8_mfma_gemm_matches_dequantised_reference(M, N, K, epi):
+    """emu_linear_fp8_bf16 (v_mfma_scale_f32_32x32x64_f8f6f4 on the 256x256 ping-pong tile): both operands quantised per row
+    by the library's quantiser; the checker is a torch fp32 GEMM on the exactly de-quantised operands (fp8 x fp8 products
+    are exact in fp32, so only the accumulation order differs), then the epilogue with the reference's bf16 rounding."""
+    import torch.nn.functional as F
+    from emu_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = (torch.randn(M, K, device="cuda", generator=g)).to(BF16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(BF16)
+    bias = (torch.randn(N, device="cuda", generator=g)).to(BF16) if epi in (0, 1, 4) else None
+    res = (torch.randn(M, N, device="cuda", generator=g)).to(BF16) if epi == 1 else None
+    x8, xs = ops.quantize_fp8_rows(x)
+    w8, ws = ops.quantize_fp8_rows(w)
+    got = ops.linear_fp8(x8, xs, w8, ws, bias=bias, res=res, epi=epi)
+    rep = ops.linear_fp8(x8, xs, w8, ws, bias=bias, res=res, epi=epi)
+    assert torch.equal(got, rep)
+    xd = x8.view(torch.float8_e4m3fn).float() * xs[:, None]
+    wd = w8.view(torch.float8_e4m3fn).float() * ws[:, None]
+    y = xd @ wd.t()
+    if bias is not None:
+        y = y + bias.float()
+    y = bfr(y)
+    if epi == 1:
+        y = bfr(y + res.float())
+    elif epi == 2:
+        y = bfr(bfr(F.silu(y[:, 0::2])) * y[:, 1::2])
+    elif epi == 4:
+        y = bfr(F.gelu(y))
+    elif epi == 5:
+        y = bfr(y[:, 0::2] * bfr(F.gelu(y[:, 1::2])))
+    err = (got.float() - y).abs()
+    tol = 1e-2 * float(y.abs().max()) + 2e-2 * y.abs()
+    assert not bool((err > tol).any()), (int((err > tol).sum()), float(err.max()), float(y.abs().max()))
+    # and the quantisation itself stays close to the bf16 product (per-row e4m3 on both operands: ~3 % relative L2)
+    if epi == 0:
+        full = bfr(x.float() @ w.float().t() + bias.float())
+        assert rel_err(got, full) < 6e-2
+
+
+def test_fp8_mfma_gemm_identity_asymmetric():
+    """A = I (exactly representable in e4m3, unit scales) against an asymmetric small-integer W: out[m, n] == W[n, m] exactly
+    -- catches any row / column / k-half swap in the 32x32x64 fragment maps."""
+    from emu_amd import ops
+    K = 256
+    x8 = torch.eye(K, device="cuda").to(torch.float8_e4m3fn).view(torch.uint8)
+    wi = ((torch.arange(320 * K, device="cuda").reshape(320, K) * 7) % 31 - 15).float()       # |w| <= 15: exact in e4m3
+    w8 = wi.to(torch.float8_e4m3fn).view(torch.uint8)
+    ones_m, ones_n = torch.ones(K, device="cuda"), torch.ones(320, device="cuda")
+    got = ops.linear_fp8(x8, ones_m, w8, ones_n)
+    assert torch.equal(got.float(), wi.t().contiguous())

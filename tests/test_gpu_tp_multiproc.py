@@ -1,0 +1,28 @@
+"""Tensor parallelism on real GPUs: the ENGINE (not a torch restatement) sharded over 2 / 4 ranks, one process per GPU over
+RCCL, must generate the golden fixture's greedy ids (the real reference's) with eager launches and under hipGraph replay.
+Needs >= 2 GPUs on the node: skipped on the 1-GPU runner (the CPU gloo tests cover the shard plan and data flow there)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_engine_tp_generates_reference_ids(world):
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs on this node (found {torch.cuda.device_count() if torch.cuda.is_available() else 0})")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "tp_engine_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
