@@ -244,6 +244,7 @@ struct emu_llama {
     const uint8_t* lm_head8 = nullptr;
     const float* lm_scale8 = nullptr;
     bool fp8_decode = false;
+    bool fp8_prefill = false;      // emu_llama_use_fp8(m, 2): W8A8 GEMMs for prefill rows as well
     const bf16_t *final_norm = nullptr, *lm_head = nullptr, *embed = nullptr, *cos = nullptr, *sin = nullptr;
     bf16_t *kcache = nullptr, *vcache = nullptr;
     int kv_batch = 0, s_max = 0;
@@ -252,6 +253,8 @@ struct emu_llama {
 namespace {
 struct LlamaWs {
     bf16_t *hB, *xn, *qkv, *attn, *act, *vt;
+    uint8_t* x8;            // prefill with fp8 weights: the current GEMM's activation rows as e4m3 bytes ...
+    float* xs;              // ... and their per-row scales
     float* dec;
     float* splitk;          // prefill only: K-slices of the GEMMs' tail round
     size_t splitk_floats;
@@ -274,8 +277,23 @@ LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
     w.dec = (float*)take(decode_fused_ws_floats(Bn, c.heads_local, c.head_dim, m->s_max > 0 ? m->s_max : 1) * sizeof(float));
     w.splitk_floats = M > 16 ? EMU_SPLITK_SCRATCH_FLOATS : 0;
     w.splitk = (float*)take(w.splitk_floats * sizeof(float));
+    const size_t kmax = std::max<size_t>(std::max<size_t>(c.hidden, HD), c.ffn_local);
+    w.x8 = (uint8_t*)take(M > 16 ? M * kmax : 0);
+    w.xs = (float*)take(M > 16 ? M * sizeof(float) : 0);
     w.total = off;
     return w;
+}
+
+// out = epi(fp8(A rows, quantised here) x fp8 weights): the prefill form of the fp8 weight set (emu_linear_fp8_bf16)
+int linear_q8(const LlamaWs& w, const bf16_t* A, int lda, const uint8_t* W8, const float* wscale, const bf16_t* res, bf16_t* C,
+              int M, int N, int K, int ldres, int ldc, int epi, hipStream_t s) {
+    int st = launch_quant_fp8_rows(A, lda, w.x8, K, w.xs, M, K, s);
+    if (st) return st;
+    GemmArgs g{reinterpret_cast<const bf16_t*>(w.x8), reinterpret_cast<const bf16_t*>(W8), nullptr, res, C, M, N, K, K, K, ldres, ldc,
+               epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+    g.a_scale = w.xs; g.w_scale = wscale;
+    g.partial = w.splitk; g.partial_floats = w.splitk_floats;
+    return launch_gemm_fp8(g, s);
 }
 }  // namespace
 
@@ -322,6 +340,7 @@ int emu_llama_use_fp8(emu_llama* m, int enable) {
     if (enable && m->layers8.size() != (size_t)m->cfg.layers)
         return fail(m->ctx, -22, "emu_llama_use_fp8: fp8 layer weights not set");
     m->fp8_decode = enable != 0;
+    m->fp8_prefill = enable == 2;
     return 0;
 }
 int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed, const void* rope_cos,
@@ -366,6 +385,9 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         bf16_t* vc = m->vcache + l * kv_layer;
         // ---- attention
         const bool f8 = m->fp8_decode && M <= 2;
+        // prefill with the fp8 weight set: activations are quantised per row ahead of every GEMM, the block-scaled MFMA
+        // runs at twice the bf16 rate (BASELINE configs[4]); needs whole 128-element k tiles
+        const bool f8p = m->fp8_prefill && M > 16 && !(H & 127) && !(HD & 127) && !(Fl & 127) && m->layers8[l].wqkv;
         const emu_llama::Layer8 L8 = f8 ? m->layers8[l] : emu_llama::Layer8{};
         if (f8 && !L8.wqkv) return fail(cx, -22, "emu_llama_forward: fp8 decode enabled but fp8 layer weights not set");
         if (f8) {
@@ -374,7 +396,8 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
         } else {                                     // 2..16 rows: norm once, skinny MFMA stream; more: GEMM
             TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
-            TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
+            if (f8p) TRY(cx, linear_q8(w, w.xn, H, m->layers8[l].wqkv, m->layers8[l].sqkv, nullptr, w.qkv, M, 3 * HD, H, 0, 3 * HD, EPI_NONE, s));
+            else TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
         }
         if (T == 1) {
             // RoPE + KV append + attention in one launch; context = slot + 1 is read on the device (graph replay)
@@ -393,6 +416,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, launch_flash_attn(f, s));
         }
         if (f8) TRY(cx, linear(w.attn, B(L8.wo), nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, L8.so));
+        else if (f8p) TRY(cx, linear_q8(w, w.attn, HD, m->layers8[l].wo, m->layers8[l].so, hA, w.hB, M, H, HD, H, H, epi_res, s));
         else TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, nullptr, w.splitk, w.splitk_floats));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, w.hB, (size_t)M * H, s_));
         // ---- SwiGLU MLP
@@ -402,9 +426,11 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, linear(w.hB, L.wgu, nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s));
         } else {
             TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
-            TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s));
+            if (f8p) TRY(cx, linear_q8(w, w.xn, H, m->layers8[l].wgu, m->layers8[l].sgu, nullptr, w.act, M, 2 * Fl, H, 0, Fl, EPI_SWIGLU, s));
+            else TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s));
         }
         if (f8) TRY(cx, linear(w.act, B(L8.wdown), nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, L8.sdown));
+        else if (f8p) TRY(cx, linear_q8(w, w.act, Fl, m->layers8[l].wdown, m->layers8[l].sdown, w.hB, hA, M, H, Fl, H, H, epi_res, s));
         else TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, nullptr, w.splitk, w.splitk_floats));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)M * H, s_));
     }

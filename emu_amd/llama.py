@@ -175,11 +175,12 @@ class LlamaEngine:
         self._fp8["lm_head"] = (q, sc)
         check(lib().emu_llama_set_head_fp8(self.handle, q.data_ptr(), sc.data_ptr()), "emu_llama_set_head_fp8")
 
-    def use_fp8(self, enable: bool = True) -> None:
-        """Switch the decode stream between the bf16 and the fp8 weights (invalidates captured decode graphs)."""
+    def use_fp8(self, enable: bool = True, prefill: bool = False) -> None:
+        """Switch the decode stream between the bf16 and the fp8 weights (invalidates captured decode graphs).
+        ``prefill=True`` also runs the prefill GEMMs W8A8 on the block-scaled fp8 MFMA (activations quantised per row)."""
         if enable:
             self.quantize_fp8()
-        check(lib().emu_llama_use_fp8(self.handle, int(bool(enable))), "emu_llama_use_fp8", self.ctx.handle)
+        check(lib().emu_llama_use_fp8(self.handle, (2 if prefill else 1) if enable else 0), "emu_llama_use_fp8", self.ctx.handle)
         self.fp8_decode = bool(enable)
 
     def fp8_dequantized(self, key: str) -> torch.Tensor:

@@ -152,8 +152,10 @@ int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* w
                         const void* wdown, const void* ln1, const void* ln2);
 /* Optional fp8 decode stream (not in the reference, which runs bf16 end to end -- Emu2/emu/chat.py:199-213; this is
  * the weight-only quantised serving mode of BASELINE.json configs[5]).  W8: OCP e4m3fn bytes in the SAME packed row
- * layout as the bf16 weight; scale: fp32 [rows], W ~= fp8 * scale[row].  Only decode rows (B*T <= 2) use them; prefill
- * keeps the bf16 weights.  emu_llama_use_fp8 toggles the stream (fails if the fp8 tensors were not registered). */
+ * layout as the bf16 weight; scale: fp32 [rows], W ~= fp8 * scale[row].  emu_llama_use_fp8(m, 1): decode rows (B*T <= 2)
+ * stream them, prefill keeps the bf16 weights; (m, 2): prefill rows (B*T > 16) run W8A8 GEMMs as well -- activations
+ * quantised per row ahead of every GEMM, emu_linear_fp8_bf16 -- when hidden, heads_local*head_dim and ffn_local are
+ * multiples of 128 (BASELINE.json configs[4], "fp8 MFMA weights"); (m, 0): bf16.  Fails if the fp8 tensors were not registered. */
 int emu_llama_set_layer_fp8(emu_llama* m, int layer, const void* wqkv8, const float* sqkv, const void* wo8,
                             const float* so, const void* wgu8, const float* sgu, const void* wdown8,
                             const float* sdown);

@@ -266,3 +266,35 @@ def test_fp8_mfma_gemm_identity_asymmetric():
     ones_m, ones_n = torch.ones(K, device="cuda"), torch.ones(320, device="cuda")
     got = ops.linear_fp8(x8, ones_m, w8, ones_n)
     assert torch.equal(got.float(), wi.t().contiguous())
+
+
+def test_fp8_prefill_true_width_layer_tracks_bf16():
+    """One LLaMA-33B-shaped decoder layer (6656 / 52 heads / 17920), S = 300 prompt rows: prefill with use_fp8(prefill=True)
+    (W8A8 GEMMs on the block-scaled MFMA, activations quantised per row) stays within 0.2 relative L2 of the bf16 prefill on
+    random N(0, 0.02) weights (measured 0.13: four chained GEMMs with two e4m3 roundings each, ~5 % per GEMM, nothing to
+    average the error down on unstructured weights) -- a plumbing check, not a parity claim: the reference has no fp8 mode and
+    the GEMM itself is pinned exactly in test_fp8_mfma_gemm_matches_dequantised_reference -- and is deterministic."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import LlamaCfg
+    from emu_amd.llama import EmuHipContext, LlamaEngine
+    l = LlamaCfg(num_hidden_layers=1)
+    eng = LlamaEngine(l, 256, EmuHipContext(torch.device("cuda", 0)))
+    eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, 256), device="cuda", dtype=BF16))
+    S = 300
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, S, l.hidden_size, generator=g).to(BF16).cuda()
+    mask = torch.ones(1, S, dtype=torch.long)
+    s_max = eng.kv_capacity(S + 8)
+    ref, _, _ = eng.prefill(x.clone(), mask, s_max)
+    ref = ref.clone()
+    eng.use_fp8(True, prefill=True)
+    try:
+        a, _, _ = eng.prefill(x.clone(), mask, s_max)
+        a = a.clone()
+        b, _, _ = eng.prefill(x.clone(), mask, s_max)
+        assert torch.equal(a, b)
+    finally:
+        eng.use_fp8(False)
+    assert bool(torch.isfinite(a.float()).all())
+    assert rel_err(a, ref) < 0.2, rel_err(a, ref)
+    assert rel_err(a, ref) > 1e-4                    # the fp8 path really ran
