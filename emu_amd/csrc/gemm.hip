@@ -269,24 +269,45 @@ int pick_ksplit(const GemmArgs& a, int tiles, int tile_elems, int min_k) {
     return ksplit;
 }
 
-// Does the 256x256 ping-pong tile (gemm256.hip) take this problem?  0 = no, 1 = whole-K workgroups, >= 2 = K-slices.
-// From tools/gemm_ab.py on MI355X (profiles/r02_gemm_ab_v8_dispatch.log): the tile wins wherever it fills most of a round
-// of CUs with enough k tiles to amortise its pipeline fill and 64K-element epilogue -- LLaMA prefill qkv / gate-up
-// (+30-60 % over the 128x128 / 256x128 tiles), every S >= 1024 shape, ViT fc1, the UNet's 64^2 / 128^2 levels -- and, cut
-// into K-slices, the few-tile long-K problems (prefill o / down +20-40 %, the 32^2-level convs +10 %).  It loses where a
-// round is badly quantised (320 tiles = 1.25 rounds), on short-K few-tile GEMMs (ViT qkv / proj, the UNet's K = 1280
-// projections) and on thin prompts (M < 192).
-template <int EPI>
-int pick_pp(const GemmArgs& a) {
-    if (!gemm256_ok(a) || a.M < 192) return 0;
-    const int tp = gemm256_tiles(a), nk = a.K / BK;
-    if (tp >= 180) {
-        const int rounds = (tp + 255) / 256;
-        return (nk >= 8 && tp * 10 >= rounds * 256 * 7) ? 1 : 0;
+// How the 256x256 ping-pong tile (gemm256.hip) is spread over the 256 CUs: `full` tiles by one workgroup each, every
+// later tile cut into `ks` K-slices (fp32 slabs + a reduce launch).  A cost model picks ks for the tiles beyond the last
+// whole round (all of them when there are fewer tiles than CUs): rounds of workgroups x the time of one slice, plus what
+// the slabs cost (288 KiB written and read per slice at ~4 TB/s) and the second launch.  Checked against tools/gemm_ab.py
+// (profiles/r02_gemm_ab_v10_tail_slices.log): S=770 o / down 3 slices (+75 % / +100 % over one workgroup per tile),
+// S=1544 down 3 slices (+13 %), S=770 gate/up none (420 tiles: 2 rounds either way), S=1544 gate/up 2-3 slices (+3 %).
+struct PpPlan { bool use; int full_tiles, ksplit; double us; };
+inline PpPlan plan_pp(const GemmArgs& a) {
+    const int tp = gemm256_tiles(a), nk = a.K / BK, CU = 256;
+    const double t_tile = 256.0 * 256.0 * a.K * 2.0 / 5.4e6;           // us: one CU at ~55 % of its share of the MFMA peak
+    const int rem = tp % CU, full = tp - rem;
+    PpPlan best{true, tp, 1, (double)((tp + CU - 1) / CU) * t_tile};
+    if (rem == 0 || (a.N & 3) || !a.partial) return best;
+    for (int ks = 2; ks <= 8; ++ks) {
+        if (nk / ks < 8) break;
+        if ((size_t)rem * ks * EMU_GEMM256_SLICE_FLOATS > a.partial_floats) break;
+        const double us = (full / CU + (double)((rem * ks + CU - 1) / CU) / ks) * t_tile + rem * ks * 0.144 + 8.0;
+        if (us < best.us * 0.95) best = PpPlan{true, full, ks, us};
     }
-    const int ks = pick_ksplit<EPI>(a, tp, (int)EMU_GEMM256_SLICE_FLOATS, 16);
-    if (ks >= 2 && tp * ks >= 150) return ks;
-    return (tp >= 150 && nk >= 32) ? 1 : 0;
+    return best;
+}
+
+// Does the 256x256 ping-pong tile take this problem?  From tools/gemm_ab.py on MI355X (profiles/r02_gemm_ab_*): it wins
+// wherever a workgroup gets enough k tiles to amortise its pipeline fill and 64K-element epilogue -- LLaMA prefill
+// (+30-60 % over the 128x128 / 256x128 tiles), every S >= 1024 shape, ViT fc1 / fc2, the UNet's 64^2 / 128^2 levels and
+// convs -- and loses on short-K few-tile GEMMs (ViT qkv / proj, the UNet's K = 1280 projections), on a badly quantised
+// round of short-K tiles (320 tiles, K = 1280) and on thin prompts (M < 192).
+inline PpPlan pick_pp(const GemmArgs& a) {
+    PpPlan no{false, 0, 1, 0.0};
+    if (!gemm256_ok(a) || a.M < 192) return no;
+    const int tp = gemm256_tiles(a), nk = a.K / BK, CU = 256;
+    const PpPlan p = plan_pp(a);
+    if (tp >= 180) {
+        if (nk < 8) return no;
+        const int rounds = (tp + CU - 1) / CU;
+        return (p.ksplit > 1 || tp * 10 >= rounds * CU * 7) ? p : no;
+    }
+    if (p.ksplit > 1 && nk / p.ksplit >= 16 && tp * p.ksplit >= 150) return p;
+    return (tp >= 150 && nk >= 32) ? PpPlan{true, tp, 1, 0.0} : no;
 }
 
 template <int EPI, bool CONV>
@@ -298,8 +319,8 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
     if (cfg == 'S' && !k64) cfg = 0;
     if ((cfg == 'P' || cfg == 'Q') && !gemm256_ok(a)) cfg = 0;
     if (!cfg) {
-        const int pp = pick_pp<EPI>(a);
-        if (pp) return pp > 1 ? launch_gemm256(a, s, 0, pp) : launch_gemm256(a, s, -1, 1);
+        const PpPlan pp = pick_pp(a);
+        if (pp.use) return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
         // The 256x128 tile moves the fewest bytes per FLOP through L2 of the lock-step tiles (the binding resource of
         // these kernels) but runs one workgroup per CU: a 2048 x 1280 output is only 80 tiles (0.31 round).  Problems
         // with fewer tiles than CUs are cut into K-slices so they fill the CUs once: fp32 slice tiles land in a
@@ -319,10 +340,9 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
     }
     switch (cfg) {
         case 'Q': return launch_gemm256(a, s, -1, 1);  // 256x256 ping-pong, never K-sliced (A/B)
-        case 'P': {                                   // 256x256 ping-pong, K-sliced when it has under half a round of tiles
-            const int tp = gemm256_tiles(a);
-            const int ksplit = tp <= 128 ? pick_ksplit<EPI>(a, tp, (int)EMU_GEMM256_SLICE_FLOATS, 8) : 0;
-            return ksplit ? launch_gemm256(a, s, 0, ksplit) : launch_gemm256(a, s, -1, 1);
+        case 'P': {                                   // 256x256 ping-pong with the planned K-slices, whatever the shape
+            const PpPlan pp = plan_pp(a);
+            return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
         }
         case 'S': {
             const int tc = tiles_of(a, 256, 128);
@@ -350,9 +370,8 @@ int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
     if (!gemm256_ok(a)) return -22;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
-    const int tp = gemm256_tiles(a);
-    const int ks = tp <= 128 && a.epi != EPI_SWIGLU && a.epi != EPI_GEGLU ? pick_ksplit<EPI_NONE>(a, tp, (int)EMU_GEMM256_SLICE_FLOATS, 8) : 0;
-    return ks >= 2 ? launch_gemm256(a, s, 0, ks) : launch_gemm256(a, s, -1, 1);
+    const PpPlan pp = plan_pp(a);
+    return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {

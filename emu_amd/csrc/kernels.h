@@ -65,7 +65,7 @@ int gemm256_tiles(const GemmArgs& a);           // workgroups of a whole-K launc
 bool gemm256_ok(const GemmArgs& a);             // K % 64 == 0 and operands within reach of 32-bit descriptor offsets
 constexpr size_t EMU_GEMM256_SLICE_FLOATS = 288 * 256;
 // scratch that always suffices: at most 256 slices (one per CU) of the largest tile (256 x 256 + 32 remainder rows, fp32)
-constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)256 * 288 * 256;
+constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)512 * 288 * 256;
 // process-wide default split-K scratch for callers that do not pass one (the C-ABI primitives); caller-owned memory
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
 // test / bench hook: pin the tile configuration ('B', 'C', 'K', 'S', 'P'; 0 = heuristic)

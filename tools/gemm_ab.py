@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     a = ap.parse_args()
     L = lib()
-    sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")
+    sk = torch.zeros(512 * 288 * 256, dtype=torch.float32, device="cuda")
     L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
     g = torch.Generator(device="cuda").manual_seed(0)
 
