@@ -132,15 +132,13 @@ class EmuChatGeneration:
     @classmethod
     def from_pretrained(cls, path: str, instruct: bool = False, dtype: torch.dtype = torch.bfloat16,
                         use_safetensors: bool = False, **kwargs):
-        """chat.py:197-213: single-file checkpoint (.pth via torch.load or safetensors), strict key match.  Weights are
+        """chat.py:197-213: single-file checkpoint (.pth via torch.load or safetensors), strict key match -- or a Hugging Face
+        sharded checkpoint (directory / ``*.index.json``), streamed shard by shard (emu_amd/checkpoint.py).  Weights are
         always stored bf16 on the device (``dtype`` is accepted for signature compatibility)."""
+        from .checkpoint import find_index, iter_checkpoint
         ins = cls.from_config(instruct=instruct, **kwargs)
-        if use_safetensors:
-            from safetensors.torch import load_file
-            state_dict = load_file(path)
-        else:
-            state_dict = torch.load(path, map_location="cpu")
-        ins.emu_model.load_state_dict(state_dict, strict=True)
+        st = use_safetensors if find_index(path) is None else None
+        ins.emu_model.load_weights(iter_checkpoint(path, st), strict=True)
         return ins
 
     def multito(self, device_list: List[Union[str, torch.device]]):

@@ -173,12 +173,9 @@ class EmuVisualGeneration:
     @classmethod
     def from_pretrained(cls, model_path: str, config_path: Optional[str] = None, dtype: torch.dtype = torch.bfloat16,
                         use_safetensors: bool = True, **kwargs):
+        from .checkpoint import find_index, iter_checkpoint
         ins = cls.from_config(**kwargs)
-        if use_safetensors:
-            from safetensors.torch import load_file
-            sd = load_file(model_path)
-        else:
-            sd = torch.load(model_path, map_location="cpu")
+        sd = dict(iter_checkpoint(model_path, use_safetensors if find_index(model_path) is None else None))
         ins.load_state_dict(sd, strict=True)
         return ins
 
