@@ -112,6 +112,15 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise EmuHipError(f"{LIB_PATH} not found: build it with `python -m emu_amd.build` "
                               "(there is no CPU fallback in emu_amd)")
+        # Bring torch's HIP runtime up BEFORE the library is mapped: mapped first and initialised second, the library's
+        # HIP calls fail with hipErrorNoDevice (measured: build() + smoke() in one process); the other order shares one
+        # initialised runtime.  No GPU (the CPU-side build / symbol check): nothing to initialise.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
