@@ -276,12 +276,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    # validation hook, not a measurement: EMU_TP_SHARED_GPU=1 puts every rank on cuda:0 (RCCL refuses that, so gloo rendezvous
+    # and the peer-to-peer all-reduce for every message) to run the full-size TP data path on a 1-GPU box
+    shared = world > 1 and os.environ.get("EMU_TP_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rdev = "cpu" if shared else dev
 
     from emu_amd import CLIPVisionCfg, LlamaCfg, TextDecoderCfg, synth
     from emu_amd._lib import lib, check
@@ -302,7 +311,15 @@ def main():
             box = [b]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        ctx.init_tp(bcast)
+
+        def allgather(b):
+            box = [None] * world
+            dist.all_gather_object(box, b)
+            return box
+        # RCCL for the prefill-sized messages; the one-shot peer-to-peer all-reduce (csrc/p2p.hip) for the 13 KB decode ones when
+        # its self-test passes on every rank (EMU_TP_P2P=0 keeps everything on RCCL)
+        ctx.init_tp(bcast, allgather_bytes=allgather if os.environ.get("EMU_TP_P2P", "1") != "0" else None, rccl=not shared)
+        log(f"rank {rank}: decode all-reduce = {'one-shot P2P over IPC' if ctx.p2p else 'RCCL'}")
 
     vcfg = CLIPVisionCfg(n_query=256, v_query=64, layers=a.vit_layers)          # Emu2-Chat: n_query 256 (chat.py:221-223)
     lcfg = LlamaCfg(num_hidden_layers=a.layers)
@@ -404,7 +421,7 @@ def main():
         sync()
         dt = time.perf_counter() - t
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     tok_s = a.steps / dt
@@ -457,7 +474,7 @@ def main():
                     step8()
                 sync(); dt8 = time.perf_counter() - t
                 if world > 1:
-                    tt = torch.tensor([dt8], device=dev, dtype=torch.float64)
+                    tt = torch.tensor([dt8], device=rdev, dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     dt8 = float(tt.item())
                 check(lib().emu_profile_gemv(1), "emu_profile_gemv")
@@ -548,8 +565,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: Emu2-Chat 37B text generate, 1x448x448 image "
                                    f"(256 visual tokens) + {a.prompt_tokens}-token prompt (S={S}), greedy, batch 1",
                        "decoder_layers": lcfg.num_hidden_layers, "vit_layers": vcfg.layers,
-                       "parallelism": f"tp{world}", "launch": "hipGraph replay" if use_graph else "eager",
-                       "valid": bool(a.layers == 60 and a.vit_layers == 64)},
+                       "parallelism": f"tp{world}" + (" (ranks sharing one GPU: validation only)" if shared else ""), "allreduce": ("p2p one-shot (<=256 KiB) + rccl" if ctx.p2p else "rccl") if world > 1 else None,
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "valid": bool(a.layers == 60 and a.vit_layers == 64 and not shared)},
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel (weight-streaming GEMV, all epilogues)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

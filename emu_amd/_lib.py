@@ -49,6 +49,11 @@ _PROTOS = {
     "emu_tp_unique_id": (i32, [vp]),
     "emu_tp_init": (i32, [vp, vp]),
     "emu_allreduce_bf16": (i32, [vp, vp, sz, vp]),
+    "emu_tp_p2p_create": (i32, [vp, vp]),
+    "emu_tp_p2p_open": (i32, [vp, vp, i32]),
+    "emu_tp_p2p_allreduce_bf16": (i32, [vp, vp, sz, vp]),
+    "emu_tp_p2p_enable": (i32, [vp, i32]),
+    "emu_tp_p2p_giveups": (C.c_uint, []),
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_set_splitk_scratch": (None, [vp, sz]),
     "emu_gemm_force_config": (None, [i32]),

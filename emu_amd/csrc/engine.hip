@@ -15,6 +15,8 @@
 struct emu_ctx {
     int device = 0, tp_rank = 0, tp_size = 1;
     ncclComm_t comm = nullptr;
+    EmuP2p* p2p = nullptr;                          // one-shot all-reduce blocks (p2p.hip); used only once enabled
+    bool p2p_on = false;
     std::string err;
 };
 
@@ -114,6 +116,7 @@ int emu_ctx_create(int device, int tp_rank, int tp_size, emu_ctx** out) {
 void emu_ctx_destroy(emu_ctx* ctx) {
     if (!ctx) return;
     if (ctx->comm) ncclCommDestroy(ctx->comm);
+    emu_p2p_destroy(ctx->p2p);
     delete ctx;
 }
 
@@ -140,8 +143,44 @@ int emu_tp_init(emu_ctx* ctx, const void* id128) {
     return 0;
 }
 
+int emu_tp_p2p_create(emu_ctx* ctx, void* handle64_out) {
+    if (!ctx || !handle64_out) return -22;
+    if (ctx->p2p) return fail(ctx, -17, "emu_tp_p2p_create: already created");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, (int)e, "hipSetDevice");
+    ctx->p2p = emu_p2p_create(ctx->tp_rank, ctx->tp_size, handle64_out);
+    return ctx->p2p ? 0 : fail(ctx, -12, "emu_tp_p2p_create: comm block allocation / IPC export failed");
+}
+
+int emu_tp_p2p_open(emu_ctx* ctx, const void* handles, int timeout_ms) {
+    if (!ctx || !ctx->p2p) return -22;
+    emu_p2p_set_timeout_ms(ctx->p2p, timeout_ms);
+    int st = emu_p2p_open(ctx->p2p, handles);
+    return st == 0 ? 0 : fail(ctx, st, "hipIpcOpenMemHandle");
+}
+
+int emu_tp_p2p_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s) {
+    if (!ctx || !ctx->p2p) return -22;
+    int st = emu_p2p_allreduce(ctx->p2p, reinterpret_cast<bf16_t*>(buf), n, S(s));
+    return st == 0 ? 0 : fail(ctx, st, "emu_p2p_allreduce");
+}
+
+int emu_tp_p2p_enable(emu_ctx* ctx, int on) {
+    if (!ctx || (on && !ctx->p2p)) return -22;
+    ctx->p2p_on = on != 0;
+    return 0;
+}
+
+unsigned int emu_tp_p2p_giveups(void) { return emu_p2p_giveups_read(); }
+
 int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s) {
     if (!ctx) return -22;
+    // small messages (decode: 13 KB) take the one-shot P2P path once the host has enabled it; without a RCCL communicator
+    // (two ranks on one GPU in the tests) everything does, in slot-sized chunks
+    if (ctx->p2p_on && (n * sizeof(bf16_t) <= EMU_P2P_SLOT_BYTES || !ctx->comm)) {
+        int st = emu_p2p_allreduce(ctx->p2p, reinterpret_cast<bf16_t*>(buf), n, S(s));
+        return st == 0 ? 0 : fail(ctx, st, "emu_p2p_allreduce");
+    }
     if (!ctx->comm) {
         if (ctx->tp_size == 1) return 0;
         return fail(ctx, -107, "emu_allreduce_bf16: communicator not initialised (emu_tp_init)");

@@ -181,3 +181,14 @@ int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out
 // per-row fp8 e4m3fn quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = rne(w / scale)
 int launch_quant_fp8_rows(const bf16_t* w, int ldw, uint8_t* q, int ldq, float* scale, int N, int K, hipStream_t s);
 int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s);
+
+// ---- one-shot peer-to-peer all-reduce over IPC-mapped comm blocks (p2p.hip)
+constexpr int EMU_P2P_MAX_RANKS = 8;
+constexpr size_t EMU_P2P_SLOT_BYTES = 256 * 1024;
+struct EmuP2p;
+EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out);          // nullptr on failure
+int emu_p2p_open(EmuP2p* p, const void* handles);                      // n x 64 bytes, rank order (own entry ignored)
+void emu_p2p_destroy(EmuP2p* p);
+void emu_p2p_set_timeout_ms(EmuP2p* p, int ms);
+int emu_p2p_allreduce(EmuP2p* p, bf16_t* x, size_t n, hipStream_t s);  // in place; > one slot goes through in chunks
+unsigned int emu_p2p_giveups_read();

@@ -1,0 +1,188 @@
+// One-shot peer-to-peer all-reduce for the tensor-parallel decoder's small messages (decode: 13 KB per all-reduce, 120 per
+// token) over xGMI, instead of 120 latency-bound RCCL collectives per token.
+//
+// Every rank owns one COMM BLOCK in its own HBM (uncached, exported with hipIpcGetMemHandle and mapped by every peer):
+// two data slots of P2P_SLOT_BYTES and 64-bit flags per slot.  A message is cut into 8 KiB pieces, one workgroup and one
+// 16-byte vector per lane each (13 KB = 2 workgroups, 256 KiB = 32), and every piece runs the protocol on its own counter,
+// flag and slot region.  All-reduce number s of a piece (a device-side counter, so a captured hipGraph replays correctly)
+// uses slot s & 1:
+//   1. copy my partial vector into MY slot, system-scope release, flag[slot] = s;
+//   2. for every rank r in rank order (my own included): wait until r's flag[slot] >= s (system-scope acquire), read r's
+//      slot over xGMI, add in fp32 -- the same order on every rank, so all ranks hold bit-identical sums;
+//   3. round to bf16 in place.
+// Point-to-point xGMI means every rank reads the other N - 1 vectors directly (N - 1 links busy per rank, one hop, no
+// ring): for 13 KB the cost is one flag round trip + one remote read, not 2 (N - 1) ring steps.
+// Slot reuse is safe with two slots: a rank rewrites slot s & 1 at all-reduce s + 2, which it reaches only after finishing
+// s + 1, which needed every peer's s + 1 vector, which a peer publishes only after its reads of all-reduce s are done.
+// Every wait is BOUNDED in wall-clock time (s_memrealtime, 100 MHz): past the limit a give-up counter is raised, the kernel
+// proceeds, and every later all-reduce skips its wait, so a dead peer or a platform problem costs one time-out, never a hung
+// GPU.  The host reads the counter (emu_tp_p2p_giveups) after the self-test at initialisation -- a failed self-test keeps the
+// path on RCCL -- and after every generation, where a non-zero count is an error (the sums are garbage).
+// Messages larger than a slot go through it in chunks (tests on one GPU); production sends them to RCCL (engine.hip).
+//
+// Replaces (with emu_amd/tp.py) the reference's layer-placement "model parallel": Emu2/emu/mixin.py:14-85, chat.py:235-283.
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ unsigned int g_p2p_giveups = 0;
+
+struct P2pPeers {
+    char* block[EMU_P2P_MAX_RANKS];                 // every rank's comm block as mapped in THIS process (own block included)
+    int n, rank;
+    long long limit_ticks;                          // wait bound in s_memrealtime ticks (100 MHz)
+};
+
+// piece g of a message: elements [g * P2P_PIECE, (g + 1) * P2P_PIECE), one 16-byte vector per lane of workgroup g, which runs
+// its own instance of the protocol (own sequence counter, own flag per slot, own 8 KiB of each slot)
+constexpr int P2P_PIECE = 512 * 8;
+constexpr int P2P_PIECES = (int)(EMU_P2P_SLOT_BYTES / (P2P_PIECE * 2));
+
+__device__ __forceinline__ unsigned long long* flag_of(char* block, int slot, int g) {
+    return reinterpret_cast<unsigned long long*>(block + 2 * EMU_P2P_SLOT_BYTES) + slot * P2P_PIECES + g;
+}
+
+__global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned long long* seq_counter, bf16_t* x, int n) {
+    __shared__ unsigned long long s_sh;
+    const int tid = threadIdx.x, g = blockIdx.x;
+    if (tid == 0) { s_sh = seq_counter[g] + 1; seq_counter[g] = s_sh; }   // launches of one stream are ordered: no race
+    __syncthreads();
+    const unsigned long long s = s_sh;
+    const int slot = (int)(s & 1);
+    const int e0 = g * P2P_PIECE + tid * 8;                                 // my 8 elements
+    const size_t off = (size_t)slot * EMU_P2P_SLOT_BYTES + (size_t)e0 * 2;
+    const bool full = e0 + 8 <= n, part = e0 < n;
+    // ---- 1. publish my piece
+    if (part) {
+        u32x4 v;
+        if (full) v = ld16(x + e0);
+        else {
+            bf16_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; e0 + j < n; ++j) t[j] = x[e0 + j];
+            v = *reinterpret_cast<u32x4*>(t);
+        }
+        *reinterpret_cast<u32x4*>(p.block[p.rank] + off) = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag_of(p.block[p.rank], slot, g), s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- 2. wait for every rank's piece of this sequence number
+    if (tid < p.n) {
+        unsigned long long* f = flag_of(p.block[tid], slot, g);
+        const bool dead = __hip_atomic_load(&g_p2p_giveups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < s) {
+            if (dead || wall_clock64() - t0 > p.limit_ticks) { atomicAdd(&g_p2p_giveups, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();                                                // every wave: nothing of this slot's previous use is cached
+    // ---- 3. sum in rank order, fp32
+    if (part) {
+        u32x4 v[EMU_P2P_MAX_RANKS];
+#pragma unroll
+        for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r)
+            if (r < p.n) v[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.block[r] + off));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r)
+            if (r < p.n) {
+                float f[8];
+                unpack8(v[r], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        if (full) st16(x + e0, pack8(acc));
+        else for (int j = 0; e0 + j < n; ++j) x[e0 + j] = f2bf(acc[j]);
+    }
+}
+
+}  // namespace
+
+struct EmuP2p {
+    char* mine = nullptr;                           // my comm block (device memory owned by this object)
+    char* block[EMU_P2P_MAX_RANKS] = {};
+    bool opened[EMU_P2P_MAX_RANKS] = {};
+    unsigned long long* seq = nullptr;              // device-side sequence counters, one per piece (plain device memory)
+    int n = 0, rank = 0;
+    long long limit_ticks = 10LL * 100000000LL;     // 10 s
+};
+
+EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out) {
+    if (n < 1 || n > EMU_P2P_MAX_RANKS || rank < 0 || rank >= n) return nullptr;
+    EmuP2p* p = new EmuP2p();
+    p->n = n; p->rank = rank;
+    const size_t bytes = 2 * EMU_P2P_SLOT_BYTES + 2 * P2P_PIECES * sizeof(unsigned long long);
+    void* ptr = nullptr;
+    // uncached (what RCCL uses for its own peer-visible buffers on gfx94x/gfx950), else fine-grained, else plain device memory:
+    // the kernel's system-scope release / acquire pairs are sufficient for any of the three.
+    if (hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMalloc(&ptr, bytes) != hipSuccess) { delete p; return nullptr; }
+        }
+    }
+    p->mine = reinterpret_cast<char*>(ptr);
+    if (hipMemset(p->mine, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&p->seq), P2P_PIECES * 8) != hipSuccess ||
+        hipMemset(p->seq, 0, P2P_PIECES * 8) != hipSuccess) { emu_p2p_destroy(p); return nullptr; }
+    (void)hipDeviceSynchronize();
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle is 64 bytes");
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, p->mine) != hipSuccess) { emu_p2p_destroy(p); return nullptr; }
+    memcpy(handle64_out, &h, 64);
+    p->block[rank] = p->mine;
+    return p;
+}
+
+int emu_p2p_open(EmuP2p* p, const void* handles) {
+    if (!p || !handles) return -22;
+    for (int r = 0; r < p->n; ++r) {
+        if (r == p->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, reinterpret_cast<const char*>(handles) + 64 * r, 64);
+        void* ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return (int)e;
+        p->block[r] = reinterpret_cast<char*>(ptr);
+        p->opened[r] = true;
+    }
+    return 0;
+}
+
+void emu_p2p_destroy(EmuP2p* p) {
+    if (!p) return;
+    for (int r = 0; r < p->n; ++r)
+        if (p->opened[r]) (void)hipIpcCloseMemHandle(p->block[r]);
+    if (p->mine) (void)hipFree(p->mine);
+    if (p->seq) (void)hipFree(p->seq);
+    delete p;
+}
+
+int emu_p2p_allreduce(EmuP2p* p, bf16_t* x, size_t n, hipStream_t s) {
+    if (!p || !x) return -22;
+    for (int r = 0; r < p->n; ++r)
+        if (!p->block[r]) return -107;                                     // peers not mapped yet
+    P2pPeers peers;
+    for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r) peers.block[r] = r < p->n ? p->block[r] : nullptr;
+    peers.n = p->n; peers.rank = p->rank; peers.limit_ticks = p->limit_ticks;
+    const size_t chunk = EMU_P2P_SLOT_BYTES / 2;                           // elements per slot
+    for (size_t o = 0; o < n; o += chunk) {
+        const int m = (int)(n - o < chunk ? n - o : chunk);
+        hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((m + P2P_PIECE - 1) / P2P_PIECE), dim3(512), 0, s, peers, p->seq, x + o, m);
+    }
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+void emu_p2p_set_timeout_ms(EmuP2p* p, int ms) { if (p && ms > 0) p->limit_ticks = (long long)ms * 100000LL; }
+
+unsigned int emu_p2p_giveups_read() {
+    unsigned int v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_p2p_giveups), sizeof v);
+    return v;
+}

@@ -40,26 +40,73 @@ class EmuHipContext:
         if self.device.type != "cuda":
             raise ValueError("emu_amd needs a GPU device (no CPU path)")
         self.tp_rank, self.tp_size = tp_rank, tp_size
+        self.p2p = False
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         check(lib().emu_ctx_create(idx, tp_rank, tp_size, C.byref(h)), "emu_ctx_create")
         self.handle = h
 
-    def init_tp(self, broadcast_bytes, force: bool = False) -> None:
+    def init_tp(self, broadcast_bytes, force: bool = False, allgather_bytes=None, rccl: bool = True,
+                p2p_timeout_ms: int = 0) -> None:
         """Create the RCCL communicator.  ``broadcast_bytes(b: bytes|None) -> bytes`` must return rank 0's
         128-byte unique id on every rank (e.g. via the torch.distributed store).  ``force`` creates a communicator
-        even for tp_size 1 (a 1-rank RCCL all-reduce: used to exercise the RCCL + hipGraph path on a single GPU)."""
+        even for tp_size 1 (a 1-rank RCCL all-reduce: used to exercise the RCCL + hipGraph path on a single GPU).
+
+        ``allgather_bytes(b: bytes) -> list[bytes]`` (every rank's bytes, in rank order) additionally sets up the one-shot
+        peer-to-peer all-reduce for the decode-sized messages (csrc/p2p.hip): IPC handles are exchanged, every rank runs a
+        self-test, and the path is enabled only if it passed on ALL ranks -- otherwise the all-reduces stay on RCCL and
+        ``self.p2p`` is False.  ``rccl=False`` skips the communicator (ranks sharing one GPU in the tests, which RCCL
+        refuses); the P2P path is then mandatory."""
         if self.tp_size == 1 and not force:
             return
-        buf = (C.c_char * 128)()
-        if self.tp_rank == 0:
-            check(lib().emu_tp_unique_id(buf), "emu_tp_unique_id")
-            uid = broadcast_bytes(bytes(buf))
-        else:
-            uid = broadcast_bytes(None)
-        buf = (C.c_char * 128).from_buffer_copy(uid)
-        with torch.cuda.device(self.device):
-            check(lib().emu_tp_init(self.handle, buf), "emu_tp_init", self.handle)
+        if rccl:
+            buf = (C.c_char * 128)()
+            if self.tp_rank == 0:
+                check(lib().emu_tp_unique_id(buf), "emu_tp_unique_id")
+                uid = broadcast_bytes(bytes(buf))
+            else:
+                uid = broadcast_bytes(None)
+            buf = (C.c_char * 128).from_buffer_copy(uid)
+            with torch.cuda.device(self.device):
+                check(lib().emu_tp_init(self.handle, buf), "emu_tp_init", self.handle)
+        if allgather_bytes is not None:
+            self.p2p = self._init_p2p(allgather_bytes, p2p_timeout_ms)
+        if not rccl and not self.p2p:
+            raise RuntimeError("tensor parallelism without RCCL needs the peer-to-peer all-reduce, and its self-test failed")
+
+    def _init_p2p(self, allgather_bytes, timeout_ms: int) -> bool:
+        L = lib()
+        h = (C.c_char * 64)()
+        ok = L.emu_tp_p2p_create(self.handle, h) == 0
+        handles = allgather_bytes(bytes(h) if ok else b"")
+        if not all(len(x) == 64 for x in handles):           # some rank could not export: nobody maps anything
+            return False
+        ok = L.emu_tp_p2p_open(self.handle, (C.c_char * (64 * self.tp_size)).from_buffer_copy(b"".join(handles)), timeout_ms) == 0
+        ok = all(x == b"1" for x in allgather_bytes(b"1" if ok else b"0"))   # also the barrier: every peer block is mapped
+        if ok:
+            # self-test: four all-reduces (both slots, one reuse each) of rank-dependent vectors; exact in bf16
+            n = 6656
+            base = torch.arange(n, device=self.device, dtype=torch.float32) % 13
+            want = sum(base * (r + 1) + r for r in range(self.tp_size)).to(BF16)
+            s = ops.stream(self.device)
+            for it in range(4):
+                x = (base * (self.tp_rank + 1) + self.tp_rank).to(BF16)
+                ok = ok and L.emu_tp_p2p_allreduce_bf16(self.handle, x.data_ptr(), n, s) == 0
+                torch.cuda.synchronize(self.device)
+                ok = ok and bool(torch.equal(x, want))
+            ok = ok and L.emu_tp_p2p_giveups() == 0
+        ok = all(x == b"1" for x in allgather_bytes(b"1" if ok else b"0"))
+        if ok:
+            check(L.emu_tp_p2p_enable(self.handle, 1), "emu_tp_p2p_enable", self.handle)
+        elif self.tp_rank == 0:
+            import warnings
+            warnings.warn("peer-to-peer all-reduce self-test failed; tensor-parallel all-reduces stay on RCCL")
+        return ok
+
+    def check_p2p(self) -> None:
+        """Raise if a device-side wait of the P2P all-reduce ever timed out (the sums since then are invalid)."""
+        if self.p2p and lib().emu_tp_p2p_giveups() != 0:
+            raise RuntimeError("peer-to-peer all-reduce timed out waiting for a peer rank; results are invalid")
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
         check(lib().emu_allreduce_bf16(self.handle, t.data_ptr(), t.numel(), ops.stream(self.device)), "emu_allreduce_bf16", self.handle)
@@ -325,6 +372,7 @@ class LlamaEngine:
                     if bool((out_ids[: i + 2] == eos_id).any(dim=0).all()):
                         break
         ids = out_ids.t().to(torch.int64)                       # [B, max_new]
+        self.ctx.check_p2p()
         if not stop_on_eos:
             return ids
         return apply_eos_padding(ids, eos_id, pad_id)
@@ -367,6 +415,7 @@ class LlamaEngine:
             self.forward(hid, B, 1, pos, slot, kstart, ctx=S + step + 1)
             pos = pos + 1
             row = hid
+        self.ctx.check_p2p()
         return out[:, :n]
 
     # ------------------------------------------------------------------ beam search
@@ -467,6 +516,7 @@ class LlamaEngine:
             pos = pos + 1
             lp_rows = self.logits(hid).float().view(B, nb, V)
         out_len = int(seq_len[:, 0].max().item())
+        self.ctx.check_p2p()
         return sequences[:, 0, :out_len]
 
 

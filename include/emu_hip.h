@@ -41,6 +41,18 @@ const char* emu_last_error(const emu_ctx* ctx);
 int emu_tp_unique_id(void* out128);                      /* rank 0: 128-byte RCCL unique id           */
 int emu_tp_init(emu_ctx* ctx, const void* id128);        /* all ranks: ncclCommInitRank               */
 int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);   /* in-place sum          */
+/* One-shot peer-to-peer all-reduce for the decode-sized messages (13 KB, 120 per token), emu_amd/csrc/p2p.hip: every rank
+ * exports a comm block over HIP IPC (create: 64-byte handle out), maps every peer's (open: tp_size x 64 bytes in rank
+ * order; timeout_ms bounds every device-side wait, <= 0 keeps the 10 s default), and reads the peers' partial vectors
+ * straight over xGMI.  emu_allreduce_bf16 uses it for messages of at most 256 KiB once emu_tp_p2p_enable(ctx, 1) was
+ * called (and for every message when no RCCL communicator exists); the host enables it only after a self-test through
+ * emu_tp_p2p_allreduce_bf16 on every rank.  emu_tp_p2p_giveups: device-side waits that timed out since process start --
+ * non-zero means sums since then are invalid. */
+int emu_tp_p2p_create(emu_ctx* ctx, void* handle64_out);
+int emu_tp_p2p_open(emu_ctx* ctx, const void* handles, int timeout_ms);
+int emu_tp_p2p_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);
+int emu_tp_p2p_enable(emu_ctx* ctx, int on);
+unsigned int emu_tp_p2p_giveups(void);
 
 /* Optional fp32 scratch for split-K GEMMs / convolutions issued through the primitives below (emu_linear_bf16,
  * emu_conv3x3_nhwc_bf16): few-tile long-K problems are cut into up to 4 K-slices that land here before a second launch

@@ -8,6 +8,11 @@ from emu_amd.llama import LlamaEngine
 from oracle import emu2_ref as R
 
 
+class _NoComm:                                       # the product checks its communicator after a generation
+    def check_p2p(self):
+        pass
+
+
 class FakeEngine:
     def __init__(self, lcfg: LlamaCfg, vocab: int, W, rcfg: R.LlamaCfg):
         self.cfg, self.vocab, self.W, self.rcfg = lcfg, vocab, W, rcfg
@@ -15,6 +20,7 @@ class FakeEngine:
         self.embed = W["decoder.lm.model.embed_tokens.weight"]
         self.kcache = self.vcache = None
         self.kv_batch = self.s_max = 0
+        self.ctx = _NoComm()
 
     KV_BUCKETS = LlamaEngine.KV_BUCKETS
     kv_capacity = LlamaEngine.kv_capacity            # the product's own bucket logic

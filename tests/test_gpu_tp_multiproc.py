@@ -1,6 +1,8 @@
 """Tensor parallelism on real GPUs: the ENGINE (not a torch restatement) sharded over 2 / 4 ranks, one process per GPU over
 RCCL, must generate the golden fixture's greedy ids (the real reference's) with eager launches and under hipGraph replay.
-Needs >= 2 GPUs on the node: skipped on the 1-GPU runner (the CPU gloo tests cover the shard plan and data flow there)."""
+The multi-GPU cases need >= 2 GPUs on the node and skip on the 1-GPU runner; the shared-GPU cases run there: 2 / 4 rank
+processes on ONE device, every all-reduce through the one-shot peer-to-peer path over HIP IPC (RCCL refuses ranks that share
+a device), which is the engine's real TP data flow and the real P2P protocol minus the xGMI hop."""
 import os
 import socket
 import subprocess
@@ -26,3 +28,15 @@ def test_engine_tp_generates_reference_ids(world):
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "tp_engine_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_engine_tp_ranks_sharing_one_gpu(world):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", EMU_TP_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "tp_engine_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("p2p all-reduce on") == world, r.stdout[-3000:]

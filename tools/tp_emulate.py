@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-rank decode cost of a TP shard on ONE GPU: rank 0's 1/tp slice of LLaMA-33B with a 1-rank RCCL communicator in the
-loop (the all-reduce launches are real, their cross-GPU latency is not).  Usage: python tools/tp_emulate.py [tp] [steps]"""
+loop (the all-reduce launches are real, their cross-GPU latency is not).  With a third argument "p2p" the all-reduces are the
+one-shot peer-to-peer kernel (csrc/p2p.hip) with one rank instead.  Usage: python tools/tp_emulate.py [tp] [steps] [p2p]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,11 @@ tp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 dev = torch.device("cuda", 0)
 real = EmuHipContext(dev, 0, 1)
-real.init_tp(lambda b: b, force=True)
+p2p = len(sys.argv) > 3 and sys.argv[3] == "p2p"
+if p2p:
+    real.init_tp(lambda b: b, force=True, allgather_bytes=lambda b: [b], rccl=False)
+else:
+    real.init_tp(lambda b: b, force=True)
 
 
 class ShardView:                      # the engine plans its shard from (tp_rank, tp_size); RCCL sees the 1-rank context
@@ -44,5 +49,5 @@ with torch.no_grad():
             fn()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) / steps * 1e3
-        print(f"tp={tp} shard on one GPU, {'hipGraph' if graph else 'eager'}: {ms:.3f} ms/token "
+        print(f"tp={tp} shard on one GPU, {'p2p' if p2p else 'rccl'} all-reduce, {'hipGraph' if graph else 'eager'}: {ms:.3f} ms/token "
               f"({eng.weight_bytes_per_token() / 1e9:.2f} GB of weights per token per rank)")
