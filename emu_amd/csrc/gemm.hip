@@ -310,6 +310,25 @@ inline PpPlan pick_pp(const GemmArgs& a) {
     return (tp >= 150 && nk >= 32) ? PpPlan{true, tp, 1, 0.0} : no;
 }
 
+// Whole rounds on the 256x256 tile + the remaining weight rows on the lock-step tiles.  A problem of r * 256 + f tiles with a
+// small f (the UNet's GEGLU: 8 x 40 = 320 tiles; S=1544 gate/up: 6 x 140 = 840) pays a whole extra round for the f tiles,
+// and K-slicing them costs fp32 slabs.  Instead the first n1 tile columns (tiles_m * n1 ~ r * 256: every CU exactly r
+// tiles) go to the ping-pong kernel and columns [n1 * 256, N) are a second, independent GEMM on the same A (pointer offsets
+// only: W rows, bias, residual / output columns -- half of them for the interleaved GLU pairs).  n1 = 0: not applicable.
+// The heuristic takes it for f <= 3/8 of a round when the cost model would not K-slice the tail (short K): measured
+// (profiles/r02_gemm_ab_v12_hybrid.log) UNet GEGLU 608 (256x128) / 701 (256x256, two rounds) -> 747 TFLOP/s, denoise step
+// 29.0 -> 27.7 ms; with long K the sliced tail stays ahead (S=1544 gate/up 1124 vs 1066) and at f = 1/2 the plain rounds do.
+inline int plan_hybrid(const GemmArgs& a, bool forced) {
+    if (!gemm256_ok(a) || a.M < 192 || a.K / BK < 8 || a.conv.mode != CONV_NONE) return 0;
+    const int CU = 256, tn = (a.N + 255) / 256, tp = gemm256_tiles(a), tm = tp / tn;
+    const int r = tp / CU, rem = tp % CU;
+    if (r < 1 || rem == 0 || rem > CU / 2) return 0;
+    if (!forced && (rem * 8 > CU * 3 || plan_pp(a).ksplit > 1)) return 0;
+    const int n1 = r * CU / tm;
+    if (n1 < 1 || n1 >= tn || tm * n1 * 10 < r * CU * 9) return 0;
+    return n1;
+}
+
 template <int EPI, bool CONV>
 int launch_v2(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
@@ -318,6 +337,28 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
     const bool k64 = (a.K & 63) == 0;
     if (cfg == 'S' && !k64) cfg = 0;
     if ((cfg == 'P' || cfg == 'Q') && !gemm256_ok(a)) cfg = 0;
+    if (!cfg || cfg == 'H') {
+        const int n1 = CONV ? 0 : plan_hybrid(a, cfg == 'H');
+        if (n1 > 0) {
+            constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
+            GemmArgs head = a, rest = a;
+            head.N = n1 * 256;
+            rest.N = a.N - head.N;
+            rest.W = a.W + (size_t)head.N * a.ldw;
+            if (a.bias) rest.bias = a.bias + head.N;
+            if (a.res) rest.res = a.res + head.N;
+            if (a.bias2) rest.bias2 = a.bias2 + head.N;
+            rest.C = a.C + (GLU ? head.N / 2 : head.N);
+            int st = launch_gemm256(head, s, -1, 1);
+            if (st != 0) return st;
+            const int keep = g_force_cfg;
+            g_force_cfg = 0;                                       // the remainder takes whatever the heuristic says
+            st = launch_v2<EPI, CONV>(rest, s);
+            g_force_cfg = keep;
+            return st;
+        }
+        cfg = 0;
+    }
     if (!cfg) {
         const PpPlan pp = pick_pp(a);
         if (pp.use) return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);

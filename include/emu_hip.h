@@ -61,8 +61,9 @@ unsigned int emu_tp_p2p_giveups(void);
 void emu_set_splitk_scratch(void* ptr, size_t bytes);
 /* Test / bench hook: pin the tile configuration of every following GEMM / conv launch of this process.  0 (default) =
  * the shape heuristic; 'B' 128x128, 'C' 256(n)x128(m), 'K' 128x64 with two k-groups, 'S' 256x128 K-sliced,
-* 'P' 256x256 ping-pong (K-sliced under half a round of tiles), 'Q' the same never sliced (both: K % 64 == 0 and
- * operands within 2 GiB, else the heuristic).  The parity tests walk every configuration over the
+ * 'P' 256x256 ping-pong (K-sliced under half a round of tiles), 'Q' the same never sliced (both: K % 64 == 0 and
+ * operands within 2 GiB, else the heuristic), 'H' whole rounds of the 256x256 tile + the remaining columns as a second
+ * GEMM (where the tile count allows, else the heuristic).  The parity tests walk every configuration over the
  * bench's true shapes with it (tests/test_gpu_ops.py); production code never calls it. */
 void emu_gemm_force_config(int cfg);
 

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
-CFGS = ["B", "C", "S", "K", "P", "Q", "0"]
+CFGS = ["B", "C", "S", "K", "P", "Q", "H", "0"]
 
 
 def bfr(t):
@@ -63,6 +63,7 @@ SHAPES = [
     (1544, 6656, 6656, (0, 1, 2, 3, 4, 5)), (1025, 6144, 1792, (0,)), (1025, 1792, 2048, (1,)), (1025, 15360, 1792, (4,)),
     (1025, 1792, 15360, (1,)), (2048, 1280, 1280, (0, 1)), (2048, 10240, 1280, (5,)), (2048, 1280, 5120, (1,)),
     (8192, 1920, 640, (0,)), (8192, 5120, 640, (5,)), (8192, 640, 2560, (1,)), (800, 512, 1536, (0, 1, 2, 3, 4, 5)),
+    (2048, 10240, 640, (0, 1, 2)),                      # 320 tiles of 256x256: one whole round + 2048 columns ('H')
 ]
 
 
