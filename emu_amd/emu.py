@@ -172,15 +172,15 @@ class EmuModel:
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
             x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
+        if num_beams > 1:
+            return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
+                                                        length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,
+                                                        do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
+                                                        repetition_penalty=repetition_penalty)
         if do_sample or repetition_penalty != 1.0:
-            if num_beams > 1:
-                raise NotImplementedError("beam search combined with sampling / repetition penalty is not built")
             return self.decoder.lm.sample_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len, do_sample,
                                                    temperature, top_k, top_p, repetition_penalty, eos_id=EOS_TOKEN_ID,
                                                    pad_id=PAD_TOKEN_ID)
-        if num_beams > 1:
-            return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
-                                                        length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID)
         return self.decoder.lm.greedy_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len,
                                                eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID, use_graph=self.use_graph,
                                                stop_on_eos=stop_on_eos)

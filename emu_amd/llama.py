@@ -422,14 +422,21 @@ class LlamaEngine:
     @torch.no_grad()
     def beam_search_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, num_beams: int,
                              max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0, eos_id: int = 2,
-                             pad_id: int = 32000) -> torch.Tensor:
+                             pad_id: int = 32000, do_sample: bool = False, temperature: Optional[float] = None,
+                             top_k: Optional[int] = None, top_p: Optional[float] = None,
+                             repetition_penalty: float = 1.0) -> torch.Tensor:
         """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False, early_stopping=False)`` -- the reference's
         DEFAULT decoding mode (num_beams=5, length_penalty=-1, Emu2/emu/emu.py:163-172,213-229).  Restates
         transformers' vectorised beam search: per step keep the 2N best continuations over beams x vocab, the N best
         non-finished ones keep running, finished ones (EOS, or the length limit) compete for the N result slots with
         score / len**length_penalty, and the loop ends when no running beam can beat the worst kept result.
         One prefill for the B prompts; the KV cache is then replicated per beam and re-ordered by beam index each
-        step (rows are gathered on the device).  Returns the best sequence per prompt [B, <= max_new_tokens]."""
+        step (rows are gathered on the device).  Returns the best sequence per prompt [B, <= max_new_tokens].
+
+        ``do_sample=True`` is the library's *beam-search multinomial sampling*: the per-beam log-probabilities go through
+        the logits pipeline (repetition penalty, min length, temperature / top-k / top-p with min_tokens_to_keep = 2)
+        BEFORE the beam scores are added, and the 2N continuations are drawn without replacement from
+        softmax(accumulated scores) instead of taken by top-k.  ``repetition_penalty`` alone gives penalised beam search."""
         B, S, H = embeds.shape
         nb, V, dev = num_beams, self.vocab, self.device
         s_max = self.kv_capacity(S + max_new_tokens)
@@ -464,11 +471,19 @@ class LlamaEngine:
         lp_rows = logits[:, None, :].expand(B, nb, V)                                   # step 0: every beam = the prompt
         while True:
             log_probs = torch.log_softmax(lp_rows, dim=-1)
-            if cur < min_len:
+            if do_sample or repetition_penalty != 1.0:
+                log_probs = process_logits(log_probs.reshape(B * nb, V), running_seq[:, :, :cur].reshape(B * nb, cur), cur < min_len,
+                                           eos_id, do_sample, temperature, top_k, top_p, repetition_penalty,
+                                           min_keep=2).view(B, nb, V)
+            elif cur < min_len:
                 log_probs = log_probs.clone()
                 log_probs[..., eos_id] = -float("inf")
             acc = (log_probs + running_scores[:, :, None]).reshape(B, nb * V)
-            top_lp, top_idx = torch.topk(acc, k=2 * nb)
+            if do_sample:
+                top_idx = torch.multinomial(torch.softmax(acc, dim=-1), num_samples=2 * nb)
+                top_lp = torch.gather(acc, 1, top_idx)
+            else:
+                top_lp, top_idx = torch.topk(acc, k=2 * nb)
             src_beam = top_idx // V
             tok = top_idx % V
             cand_seq = gather(running_seq, src_beam)
@@ -522,11 +537,12 @@ class LlamaEngine:
 
 def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: bool, eos_id: int, do_sample: bool,
                    temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
-                   repetition_penalty: float = 1.0) -> torch.Tensor:
+                   repetition_penalty: float = 1.0, min_keep: int = 1) -> torch.Tensor:
     """transformers' logits pipeline for ``generate(inputs_embeds=...)`` in its order: RepetitionPenaltyLogitsProcessor over
     the ids generated so far (with inputs_embeds the prompt contributes no ids), MinLengthLogitsProcessor (EOS -> -inf),
     then -- only when sampling -- TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper.  ``scores`` [B, V] fp32,
-    ``generated`` [B, n] int64.  Pure torch: pinned against the library's own processors in tests/test_host_logic.py."""
+    ``generated`` [B, n] int64.  ``min_keep`` is the warpers' min_tokens_to_keep (2 under beam search: one EOS id + 1).
+    Pure torch: pinned against the library's own processors in tests/test_host_logic.py."""
     if repetition_penalty != 1.0 and generated.shape[1] > 0:
         g = torch.gather(scores, 1, generated)
         g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
@@ -538,13 +554,13 @@ def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: 
         if temperature is not None and temperature != 1.0:
             scores = scores / temperature
         if top_k is not None and top_k > 0:
-            kth = torch.topk(scores, min(top_k, scores.shape[-1]))[0][..., -1, None]
+            kth = torch.topk(scores, min(max(top_k, min_keep), scores.shape[-1]))[0][..., -1, None]
             scores = scores.masked_fill(scores < kth, -float("inf"))
         if top_p is not None and top_p < 1.0:
             srt, idx = torch.sort(scores, descending=False)
             cum = srt.softmax(dim=-1).cumsum(dim=-1)
             remove = cum <= (1 - top_p)
-            remove[..., -1:] = False
+            remove[..., -min_keep:] = False
             scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
     return scores
 

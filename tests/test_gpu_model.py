@@ -136,6 +136,27 @@ def test_generate_beam_search(tiny_model, golden_dir):
     assert ref_logprob(b1[0].cpu().tolist()) > ref_logprob(z["beam1"][0].tolist()) - 1.5
 
 
+def test_generate_beam_sampling_and_penalised_beams(tiny_model, golden_dir):
+    """num_beams > 1 with do_sample (beam-search multinomial sampling) and with repetition_penalty on the GPU engine.  The
+    host logic is pinned to the real reference's ids on CPU (tests/test_host_logic.py, same torch seed); here: the device
+    path runs, is reproducible under a seed, keeps the warpers' constraints, and the deterministic penalised search
+    reproduces the reference's ids for the prompt row whose decisions have a margin."""
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_beam_sample_tiny.npz")
+    ids, mask = _t(z["ids"]), _t(z["mask"])
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        outs.append(m.generate_ids(ids, mask, None, max_new_tokens=8, num_beams=3, do_sample=True, top_k=40, top_p=0.9,
+                                   temperature=0.7).cpu())
+    assert outs[0].tolist() == outs[1].tolist() and outs[0].shape[0] == 2 and 1 <= outs[0].shape[1] <= 8
+    assert int(outs[0].max()) <= 32000 + 274 and int(outs[0].min()) >= 0
+    pen = m.generate_ids(ids, mask, None, max_new_tokens=8, num_beams=3, repetition_penalty=1.5).cpu()
+    assert pen.shape == (2, 8)
+    same = [pen[b].tolist() == z["bs_penalty"][b].tolist() for b in range(2)]
+    assert any(same), (pen.tolist(), z["bs_penalty"].tolist())
+
+
 def test_generate_graph_replay_equals_eager(tiny_model, golden_dir):
     m, W, cfg = tiny_model
     z = tiny.load(golden_dir, "generate_tiny.npz")

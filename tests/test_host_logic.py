@@ -116,6 +116,34 @@ def test_product_beam_search_host_logic_matches_reference(golden_dir, monkeypatc
     assert out.tolist() == z["beam2"].tolist()
 
 
+@pytest.mark.parametrize("case,kw", [
+    ("bs_sample", dict(num_beams=3, do_sample=True, top_k=40, top_p=0.9, temperature=0.7, max_new_tokens=8)),
+    ("bs_sample_plain", dict(num_beams=4, do_sample=True, max_new_tokens=6)),
+    ("bs_penalty", dict(num_beams=3, repetition_penalty=1.5, max_new_tokens=8)),
+])
+def test_product_beam_sampling_and_penalty_match_reference(golden_dir, monkeypatch, case, kw):
+    """Beam-search multinomial sampling (num_beams > 1 with do_sample) and penalised beam search through the PRODUCT's
+    beam_search_generate on the CPU stand-in engine: the ids the real reference produced for the same prompts under the
+    same torch seed (oracle/make_golden_beam_sample.py; the draws come from torch's global CPU generator)."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_beam_sample_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    eng = FakeEngine(l, vocab, W, cfg.llama)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    x = R.embed_tokens(t(z["ids"]), W)
+    kw = dict(kw)
+    nb, n_new = kw.pop("num_beams"), kw.pop("max_new_tokens")
+    torch.manual_seed(int(z["seed"]))
+    out = L.LlamaEngine.beam_search_generate(eng, x, t(z["mask"]), nb, n_new, **kw)
+    assert out.tolist() == z[case].tolist()
+
+
 def test_emu1_lora_merge_both_peft_layouts():
     """Emu1 instruct checkpoints carry peft LoRA adapters (Emu1/inference.py:40-51); the loader folds them into the base
     matrices: W' = W + (alpha / r) * B @ A, for both peft key layouts, and leaves adapter-free dicts untouched."""
