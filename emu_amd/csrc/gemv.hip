@@ -64,6 +64,50 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     float rinv[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) rinv[m] = 1.f;
+    // PRE < 0 ("head" form, MB == 1, fused norm, K <= 8192): the activation vector and the gain (<= 4 chunks per thread
+    // each, L2 hits, returned first because loads complete in order) and the first trip of the weight stream are requested
+    // before the RMSNorm statistics are reduced, and the reduction goes through a raw s_barrier (a __syncthreads drains
+    // vmcnt, i.e. waits for the weights): HBM streams during the prologue instead of after it.  The normalised activations
+    // are packed once into registers, so the remaining trips issue nothing but weight loads.
+    u32x4 hx[4], hg[4];
+    u32x4 hw[R];
+    if constexpr (PRE < 0) {
+        static_assert(PRE >= 0 || (MB == 1 && NORM), "head form: single row with the fused norm");
+        __shared__ float ssp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int vi = tid + 256 * c;
+            const int vc = vi < KV ? vi : KV - 1;
+            hx[c] = vi < KV ? ld16(a.x + vi * 8) : u32x4{0u, 0u, 0u, 0u};
+            hg[c] = ld16(a.norm_w + vc * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)                                    // short rows (K < 2048): clamped, against a zero operand
+            hw[r] = ld_stream(reinterpret_cast<const u32x4*>(wrow[r] + (tid < KV ? tid : KV - 1) * 8));
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float f[8];
+            unpack8(hx[c], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) *reinterpret_cast<volatile float*>(&ssp[wave]) = ss;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const volatile float* sp = ssp;
+        rinv[0] = rsqrtf((sp[0] + sp[1] + sp[2] + sp[3]) / (float)a.K + a.eps);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                  // hx <- bf16(g * bf16(x * rinv)), the dot2 operand
+            float xf[8], g[8];
+            unpack8(hx[c], xf);
+            unpack8(hg[c], g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = g[j] * bfround(xf[j] * rinv[0]);
+            hx[c] = pack8(xf);
+        }
+    } else
     if constexpr (NORM) {
         float ss[MB];
 #pragma unroll
@@ -137,7 +181,37 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         }
     };
 
-    if constexpr (PRE > 0) {
+    if constexpr (PRE < 0) {
+        auto dots = [&](const u32x4 (&wv)[R], const u32x4& xp) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float t = acc[r][0];
+                t = bf16_dot2(wv[r].x, xp.x, t);
+                t = bf16_dot2(wv[r].y, xp.y, t);
+                t = bf16_dot2(wv[r].z, xp.z, t);
+                t = bf16_dot2(wv[r].w, xp.w, t);
+                acc[r][0] = t;
+            }
+        };
+        // trip 0 from the head registers; trips 1..3 stream behind it through two register sets (two trips in flight)
+        u32x4 w1[R];
+        auto fetch = [&](u32x4 (&wv)[R], int c) {
+            const int vi = tid + 256 * c;
+            if (vi < KV) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) wv[r] = ld_stream(reinterpret_cast<const u32x4*>(wrow[r] + vi * 8));
+            }
+        };
+        fetch(w1, 1);
+        dots(hw, hx[0]);
+        __builtin_amdgcn_sched_barrier(0);                             // a third register set would cost a wave of occupancy
+        fetch(hw, 2);
+        if (tid + 256 < KV) dots(w1, hx[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(w1, 3);
+        if (tid + 512 < KV) dots(hw, hx[2]);
+        if (tid + 768 < KV) dots(w1, hx[3]);
+    } else if constexpr (PRE > 0) {
 #pragma unroll
         for (int c = 0; c < PRE; ++c) {
             const int vi = tid + 256 * c;
@@ -582,8 +656,8 @@ int launch_gemv_mfma(const GemvArgs& a, hipStream_t s) {
 template <int R, int MB, bool NORM, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
     __shared__ float red[NW][R * MB];
+    __shared__ float red_ss[NW][MB];
     __shared__ float fin[R * MB];
-    __shared__ float scratch[NW];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int KV = a.K >> 4;                       // 16-element groups per row
@@ -596,30 +670,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
         n = n < a.N ? n : a.N - 1;
         wrow[r] = W8 + (size_t)n * a.ldw;
     }
-    float rinv[MB];
+    // fused RMSNorm without a prologue: y = rinv * sum_k w[k] * (g[k] * x[k]), rinv = rsqrt(mean(x^2) + eps).  The sum of
+    // squares rides along the one pass over x (every column belongs to exactly one lane of the workgroup), so the weight
+    // stream starts at once instead of behind a load -> reduce -> barrier round trip; the reference's two bf16 rounding
+    // points inside the norm are not reproduced (2^-9 relative, far below the e4m3 weight error of this optional stream).
+    float ss[MB];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) rinv[m] = 1.f;
-    if constexpr (NORM) {
-        float ss[MB];
-#pragma unroll
-        for (int m = 0; m < MB; ++m) ss[m] = 0.f;
-        for (int vi = tid; vi < (a.K >> 3); vi += NW * 64) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (m < a.M) {
-                    float f[8];
-                    unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ss[m] += f[j] * f[j];
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float t = block_sum<NW>(ss[m], scratch);
-            rinv[m] = rsqrtf(t / (float)a.K + a.eps);
-        }
-    }
+    for (int m = 0; m < MB; ++m) ss[m] = 0.f;
     float acc[R][MB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -641,7 +698,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
                 unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 16 + 8), xf[m] + 8);
                 if constexpr (NORM) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) xf[m][j] = bfround(g[j] * bfround(xf[m][j] * rinv[m]));
+                    for (int j = 0; j < 16; ++j) { ss[m] = fmaf(xf[m][j], xf[m][j], ss[m]); xf[m][j] *= g[j]; }
                 }
             } else {
 #pragma unroll
@@ -673,13 +730,26 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
             const float v = wave_sum(acc[r][m]);
             if (lane == 0) red[wave][r * MB + m] = v;
         }
+    if constexpr (NORM) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float v = wave_sum(ss[m]);
+            if (lane == 0) red_ss[wave][m] = v;
+        }
+    }
     __syncthreads();
     if (tid < R * MB) {
         const int n = n0 + tid / MB;
-        float t = 0.f;
+        float t = 0.f, rinv = 1.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += red[w][tid];
-        fin[tid] = t * a.wscale[n < a.N ? n : a.N - 1];
+        if constexpr (NORM) {
+            float q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) q += red_ss[w][tid % MB];
+            rinv = rsqrtf(q / (float)a.K + a.eps);
+        }
+        fin[tid] = t * rinv * a.wscale[n < a.N ? n : a.N - 1];
     }
     __syncthreads();
     if constexpr (EPI == EPI_SWIGLU) {
@@ -710,8 +780,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8_kernel(const GemvArgs a) {
 template <int R, int MB, bool NORM, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
     __shared__ float red[NW][R * MB];
+    __shared__ float red_ss[NW][MB];
     __shared__ float fin[R * MB];
-    __shared__ float scratch[NW];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int KV = a.K >> 3;                       // 8-element groups per row (8-byte weight loads)
@@ -724,30 +794,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
         n = n < a.N ? n : a.N - 1;
         wrow[r] = W8 + (size_t)n * a.ldw;
     }
-    float rinv[MB];
+    float ss[MB];                                  // sum of squares rides along the pass over x (see gemv_fp8_kernel)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) rinv[m] = 1.f;
-    if constexpr (NORM) {
-        float ss[MB];
-#pragma unroll
-        for (int m = 0; m < MB; ++m) ss[m] = 0.f;
-        for (int vi = tid; vi < (a.K >> 3); vi += NW * 64) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (m < a.M) {
-                    float f[8];
-                    unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ss[m] += f[j] * f[j];
-                }
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float t = block_sum<NW>(ss[m], scratch);
-            rinv[m] = rsqrtf(t / (float)a.K + a.eps);
-        }
-    }
+    for (int m = 0; m < MB; ++m) ss[m] = 0.f;
     float acc[R][MB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -768,7 +817,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
                 unpack8(ld16(a.x + (size_t)m * a.ldx + vi * 8), xf[m]);
                 if constexpr (NORM) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xf[m][j] = bfround(g[j] * bfround(xf[m][j] * rinv[m]));
+                    for (int j = 0; j < 8; ++j) { ss[m] = fmaf(xf[m][j], xf[m][j], ss[m]); xf[m][j] *= g[j]; }
                 }
             } else {
 #pragma unroll
@@ -800,13 +849,26 @@ __global__ __launch_bounds__(NW * 64) void gemv_fp8v8_kernel(const GemvArgs a) {
             const float v = wave_sum(acc[r][m]);
             if (lane == 0) red[wave][r * MB + m] = v;
         }
+    if constexpr (NORM) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float v = wave_sum(ss[m]);
+            if (lane == 0) red_ss[wave][m] = v;
+        }
+    }
     __syncthreads();
     if (tid < R * MB) {
         const int n = n0 + tid / MB;
-        float t = 0.f;
+        float t = 0.f, rinv = 1.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += red[w][tid];
-        fin[tid] = t * a.wscale[n < a.N ? n : a.N - 1];
+        if constexpr (NORM) {
+            float q = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) q += red_ss[w][tid % MB];
+            rinv = rsqrtf(q / (float)a.K + a.eps);
+        }
+        fin[tid] = t * rinv * a.wscale[n < a.N ? n : a.N - 1];
     }
     __syncthreads();
     if constexpr (EPI == EPI_SWIGLU) {
@@ -899,6 +961,9 @@ int launch_norm(const GemvArgs& a, hipStream_t s) {
     if constexpr (MB == 1 && R <= 4) {
         if (!a.norm_w && (a.K >> 3) <= 1024) return launch_epi<R, MB, false, 4>(a, s);
     }
+    if constexpr (MB == 1) {
+        if (a.norm_w && (a.K >> 3) <= 1024) return launch_epi<R, MB, true, -1>(a, s);
+    }
     return a.norm_w ? launch_epi<R, MB, true, 0>(a, s) : launch_epi<R, MB, false, 0>(a, s);
 }
 
@@ -915,13 +980,11 @@ int launch_mb(const GemvArgs& a, hipStream_t s) {
 }  // namespace
 
 int emu_gemv_rows_per_block(int N, int K, bool norm) {
-    // measured (tools/kbench.py, profiles/): kernels with the fused RMSNorm prologue want 8 rows per workgroup so the
-    // prologue is amortised; plain streams are fastest with 2 rows per workgroup (more, smaller workgroups balance the
-    // 256 CUs better).
-    // With the inner product on v_dot2c the per-column activation prep (normalise + re-pack) is the largest VALU
-    // item of a fused-norm block, so big matrices take 16 rows per workgroup (qkv / gate-up / lm_head: +1..2 %).
-    (void)K;
-    int R = norm ? 16 : 2;
+    // measured (tools/kbench.py, profiles/): plain streams are fastest with 2 rows per workgroup (more, smaller workgroups
+    // balance the 256 CUs better).  Kernels with the fused RMSNorm prologue wanted 8-16 rows so the prologue was amortised;
+    // in the head form (K <= 8192: the weight stream starts before the statistics are reduced) the prologue no longer
+    // stalls the stream and 4 rows win: decode 93.1 (16 rows) / 93.6 (8) / 95.0 (4) tokens/s, 2 rows lose 12 %.
+    int R = norm ? ((K >> 3) <= 1024 ? 4 : 16) : 2;
     while (R > 2 && (N + R - 1) / R < (R == 16 ? 1024 : 512)) R >>= 1;
     return R;
 }
@@ -951,7 +1014,7 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
         // lane, like the bf16 kernel) and long rows (down_proj, K = 17920) 4-wave blocks
         if (a.K <= 8192) return a.M <= 1 ? launch_fp8v8<8, 1, 4>(a, s) : launch_fp8v8<8, 2, 4>(a, s);   // 8-byte loads: 3.25 trips per lane at K = 6656
         const bool small = (a.N + 7) / 8 < 512;
-        if (a.M <= 1) return small ? launch_fp8<4, 1, 2>(a, s) : launch_fp8<8, 1, 2>(a, s);
+        if (a.M <= 1) return small ? launch_fp8<4, 1, 2>(a, s) : launch_fp8<4, 1, 4>(a, s);   // down_proj: 4 rows x 4 waves (21.8 vs 23.1 us)
         return small ? launch_fp8<4, 2, 2>(a, s) : launch_fp8<8, 2, 2>(a, s);
     }
     int R = a.rows_per_block > 0 ? a.rows_per_block
