@@ -165,13 +165,20 @@ class EmuModel:
     def generate_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, image: Optional[torch.Tensor] = None,
                      video: Optional[torch.Tensor] = None, max_new_tokens: int = 10, min_len: int = 1,
                      stop_on_eos: bool = True, num_beams: int = 1, length_penalty: float = -1.0, do_sample: bool = False,
-                     temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0) -> torch.Tensor:
-        """``generate`` at the token-id level (greedy for num_beams=1, else beam search): returns the NEW ids [B, n]
-        (what HF returns for inputs_embeds)."""
+                     temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0,
+                     penalty_alpha: Optional[float] = None) -> torch.Tensor:
+        """``generate`` at the token-id level: returns the NEW ids [B, n] (what HF returns for inputs_embeds).  Mode
+        selection as transformers does it: contrastive search (penalty_alpha > 0, top_k > 1, one beam, no sampling), beam
+        search / beam sampling (num_beams > 1), sampling or penalised greedy, plain greedy (device-side loop, hipGraph)."""
         B, S = input_ids.shape
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
             x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
+        if (penalty_alpha is not None and penalty_alpha > 0 and top_k is not None and top_k > 1 and num_beams == 1
+                and not do_sample):
+            return self.decoder.lm.contrastive_generate(x.view(B, S, -1), attention_mask, max_new_tokens, float(penalty_alpha),
+                                                        int(top_k), min_len, repetition_penalty, eos_id=EOS_TOKEN_ID,
+                                                        pad_id=PAD_TOKEN_ID)
         if num_beams > 1:
             return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
                                                         length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,
@@ -191,8 +198,6 @@ class EmuModel:
                  num_beams=5, max_new_tokens=10, min_len=1, do_sample=False, penalty_alpha=None, top_p=None,
                  top_k=None, temperature=None, length_penalty=-1, repetition_penalty=1.0, synced_gpus=False,
                  skip_special_tokens=True, **kwargs):
-        if penalty_alpha is not None:
-            raise NotImplementedError("contrastive search (penalty_alpha) is not built")
         # the reference forwards **kwargs to transformers' generate (emu.py:175,228); the options this engine honours
         # are mapped, anything else is refused rather than silently ignored
         if "min_new_tokens" in kwargs:
@@ -202,14 +207,15 @@ class EmuModel:
         kwargs.pop("use_cache", None)                   # always cached
         if kwargs:
             raise TypeError(f"EmuModel.generate: unsupported generation options {sorted(kwargs)} "
-                            "(the HIP engine implements greedy / beam / sampling with the arguments of the signature)")
+                            "(the HIP engine implements greedy / beam / sampling / contrastive search with the arguments of the signature)")
         tok = self.decoder.tokenizer
         text = [t.replace(image_placeholder, self.image_placeholder).replace(video_placeholder, self.video_placeholder)
                 for t in text]
         inputs = tok(text, padding="longest", return_tensors="pt")
         ids = self.generate_ids(inputs.input_ids, inputs.attention_mask, image, video, max_new_tokens, min_len,
                                 num_beams=num_beams, length_penalty=length_penalty, do_sample=do_sample,
-                                temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty)
+                                temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
+                                penalty_alpha=penalty_alpha)
         return tok.batch_decode(ids.cpu(), skip_special_tokens=skip_special_tokens)
 
     # ------------------------------------------------------------------ generate_image (emu.py:92-153)

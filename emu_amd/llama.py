@@ -418,6 +418,70 @@ class LlamaEngine:
         self.ctx.check_p2p()
         return out[:, :n]
 
+    # ------------------------------------------------------------------ contrastive search
+    @torch.no_grad()
+    def contrastive_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int,
+                             penalty_alpha: float, top_k: int, min_len: int = 1, repetition_penalty: float = 1.0,
+                             eos_id: int = 2, pad_id: int = 32000) -> torch.Tensor:
+        """``lm.generate(inputs_embeds=..., penalty_alpha=a, top_k=k)`` -- contrastive search as the reference's pinned
+        transformers 4.31 runs it (Emu2/emu/emu.py:167,223 forwards both arguments): per step the k most probable tokens
+        are each run one step further, and the one maximising (1 - a) * p(token) - a * max_j cos(h_token, h_j) over the
+        final-norm hidden states h_j of everything before it is kept.  The k candidates are k extra rows of one decoder
+        step that share the prompt's KV rows (as beams do); the kept candidate's KV slot is then copied to its siblings.
+        a = 0 or k = 1 degenerate to greedy search (tested against the real reference's greedy ids).  Deviation: hidden
+        states of left-padding positions are left out of the similarity (the library includes whatever the masked rows
+        hold).  Parity beyond those invariants is unpinned: the transformers in this image no longer ships the mode."""
+        B, S, H = embeds.shape
+        k, V, dev = int(top_k), self.vocab, self.device
+        s_max = self.kv_capacity(S + max_new_tokens)
+        hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
+        ctx_h = self.final_norm_rows(hidden.reshape(B * S, H).contiguous()).view(B, S, H).float()
+        ctx_ok = torch.arange(S, device=dev)[None, :] >= kstart[:, None].to(dev)
+        logit = self.logits(hidden[:, -1, :]).float()
+        k_old, v_old = self.kcache, self.vcache
+        self.kcache = self.vcache = None
+        self.alloc_kv(B * k, s_max)
+        rep = torch.arange(B, device=dev).repeat_interleave(k)
+        self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
+        self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
+        del k_old, v_old
+        kstart_k = kstart.repeat_interleave(k).contiguous()
+        pos = next_pos.repeat_interleave(k).contiguous()
+        out = torch.full((B, max_new_tokens), pad_id, dtype=torch.int64, device=dev)
+        unfinished = torch.ones(B, dtype=torch.int64, device=dev)
+        hid = torch.empty(B * k, H, device=dev, dtype=BF16)
+        ar = torch.arange(B, device=dev)
+        n = 0
+        for step in range(max_new_tokens):
+            scores = process_logits(logit, out[:, :step], step < min_len, eos_id, False, repetition_penalty=repetition_penalty)
+            top_p_, top_ids = torch.topk(torch.softmax(scores, dim=-1), k=k, dim=-1)          # [B, k]
+            ops.embed_gather(top_ids.reshape(-1).to(torch.int32).contiguous(), self.embed, out=hid)
+            slot = torch.full((B * k,), S + step, device=dev, dtype=torch.int32)
+            self.forward(hid, B * k, 1, pos, slot, kstart_k, ctx=S + step + 1)
+            nh = self.final_norm_rows(hid).float().view(B, k, H)
+            cand_logits = self.logits(hid).float().view(B, k, V)
+            cn = ctx_h / ctx_h.norm(dim=2, keepdim=True)
+            nn_ = nh / nh.norm(dim=2, keepdim=True)
+            cos = torch.einsum("bld,bkd->bkl", cn, nn_).masked_fill(~ctx_ok[:, None, :], -float("inf"))
+            sel = ((1.0 - penalty_alpha) * top_p_ - penalty_alpha * cos.max(dim=-1)[0]).argmax(dim=-1)   # [B]
+            nxt = top_ids[ar, sel]
+            nxt = nxt * unfinished + pad_id * (1 - unfinished)
+            out[:, step] = nxt
+            n = step + 1
+            unfinished = unfinished * (nxt != eos_id).long()
+            if int(unfinished.max().item()) == 0 or n == max_new_tokens:
+                break
+            # the kept candidate's KV slot goes to its k - 1 siblings; its hidden state joins the context
+            src = (ar * k + sel).repeat_interleave(k)
+            self.kcache[:, :, :, S + step] = self.kcache[:, src, :, S + step]
+            self.vcache[:, :, :, S + step] = self.vcache[:, src, :, S + step]
+            ctx_h = torch.cat((ctx_h, nh[ar, sel][:, None, :]), dim=1)
+            ctx_ok = torch.cat((ctx_ok, torch.ones(B, 1, dtype=torch.bool, device=dev)), dim=1)
+            logit = cand_logits[ar, sel]
+            pos = pos + 1
+        self.ctx.check_p2p()
+        return out[:, :n]
+
     # ------------------------------------------------------------------ beam search
     @torch.no_grad()
     def beam_search_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, num_beams: int,

@@ -62,6 +62,9 @@ class FakeEngine:
         hidden.copy_(h.view(B, -1))
         return hidden
 
+    def final_norm_rows(self, hidden):
+        return R.rms_norm(hidden.float(), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
+
     def logits(self, rows, out=None):
         h = R.rms_norm(rows.float(), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
         return torch.nn.functional.linear(h, self.W["decoder.lm.lm_head.weight"])

@@ -157,6 +157,22 @@ def test_generate_beam_sampling_and_penalised_beams(tiny_model, golden_dir):
     assert any(same), (pen.tolist(), z["bs_penalty"].tolist())
 
 
+def test_generate_contrastive_search(tiny_model, golden_dir):
+    """Contrastive search on the GPU engine (k candidate rows per prompt sharing the prompt KV, sibling KV copy): with
+    penalty_alpha = 0 (pure top-1 probability) it must emit the real reference's greedy ids, with and without an image;
+    a real penalty runs, stays in the vocabulary and differs from greedy on the prompt where the CPU statement differs
+    (tests/test_host_logic.py pins that against an uncached restatement)."""
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    img = _t(z["image"]).cuda()
+    g1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), img, max_new_tokens=8, penalty_alpha=1e-9, top_k=4)
+    assert g1.cpu().tolist() == z["new1"].tolist()
+    g2 = m.generate_ids(_t(z["ids2"]), _t(z["mask2"]), None, max_new_tokens=6, penalty_alpha=1e-9, top_k=3)
+    assert g2.cpu().tolist() == z["new2"].tolist()
+    c2 = m.generate_ids(_t(z["ids2"]), _t(z["mask2"]), None, max_new_tokens=5, penalty_alpha=0.6, top_k=4).cpu()
+    assert c2.shape == (2, 5) and int(c2.max()) < 32274 and c2.tolist() != z["new2"][:, :5].tolist()
+
+
 def test_generate_graph_replay_equals_eager(tiny_model, golden_dir):
     m, W, cfg = tiny_model
     z = tiny.load(golden_dir, "generate_tiny.npz")

@@ -144,6 +144,70 @@ def test_product_beam_sampling_and_penalty_match_reference(golden_dir, monkeypat
     assert out.tolist() == z[case].tolist()
 
 
+def _contrastive_uncached(x, mask, W, cfg, n_new, alpha, k, eos_id=2, pad_id=32000):
+    """Contrastive search by full recomputation (no KV cache, no candidate batching): an independent statement of the
+    algorithm (transformers 4.31 ``contrastive_search`` / ``_ranking_fast``) on the oracle's decoder, left-padding positions
+    left out of the similarity like the product does."""
+    B, S, _ = x.shape
+    lmw, nw = W["decoder.lm.lm_head.weight"], W["decoder.lm.model.norm.weight"]
+    seqs = [x[b:b + 1] for b in range(B)]
+    masks = [mask[b:b + 1] for b in range(B)]
+    out = torch.full((B, n_new), pad_id, dtype=torch.int64)
+    done = [False] * B
+    for step in range(n_new):
+        for b in range(B):
+            if done[b]:
+                continue
+            h = R.llama_model(seqs[b], masks[b], W, cfg.llama)                      # final-norm hidden states [1, L, H]
+            logit = torch.nn.functional.linear(h[0, -1], lmw).float()
+            if step < 1:
+                logit[eos_id] = -float("inf")
+            p, ids = torch.topk(torch.softmax(logit, -1), k)
+            ok = masks[b][0].bool()
+            best, best_sc = None, None
+            for j in range(k):
+                xe = torch.cat((seqs[b], R.embed_tokens(ids[j].view(1, 1), W)), dim=1)
+                me = torch.cat((masks[b], torch.ones(1, 1, dtype=masks[b].dtype)), dim=1)
+                hh = R.llama_model(xe, me, W, cfg.llama)[0]
+                cos = torch.nn.functional.cosine_similarity(hh[:-1][ok], hh[-1:], dim=-1)
+                sc = (1 - alpha) * float(p[j]) - alpha * float(cos.max())
+                if best is None or sc > best_sc:
+                    best, best_sc = j, sc
+            t = int(ids[best])
+            out[b, step] = t
+            seqs[b] = torch.cat((seqs[b], R.embed_tokens(torch.tensor([[t]]), W)), dim=1)
+            masks[b] = torch.cat((masks[b], torch.ones(1, 1, dtype=masks[b].dtype)), dim=1)
+            done[b] = t == eos_id
+        if all(done):
+            return out[:, :step + 1]
+    return out
+
+
+def test_product_contrastive_search(golden_dir, monkeypatch):
+    """LlamaEngine.contrastive_generate (candidate rows sharing the prompt KV, sibling KV copy, hidden-state context) on
+    the CPU stand-in engine: penalty_alpha = 0 and top_k = 1 must reproduce the REAL reference's greedy ids, and a real
+    setting (alpha 0.6, k 4) must equal an uncached full-recomputation statement of the algorithm."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    ids, mask = t(z["ids2"]), t(z["mask2"])
+    x = R.embed_tokens(ids, W)
+    new_eng = lambda: FakeEngine(l, vocab, W, cfg.llama)
+    assert L.LlamaEngine.contrastive_generate(new_eng(), x, mask, 6, 0.0, 4).tolist() == z["new2"].tolist()
+    assert L.LlamaEngine.contrastive_generate(new_eng(), x, mask, 6, 0.6, 1).tolist() == z["new2"].tolist()
+    got = L.LlamaEngine.contrastive_generate(new_eng(), x, mask, 5, 0.6, 4)
+    want = _contrastive_uncached(x, mask, W, cfg, 5, 0.6, 4)
+    assert got.tolist() == want.tolist()
+    assert got.tolist() != z["new2"][:, :5].tolist()          # the penalty actually changes the choice on this prompt
+
+
 def test_emu1_lora_merge_both_peft_layouts():
     """Emu1 instruct checkpoints carry peft LoRA adapters (Emu1/inference.py:40-51); the loader folds them into the base
     matrices: W' = W + (alpha / r) * B @ A, for both peft key layouts, and leaves adapter-free dicts untouched."""
