@@ -306,6 +306,9 @@ inline PpPlan pick_pp(const GemmArgs& a) {
         const int rounds = (tp + CU - 1) / CU;
         return (p.ksplit > 1 || tp * 10 >= rounds * CU * 7) ? p : no;
     }
+    // under a quarter round (UNet ff-out / 32^2 convs: 40 tiles, ViT fc2: 28) the K-sliced 256x128 tile has twice the slices to
+    // spread and smaller slabs: same-run A/B of the denoise step 28.3 -> 27.8 ms (the micro-benchmark had them level)
+    if (tp < 64) return no;
     if (p.ksplit > 1 && nk / p.ksplit >= 16 && tp * p.ksplit >= 150) return p;
     return (tp >= 150 && nk >= 32) ? PpPlan{true, tp, 1, 0.0} : no;
 }
@@ -317,7 +320,7 @@ inline PpPlan pick_pp(const GemmArgs& a) {
 // only: W rows, bias, residual / output columns -- half of them for the interleaved GLU pairs).  n1 = 0: not applicable.
 // The heuristic takes it for f <= 3/8 of a round when the cost model would not K-slice the tail (short K): measured
 // (profiles/r02_gemm_ab_v12_hybrid.log) UNet GEGLU 608 (256x128) / 701 (256x256, two rounds) -> 747 TFLOP/s, denoise step
-// 29.0 -> 27.7 ms; with long K the sliced tail stays ahead (S=1544 gate/up 1124 vs 1066) and at f = 1/2 the plain rounds do.
+// 29.1 -> 28.3 ms (same-run A/B); with long K the sliced tail stays ahead (S=1544 gate/up 1124 vs 1066) and at f = 1/2 the plain rounds do.
 inline int plan_hybrid(const GemmArgs& a, bool forced) {
     if (!gemm256_ok(a) || a.M < 192 || a.K / BK < 8 || a.conv.mode != CONV_NONE) return 0;
     const int CU = 256, tn = (a.N + 255) / 256, tp = gemm256_tiles(a), tm = tp / tn;
