@@ -154,6 +154,8 @@ int emu_tp_p2p_create(emu_ctx* ctx, void* handle64_out) {
 
 int emu_tp_p2p_open(emu_ctx* ctx, const void* handles, int timeout_ms) {
     if (!ctx || !ctx->p2p) return -22;
+    hipError_t e = hipSetDevice(ctx->device);              // the peer blocks are mapped for this context's device
+    if (e != hipSuccess) return fail(ctx, (int)e, "hipSetDevice");
     emu_p2p_set_timeout_ms(ctx->p2p, timeout_ms);
     int st = emu_p2p_open(ctx->p2p, handles);
     return st == 0 ? 0 : fail(ctx, st, "hipIpcOpenMemHandle");
