@@ -257,12 +257,12 @@ def test_true_width_single_layer_decode_and_prefill():
     assert rel_err(step, want1[:, 0]) < 2e-2, rel_err(step, want1[:, 0])
 
 
-@pytest.mark.parametrize("heads,D", [(4, 64), (3, 128)])
+@pytest.mark.parametrize("heads,D", [(4, 64), (3, 128), (9, 128)])
 @pytest.mark.parametrize("s_max", [256, 1024, 2048])
-@pytest.mark.parametrize("S,pad", [(1, 0), (37, 0), (200, 13), (255, 0)])
+@pytest.mark.parametrize("S,pad", [(1, 0), (37, 0), (200, 13), (255, 0), (511, 0), (600, 21), (1100, 0)])
 def test_decode_attention_paths(heads, D, s_max, S, pad):
     """A cached decode step against the CPU oracle: both head dims, KV capacities with and without dead splits, left
-    padding, contexts that end inside / at the edge of a 128-key split, batch 2."""
+    padding, contexts that end inside / at the edge of a 128-key split and several splits long, batch 2."""
     from emu_amd import synth
     from emu_amd.conf.emu_conf import LlamaCfg
     from emu_amd.llama import EmuHipContext, LlamaEngine
