@@ -248,18 +248,22 @@ def config_legs(m, lm, ctx, dev, vcfg, lcfg, img, unet_eng):
             if unet_eng is not None:
                 neg = torch.randint(3, 32000, (1, 1), generator=g)
 
+                # prompt and negative prompt as the pipeline's first call runs them (emu_amd/diffusion.py): two left-padded rows
+                # of one batch, each on its own positions, one weight stream per step for both
+                both_ids = torch.cat((pid, torch.cat((torch.full((1, 19), 32000, dtype=pid.dtype), neg), dim=1)), dim=0)
+                both_mask = torch.ones(2, 20, dtype=torch.long)
+                both_mask[1, :19] = 0
+
                 def chain():
-                    cond = m.generate_image_ids(pid)
-                    unc = m.generate_image_ids(neg)
-                    prompt = torch.cat([cond, unc], dim=0).to(torch.bfloat16)
+                    prompt = m.generate_image_ids(both_ids, None, both_mask).to(torch.bfloat16)      # [cond, uncond]
                     sch = unet_eng.set_timesteps(50)
                     unet_eng.set_context(prompt, 1024, 1024)
                     lat = (torch.randn(1, 4, 128, 128, device=dev) * sch.init_noise_sigma).to(torch.bfloat16).contiguous()
                     lat = unet_eng.denoise(lat, 3.0, use_graph=True)
                     return vae.decode_latents(lat)
                 t_e2e, image = timed(chain)
-                out["any_to_image_e2e"] = {"config": "BASELINE.json configs[4] at TP=1, bf16: generate_image (prompt) + generate_image "
-                                                     "(negative prompt, uncached here) -> 50-step CFG denoise (hipGraph) -> VAE decode, "
+                out["any_to_image_e2e"] = {"config": "BASELINE.json configs[4] at TP=1, bf16: generate_image of prompt + negative prompt (uncached "
+                                                     "here) as two rows of one batch -> 50-step CFG denoise (hipGraph) -> VAE decode, "
                                                      "1024x1024", "ms": t_e2e * 1e3, "finite": bool(torch.isfinite(image.float()).all())}
         finally:
             m.n_query = nq_saved

@@ -76,11 +76,15 @@ class EmuVisualGeneration:
                     self.negative_prompt[key] = enc.encode_image(image=torch.zeros_like(image_prompt))
                 prompt = torch.cat([prompt, self.negative_prompt[key]], dim=0)
         else:                                                        # image generation mode
-            prompt = enc.generate_image(text=[text_prompt], image=image_prompt)
+            key = ""
+            if do_classifier_free_guidance and key not in self.negative_prompt:
+                # first call: the prompt and the (cached from now on) negative prompt ride one weight stream -- two rows of
+                # one batch, each on its own positions, i.e. what the reference's two batch-size-1 calls compute
+                both = enc.generate_image(text=[text_prompt, key], image=image_prompt, warn_ragged=False)
+                prompt, self.negative_prompt[key] = both[:1], both[1:]
+            else:
+                prompt = enc.generate_image(text=[text_prompt], image=image_prompt)
             if do_classifier_free_guidance:
-                key = ""
-                if key not in self.negative_prompt:
-                    self.negative_prompt[key] = enc.generate_image(text=[key])
                 prompt = torch.cat([prompt, self.negative_prompt[key]], dim=0)      # cond FIRST
         return prompt
 

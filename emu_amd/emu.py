@@ -220,9 +220,12 @@ class EmuModel:
 
     # ------------------------------------------------------------------ generate_image (emu.py:92-153)
     @torch.no_grad()
-    def generate_image_ids(self, prompt_ids: torch.Tensor, image: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Visual-embedding regression at the token-id level for rows of equal length (no padding):
-        prompt + [IMG] prefill, then n_query-1 cached steps with input project_up(project_down(h_prev))."""
+    def generate_image_ids(self, prompt_ids: torch.Tensor, image: Optional[torch.Tensor] = None,
+                           attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Visual-embedding regression at the token-id level: prompt + [IMG] prefill, then n_query-1 cached steps with input
+        project_up(project_down(h_prev)).  Rows of different length arrive LEFT-padded with ``attention_mask``; every row then
+        sees the positions 0..len-1 of its own tokens (pads are masked out of the attention), i.e. exactly what it computes
+        alone -- the rows share one weight stream per step instead of being run one by one."""
         lm = self.decoder.lm
         B, S0 = prompt_ids.shape
         ids = torch.cat((prompt_ids.to(torch.int64), torch.full((B, 1), IMG_TOKEN_ID, dtype=torch.int64)), dim=1)
@@ -231,10 +234,13 @@ class EmuModel:
             raise ValueError("prompt too long for generate_image")
         x = self._prompt_embeds(ids, image, self.n_query, IMAGE_TOKEN_ID)
         mask = torch.ones(B, S, dtype=torch.int64)
-        hidden, kstart, _ = lm.prefill(x.view(B, S, -1), mask, hf_generate_positions=False)
+        if attention_mask is not None:
+            mask[:, :S0] = attention_mask.to(torch.int64)
+        # positions from the mask: arange(S) for an unpadded row (what the reference's lm.model call uses), the row's own
+        # 0..len-1 behind left padding
+        hidden, kstart, pos = lm.prefill(x.view(B, S, -1), mask, hf_generate_positions=True)
         h = lm.final_norm_rows(hidden[:, -1, :].contiguous())
         outs = [self._project(h, self.project_down)]                               # [B, width]
-        pos = torch.full((B,), S, device=self.ctx.device, dtype=torch.int32)
         for j in range(self.n_query - 1):
             xin = self._project(outs[-1], self.project_up)                        # [B, hidden]
             hj = lm.decode_embeds(xin, pos, S + j, kstart)
@@ -244,26 +250,24 @@ class EmuModel:
 
     @torch.no_grad()
     def generate_image(self, text: List[str], image: Optional[torch.Tensor] = None,
-                       placeholder: str = DEFAULT_IMG_PLACEHOLDER):
+                       placeholder: str = DEFAULT_IMG_PLACEHOLDER, warn_ragged: bool = True):
         tok = self.decoder.tokenizer
         text = [t.replace(placeholder, self.image_placeholder) for t in text]
         inputs = tok(text, padding="longest", return_tensors="pt")
         if not bool(inputs.attention_mask.all()):
-            # the reference re-pads every iteration and calls lm.model without position_ids, so
-            # its left-padded rows see RoPE positions shifted by their pad count; rows of different length are run one
-            # by one here, which is what the same rows compute un-padded (= the reference at batch size 1).
+            # the reference re-pads every iteration and calls lm.model without position_ids, so its
+            # left-padded rows see RoPE positions shifted by their pad count; here every row keeps the positions of its own
+            # tokens, which is what the same rows compute un-padded (= the reference at batch size 1).
             import warnings
-            warnings.warn("generate_image: prompts of different token lengths are computed one by one (as at batch size 1); "
-                          "the reference's batched call shifts the RoPE positions of its left-padded rows and returns "
-                          "different embeddings for them", stacklevel=2)
-            outs = []
-            for i, t in enumerate(text):
-                one = tok([t], return_tensors="pt").input_ids
-                img = None
-                if image is not None:
-                    n_img = [x.count(self.image_placeholder) for x in text]
-                    a = sum(n_img[:i])
-                    img = image[a:a + n_img[i]]
-                outs.append(self.generate_image_ids(one, img))
-            return torch.cat(outs, dim=0)
+            if warn_ragged:
+                warnings.warn("generate_image: prompts of different token lengths are computed as at batch size 1 (each row on "
+                              "its own positions); the reference's batched call shifts the RoPE positions of its left-padded "
+                              "rows and returns different embeddings for them", stacklevel=2)
+            if tok.padding_side != "left":
+                tok.padding_side, side = "left", tok.padding_side
+                try:
+                    inputs = tok(text, padding="longest", return_tensors="pt")
+                finally:
+                    tok.padding_side = side
+            return self.generate_image_ids(inputs.input_ids, image, inputs.attention_mask)
         return self.generate_image_ids(inputs.input_ids, image)

@@ -228,6 +228,27 @@ def test_generate_image_matches_reference(tiny_model, golden_dir):
     assert rel_err(out, want) < 3e-2, rel_err(out, want)
 
 
+def test_generate_image_ragged_batch_equals_rows_alone(tiny_model, golden_dir):
+    """Prompts of different length in one batch (left-padded, every row on the positions of its own tokens, one weight stream
+    per step for all rows) against the same rows run alone -- which is what the oracle's uncached loop, the reference
+    algorithm at batch size 1, computes."""
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_image_tiny.npz")
+    long_ = _t(z["prompt_text"])                                   # [1, S]
+    S = long_.shape[1]
+    short = long_[:, S - 3:]                                       # its last three tokens as a second, shorter prompt
+    ids = torch.cat((long_, torch.cat((torch.full((1, S - 3), 32000, dtype=long_.dtype), short), dim=1)), dim=0)
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[1, :S - 3] = 0
+    both = m.generate_image_ids(ids, None, mask)
+    a = m.generate_image_ids(long_, None)
+    b = m.generate_image_ids(short, None)
+    assert rel_err(both[0], a[0]) < 2e-2 and rel_err(both[1], b[0]) < 2e-2, (rel_err(both[0], a[0]), rel_err(both[1], b[0]))
+    want = R.emu_generate_image_uncached(short, None, W, cfg)
+    assert rel_err(both[1:], want) < 3e-2, rel_err(both[1:], want)
+
+
 def test_true_width_single_layer_decode_and_prefill():
     """One LLaMA-33B-shaped layer (hidden 6656, 52 heads, ffn 17920) against the CPU oracle: prefill S=96 and a
     cached decode step -- exercises the real GEMV/GEMM/attention shapes of the bench."""
