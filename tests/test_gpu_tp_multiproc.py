@@ -61,3 +61,16 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["parallelism"].startswith("tp2") and "p2p" in d["config"]["allreduce"] and d["config"]["valid"] is False
     assert {"roofline", "metric", "unit", "ms_per_step", "higher_is_better", "dtype", "data"} <= set(d)
+
+
+def test_p2p_setup_failure_is_refused_not_hung():
+    """Corrupted IPC handles: the peer-to-peer path must come up disabled on every rank without hanging; with no RCCL communicator
+    to fall back on (ranks sharing one GPU) init_tp raises."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", EMU_TP_SHARED_GPU="1", EMU_TP_BREAK_P2P="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "tp_engine_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("refused as expected") == 2, r.stdout[-3000:]

@@ -82,6 +82,21 @@ def main():
         return box
 
     ctx = EmuHipContext(dev, rank, world)
+    if os.environ.get("EMU_TP_BREAK_P2P") == "1":
+        # failure path: every peer handle arrives corrupted -> the mapping (or the self-test) fails on every rank, nothing hangs,
+        # and without an RCCL communicator to fall back on init_tp must raise
+        def broken(b):
+            got = allgather(b)
+            return [x if (i == rank or len(x) != 64) else bytes(64) for i, x in enumerate(got)]
+        try:
+            ctx.init_tp(bcast, allgather_bytes=broken, rccl=not shared, p2p_timeout_ms=500)
+        except RuntimeError as e:
+            print(f"rank {rank}: refused as expected: {e}", flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(0)
+        print(f"rank {rank}: p2p={ctx.p2p} (expected a refusal)", flush=True)
+        sys.exit(0 if (not shared and not ctx.p2p) else 1)
     ctx.init_tp(bcast, allgather_bytes=allgather, rccl=not shared, p2p_timeout_ms=3000)
     print(f"rank {rank}: p2p all-reduce {'on' if ctx.p2p else 'OFF (RCCL only)'}", flush=True)
     ok = True
