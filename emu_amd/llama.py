@@ -422,7 +422,8 @@ class LlamaEngine:
     @torch.no_grad()
     def contrastive_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int,
                              penalty_alpha: float, top_k: int, min_len: int = 1, repetition_penalty: float = 1.0,
-                             eos_id: int = 2, pad_id: int = 32000) -> torch.Tensor:
+                             eos_id: int = 2, pad_id: int = 32000, trace: Optional[dict] = None,
+                             force_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``lm.generate(inputs_embeds=..., penalty_alpha=a, top_k=k)`` -- contrastive search as the reference's pinned
         transformers 4.31 runs it (Emu2/emu/emu.py:167,223 forwards both arguments): per step the k most probable tokens
         are each run one step further, and the one maximising (1 - a) * p(token) - a * max_j cos(h_token, h_j) over the
@@ -430,7 +431,12 @@ class LlamaEngine:
         step that share the prompt's KV rows (as beams do); the kept candidate's KV slot is then copied to its siblings.
         a = 0 or k = 1 degenerate to greedy search (tested against the real reference's greedy ids).  Deviation: hidden
         states of left-padding positions are left out of the similarity (the library includes whatever the masked rows
-        hold).  Parity beyond those invariants is unpinned: the transformers in this image no longer ships the mode."""
+        hold).  Parity beyond those invariants is unpinned: the transformers in this image no longer ships the mode.
+
+        Diagnostics for the tests: ``trace`` receives ``margin`` (smallest winner / runner-up score gap) and ``steps`` (per
+        step the candidate ids, their probabilities, their degeneration penalties and the selection, on the host);
+        ``force_ids`` [B, n] replays a given token path (each forced token must be one of the step's k candidates) so two
+        engines can be compared number by number along the same path."""
         B, S, H = embeds.shape
         k, V, dev = int(top_k), self.vocab, self.device
         s_max = self.kv_capacity(S + max_new_tokens)
@@ -463,7 +469,20 @@ class LlamaEngine:
             cn = ctx_h / ctx_h.norm(dim=2, keepdim=True)
             nn_ = nh / nh.norm(dim=2, keepdim=True)
             cos = torch.einsum("bld,bkd->bkl", cn, nn_).masked_fill(~ctx_ok[:, None, :], -float("inf"))
-            sel = ((1.0 - penalty_alpha) * top_p_ - penalty_alpha * cos.max(dim=-1)[0]).argmax(dim=-1)   # [B]
+            pen = cos.max(dim=-1)[0]
+            score = (1.0 - penalty_alpha) * top_p_ - penalty_alpha * pen
+            sel = score.argmax(dim=-1)                                                                    # [B]
+            if force_ids is not None:
+                hit = top_ids == force_ids[:, step, None].to(dev)
+                if not bool((hit.any(dim=1) | ~unfinished.bool()).all()):
+                    raise ValueError(f"contrastive_generate: forced token of step {step} is not among the {k} candidates")
+                sel = torch.where(unfinished.bool(), hit.float().argmax(dim=1), sel)
+            if trace is not None:
+                t2 = torch.topk(score, k=2, dim=-1)[0]
+                gap = torch.where(unfinished.bool(), t2[:, 0] - t2[:, 1], torch.full_like(t2[:, 0], float("inf")))
+                trace["margin"] = min(trace.get("margin", float("inf")), float(gap.min()))
+                trace.setdefault("steps", []).append(dict(ids=top_ids.cpu(), p=top_p_.float().cpu(), pen=pen.float().cpu(),
+                                                          sel=sel.cpu(), live=unfinished.bool().cpu()))
             nxt = top_ids[ar, sel]
             nxt = nxt * unfinished + pad_id * (1 - unfinished)
             out[:, step] = nxt
@@ -488,7 +507,8 @@ class LlamaEngine:
                              max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0, eos_id: int = 2,
                              pad_id: int = 32000, do_sample: bool = False, temperature: Optional[float] = None,
                              top_k: Optional[int] = None, top_p: Optional[float] = None,
-                             repetition_penalty: float = 1.0) -> torch.Tensor:
+                             repetition_penalty: float = 1.0, hf_semantics: str = "4.31",
+                             trace: Optional[dict] = None) -> torch.Tensor:
         """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False, early_stopping=False)`` -- the reference's
         DEFAULT decoding mode (num_beams=5, length_penalty=-1, Emu2/emu/emu.py:163-172,213-229).  Restates
         transformers' vectorised beam search: per step keep the 2N best continuations over beams x vocab, the N best
@@ -500,7 +520,21 @@ class LlamaEngine:
         ``do_sample=True`` is the library's *beam-search multinomial sampling*: the per-beam log-probabilities go through
         the logits pipeline (repetition penalty, min length, temperature / top-k / top-p with min_tokens_to_keep = 2)
         BEFORE the beam scores are added, and the 2N continuations are drawn without replacement from
-        softmax(accumulated scores) instead of taken by top-k.  ``repetition_penalty`` alone gives penalised beam search."""
+        softmax(accumulated scores) instead of taken by top-k.  ``repetition_penalty`` alone gives penalised beam search.
+
+        ``hf_semantics`` selects the ORDER of the sampling pipeline, which changed between the transformers the reference
+        pins (4.31, ``Emu2/requirements.txt:2``) and the one installed here (5.x, the only one that can be run, so the
+        only one the golden fixture pins): "4.31" = ``beam_sample`` of that release -- logits processors, THEN the running
+        beam scores are added, THEN the warpers (temperature / top-k / top-p) act on the accumulated rows, and the 2N
+        draws are sorted by score before the beam bookkeeping (so "only the first N candidates may finish" is by rank, not
+        by draw order), and all N beams start at score 0 instead of (0, -1e9, ...); "5.x" = processors and warpers on the per-beam log-probabilities, scores added afterwards, draws
+        kept in draw order.  With temperature 1 and no top-k / top-p the two differ only in the sort.  The deterministic
+        modes (do_sample=False) are the same in both.
+
+        ``trace`` (a dict, diagnostics for the tests): receives ``margin`` = the smallest gap seen between the N-th and the
+        (N+1)-th running candidate at a pruning step and between the two best final results."""
+        if hf_semantics not in ("4.31", "5.x"):
+            raise ValueError("hf_semantics must be '4.31' or '5.x'")
         B, S, H = embeds.shape
         nb, V, dev = num_beams, self.vocab, self.device
         s_max = self.kv_capacity(S + max_new_tokens)
@@ -522,7 +556,8 @@ class LlamaEngine:
         running_seq = torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=dev)
         sequences = running_seq.clone()
         running_scores = torch.zeros(B, nb, device=dev)
-        running_scores[:, 1:] = NEG
+        if not (do_sample and hf_semantics == "4.31"):
+            running_scores[:, 1:] = NEG             # 4.31's beam_sample starts EVERY beam at 0 (the draws tell them apart)
         beam_scores = torch.full((B, nb), NEG, device=dev)
         finished = torch.zeros(B, nb, dtype=torch.bool, device=dev)
         seq_len = torch.zeros(B, nb, dtype=torch.int64, device=dev)                     # generated length of kept results
@@ -533,19 +568,27 @@ class LlamaEngine:
 
         cur = 0
         lp_rows = logits[:, None, :].expand(B, nb, V)                                   # step 0: every beam = the prompt
+        margin = float("inf")
+        old = do_sample and hf_semantics == "4.31"
         while True:
             log_probs = torch.log_softmax(lp_rows, dim=-1)
             if do_sample or repetition_penalty != 1.0:
                 log_probs = process_logits(log_probs.reshape(B * nb, V), running_seq[:, :, :cur].reshape(B * nb, cur), cur < min_len,
-                                           eos_id, do_sample, temperature, top_k, top_p, repetition_penalty,
+                                           eos_id, do_sample and not old, temperature, top_k, top_p, repetition_penalty,
                                            min_keep=2).view(B, nb, V)
             elif cur < min_len:
                 log_probs = log_probs.clone()
                 log_probs[..., eos_id] = -float("inf")
-            acc = (log_probs + running_scores[:, :, None]).reshape(B, nb * V)
+            acc = log_probs + running_scores[:, :, None]
+            if old:                                    # 4.31 beam_sample: the warpers see the ACCUMULATED scores
+                acc = warp_logits(acc.reshape(B * nb, V), temperature, top_k, top_p, min_keep=2).view(B, nb, V)
+            acc = acc.reshape(B, nb * V)
             if do_sample:
                 top_idx = torch.multinomial(torch.softmax(acc, dim=-1), num_samples=2 * nb)
                 top_lp = torch.gather(acc, 1, top_idx)
+                if old:                                # ... and its draws are ranked before the beam scorer sees them
+                    top_lp, order = torch.sort(top_lp, descending=True, dim=1)
+                    top_idx = torch.gather(top_idx, 1, order)
             else:
                 top_lp, top_idx = torch.topk(acc, k=2 * nb)
             src_beam = top_idx // V
@@ -556,6 +599,9 @@ class LlamaEngine:
             # running beams for the next step: best N non-finished candidates
             run_lp = top_lp + hits.float() * NEG
             nxt = torch.topk(run_lp, k=nb)[1]
+            if trace is not None and cur + 1 < max_len:
+                srt = torch.sort(run_lp, dim=1, descending=True)[0]
+                margin = min(margin, float((srt[:, nb - 1] - srt[:, nb]).min()))
             running_seq = gather(cand_seq, nxt)
             running_scores = torch.gather(run_lp, 1, nxt)
             beam_idx = torch.gather(src_beam, 1, nxt)                                   # which old beam each new beam extends
@@ -595,6 +641,8 @@ class LlamaEngine:
             pos = pos + 1
             lp_rows = self.logits(hid).float().view(B, nb, V)
         out_len = int(seq_len[:, 0].max().item())
+        if trace is not None:
+            trace["margin"] = min(margin, float((beam_scores[:, 0] - beam_scores[:, 1]).min()))
         self.ctx.check_p2p()
         return sequences[:, 0, :out_len]
 
@@ -615,17 +663,24 @@ def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: 
         scores = scores.clone()
         scores[:, eos_id] = -float("inf")
     if do_sample:
-        if temperature is not None and temperature != 1.0:
-            scores = scores / temperature
-        if top_k is not None and top_k > 0:
-            kth = torch.topk(scores, min(max(top_k, min_keep), scores.shape[-1]))[0][..., -1, None]
-            scores = scores.masked_fill(scores < kth, -float("inf"))
-        if top_p is not None and top_p < 1.0:
-            srt, idx = torch.sort(scores, descending=False)
-            cum = srt.softmax(dim=-1).cumsum(dim=-1)
-            remove = cum <= (1 - top_p)
-            remove[..., -min_keep:] = False
-            scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
+        scores = warp_logits(scores, temperature, top_k, top_p, min_keep)
+    return scores
+
+
+def warp_logits(scores: torch.Tensor, temperature: Optional[float] = None, top_k: Optional[int] = None,
+                top_p: Optional[float] = None, min_keep: int = 1) -> torch.Tensor:
+    """transformers' sampling warpers in their order: TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper."""
+    if temperature is not None and temperature != 1.0:
+        scores = scores / temperature
+    if top_k is not None and top_k > 0:
+        kth = torch.topk(scores, min(max(top_k, min_keep), scores.shape[-1]))[0][..., -1, None]
+        scores = scores.masked_fill(scores < kth, -float("inf"))
+    if top_p is not None and top_p < 1.0:
+        srt, idx = torch.sort(scores, descending=False)
+        cum = srt.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[..., -min_keep:] = False
+        scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
     return scores
 
 

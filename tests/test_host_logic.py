@@ -140,8 +140,133 @@ def test_product_beam_sampling_and_penalty_match_reference(golden_dir, monkeypat
     kw = dict(kw)
     nb, n_new = kw.pop("num_beams"), kw.pop("max_new_tokens")
     torch.manual_seed(int(z["seed"]))
-    out = L.LlamaEngine.beam_search_generate(eng, x, t(z["mask"]), nb, n_new, **kw)
+    # the fixture was drawn by the transformers installed here (5.x ordering of the sampling pipeline)
+    out = L.LlamaEngine.beam_search_generate(eng, x, t(z["mask"]), nb, n_new, hf_semantics="5.x", **kw)
     assert out.tolist() == z[case].tolist()
+
+
+def test_product_beam_modes_on_margin_fixtures(golden_dir, monkeypatch):
+    """The fixtures the GPU tests hold the bf16 engine to (tests/golden/generate_margin_tiny.npz, oracle/make_golden_r3.py):
+    penalised 3-beam search on a ragged batch and the default 5-beam search with an image -- ids of the REAL reference,
+    reproduced by the product's host logic in fp32 with every pruning margin >= 0.08 nat."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_margin_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    tr = {}
+    out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), R.embed_tokens(t(z["pen_ids"]), W), t(z["pen_mask"]),
+                                             3, 8, repetition_penalty=1.5, trace=tr)
+    assert out.tolist() == z["pen_new"].tolist() and tr["margin"] >= 0.08, tr
+    assert not bool(t(z["pen_mask"]).all())
+    ids = t(z["b5_ids"])
+    e = R.encode_image(t(z["image"]), W, cfg)
+    x = R.scatter_image_embeds(R.embed_tokens(ids, W), ids, torch.nn.functional.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"]))
+    tr = {}
+    out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, t(z["b5_mask"]), 5, int(z["b5_n_new"]), trace=tr)
+    assert out.tolist() == z["b5_new"].tolist() and tr["margin"] >= 0.08, tr
+
+
+def _beam_sample_431(x, mask, W, cfg, nb, n_new, temperature, top_k, top_p, eos_id=2, pad_id=32000, length_penalty=-1.0):
+    """``GenerationMixin.beam_sample`` + ``BeamSearchScorer`` as transformers 4.31 (the version the reference pins) states
+    them, written per hypothesis with python lists and full recomputation of the decoder -- an independent statement of the
+    ordering the product's hf_semantics="4.31" mode claims: log_softmax -> MinLength -> + beam score -> temperature ->
+    top-k -> top-p (min_tokens_to_keep 2) -> multinomial(2N) -> sort by score -> scorer.  The 5.x scorer conventions the
+    product keeps in BOTH modes (a finished hypothesis is scored over its length INCLUDING the EOS; early stop by the
+    current length) are used here too: this test pins the sampling order, not the scorer."""
+    B, S, _ = x.shape
+    V = W["decoder.lm.lm_head.weight"].shape[0]
+    seqs = [[[] for _ in range(nb)] for _ in range(B)]
+    scores = torch.zeros(B, nb)
+    hyps = [[] for _ in range(B)]                                      # (score, ids)
+    open_ = [True] * B
+    for cur in range(n_new):
+        nxt_seqs, nxt_scores = [], []
+        all_hit = True
+        for b in range(B):
+            rows = []
+            for j in range(nb):
+                xe = torch.cat((x[b:b + 1], R.embed_tokens(torch.tensor([seqs[b][j]], dtype=torch.long).view(1, -1), W)), dim=1) \
+                    if seqs[b][j] else x[b:b + 1]
+                me = torch.cat((mask[b:b + 1], torch.ones(1, len(seqs[b][j]), dtype=mask.dtype)), dim=1)
+                pos = (me.long().cumsum(-1) - 1).masked_fill(me == 0, 1)
+                h = R.llama_model(xe, me, W, cfg.llama, position_ids=pos)
+                lp = torch.log_softmax(torch.nn.functional.linear(h[0, -1], W["decoder.lm.lm_head.weight"]).float(), -1)
+                if cur < 1:
+                    lp[eos_id] = -float("inf")
+                rows.append(lp + scores[b, j])
+            acc = torch.stack(rows)                                     # [nb, V] accumulated
+            if temperature is not None and temperature != 1.0:
+                acc = acc / temperature
+            if top_k:
+                kth = torch.topk(acc, max(top_k, 2))[0][:, -1:]
+                acc = acc.masked_fill(acc < kth, -float("inf"))
+            if top_p is not None and top_p < 1.0:
+                srt, idx = torch.sort(acc, descending=False)
+                rm = srt.softmax(-1).cumsum(-1) <= (1 - top_p)
+                rm[:, -2:] = False
+                acc = acc.masked_fill(rm.scatter(1, idx, rm), -float("inf"))
+            flat = acc.reshape(-1)
+            draw = torch.multinomial(torch.softmax(flat, -1), num_samples=2 * nb)
+            sc = flat[draw]
+            sc, order = torch.sort(sc, descending=True)
+            draw = draw[order]
+            run = []
+            for rank in range(2 * nb):
+                j, tok = int(draw[rank]) // V, int(draw[rank]) % V
+                hit = tok == eos_id or cur + 1 >= n_new
+                if hit:
+                    if rank < nb and open_[b]:
+                        hyps[b].append((float(sc[rank]) / float((cur + 1) ** length_penalty), seqs[b][j] + [tok]))
+                        hyps[b] = sorted(hyps[b], key=lambda t_: -t_[0])[:nb]
+                elif len(run) < nb:
+                    run.append((float(sc[rank]), seqs[b][j] + [tok]))
+                if not hit:
+                    all_hit = False
+            while len(run) < nb:
+                run.append((-1.0e9, [pad_id] * (cur + 1)))
+            nxt_seqs.append([r[1] for r in run]); nxt_scores.append([r[0] for r in run])
+            if len(hyps[b]) == nb and open_[b]:
+                open_[b] = run[0][0] / float((cur + 1) ** length_penalty) > hyps[b][-1][0]
+        seqs, scores = nxt_seqs, torch.tensor(nxt_scores)
+        if not any(open_) or all_hit:
+            break
+    best = [hyps[b][0][1] for b in range(B)]
+    n = max(len(s) for s in best)
+    return torch.tensor([s + [pad_id] * (n - len(s)) for s in best])
+
+
+@pytest.mark.parametrize("kw", [dict(temperature=0.7, top_k=40, top_p=0.9), dict(temperature=None, top_k=None, top_p=None)])
+def test_product_beam_sample_431_ordering(golden_dir, monkeypatch, kw):
+    """hf_semantics="4.31" (the default: the reference pins transformers 4.31.0): the product's vectorised beam sampling
+    equals a per-hypothesis restatement of that release's pipeline order under the same seed (same number and order of
+    multinomial calls: one per prompt row per step would differ, so the restatement is run at batch size 1)."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_beam_sample_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    ids, mask = t(z["ids"])[1:2], t(z["mask"])[1:2]                   # the unpadded row
+    x = R.embed_tokens(ids, W)
+    torch.manual_seed(99)
+    got = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 3, 6, do_sample=True, **kw)
+    torch.manual_seed(99)
+    want = _beam_sample_431(x, mask, W, cfg, 3, 6, **kw)
+    assert got.tolist() == want.tolist()
+    torch.manual_seed(99)
+    new = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 3, 6, do_sample=True,
+                                             hf_semantics="5.x", **kw)
+    assert new.shape[0] == 1                                            # the other ordering runs; it need not agree
 
 
 def _contrastive_uncached(x, mask, W, cfg, n_new, alpha, k, eos_id=2, pad_id=32000):

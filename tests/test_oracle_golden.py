@@ -52,6 +52,25 @@ def test_generate_greedy_token_exact(golden_dir):
     assert float(m1.min()) > 0.05 and float(m2.min()) > 0.05, (m1, m2)
 
 
+def test_generate_multi_image_token_exact(golden_dir):
+    """Several [<IMG_PLH>] blocks in one prompt with image=[n,3,H,W] (emu.py:196-203), and a ragged batch whose rows carry
+    one and two images: greedy ids of the real reference, margins > 0.05 so a bf16 engine can be held to them."""
+    z = tiny.load(golden_dir, "generate_multi_image_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    imgs = _t(z["images"])
+    for tag, n_new in (("a", 8), ("b", 6)):
+        ids = _t(z["ids_" + tag])
+        n_img = int(z["n_img_" + tag])
+        assert int((ids == 32003).sum()) == n_img * cfg.n_query and n_img >= 2
+        new, m = R.emu_generate(ids, _t(z["mask_" + tag]), imgs[:n_img], W, cfg, max_new_tokens=n_new, return_margins=True)
+        assert new.tolist() == z["new_" + tag].tolist()
+        assert float(m.min()) > 0.05, m
+    # swapping the two images of prompt a must change the result (the scatter is order-preserving, not a set)
+    swapped = R.emu_generate(_t(z["ids_a"]), _t(z["mask_a"]), imgs[:2].flip(0), W, cfg, max_new_tokens=8)
+    assert swapped.tolist() != z["new_a"].tolist()
+
+
 def test_generate_video_token_exact(golden_dir):
     """Video frames ([gIMG] slots, v_query tokens per frame) alone and mixed with an image: ids of the real reference."""
     z = tiny.load(golden_dir, "generate_video_tiny.npz")
