@@ -91,3 +91,42 @@ def test_true_width_denoise_steps_graph_equals_eager(true_unet):
     with torch.no_grad():
         want = U.denoise(lat0.float(), prompt.float(), Wr, steps=steps, guidance=3.0, height=8 * H, width=8 * Wd, cfg=ocfg)
     assert rel_err(a, want) < 5e-2, rel_err(a, want)
+
+
+def test_true_width_unet_at_the_bench_latent_128(true_unet):
+    """BASELINE.json configs[3] at its OWN size: the 128 x 128 latent of a 1024^2 image, CFG batch 2, 64 context tokens -- the
+    shapes bench.py times (M = 32768 / 8192 / 2048 rows at the three levels, 4096-token self-attention at 64^2, 16 K-row
+    GroupNorm partial sums, the 256x256-tile convs and their K-sliced 32^2-level siblings).  One forward (first step) against
+    the fp32 restatement on the host (13.5 TFLOP: tens of seconds of host GEMMs / convs), and one full denoise step
+    (scale -> UNet -> cond-first CFG -> Euler) against the restated loop.  Same tolerances as the 32 x 32 tests above."""
+    import time
+    from oracle import unet_ref as U
+    eng, Wr, ocfg = true_unet
+    H = Wd = 128
+    g = torch.Generator().manual_seed(4)
+    prompt = torch.randn(2, 64, 1792, generator=g).to(BF16)
+    lat = torch.randn(1, 4, H, Wd, generator=g)
+    sch = U.EulerSchedule().set_timesteps(50)
+    eng.set_timesteps(50)
+    eng.set_context(prompt.cuda(), 8 * H, 8 * Wd)
+    time_ids = torch.tensor([1024, 1024, 0, 0, 8 * H, 8 * Wd] * 2)
+    x = (lat * sch.init_noise_sigma).to(BF16)
+    got = eng.forward(x, 0)
+    inp = sch.scale_model_input(torch.cat([x.float()] * 2), 0).to(BF16).float()
+    t0 = time.time()
+    with torch.no_grad():
+        want = U.unet_forward(inp, sch.timesteps[0], prompt.float(), prompt.float().mean(1).to(BF16).float(), time_ids, Wr, ocfg)
+    print(f"128x128 UNet forward: rel L2 {rel_err(got, want):.4f}, host pass {time.time() - t0:.1f} s")
+    assert got.shape == want.shape == (2, 4, H, Wd) and bool(torch.isfinite(got.float()).all())
+    assert rel_err(got, want) < 3e-2, rel_err(got, want)
+    # one CFG + Euler step from the same forward (the restated loop's arithmetic on the oracle's eps), engine eager == graph
+    e_c, e_u = want.chunk(2)
+    want_x = sch.step(e_u + 3.0 * (e_c - e_u), 0, x.float())
+    eng.set_timesteps(50)
+    a = eng.denoise(x.cuda().clone(), guidance=3.0, use_graph=False, steps=1)
+    assert rel_err(a, want_x) < 5e-2, rel_err(a, want_x)
+    eng.set_timesteps(50)
+    b = eng.denoise(x.cuda().clone(), guidance=3.0, use_graph=True, steps=2)      # eager warm-up step + one replayed step
+    eng.set_timesteps(50)
+    c = eng.denoise(x.cuda().clone(), guidance=3.0, use_graph=False, steps=2)
+    assert torch.equal(b.cpu(), c.cpu())
