@@ -145,7 +145,7 @@ def unet_param_shapes(cfg: UNetCfg = UNetCfg()) -> "OrderedDict[str, Tuple[int, 
 def timestep_embedding(timesteps: Tensor, dim: int) -> Tensor:
     """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0, scale=1): fp32 [N, dim] = [cos | sin]."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half
     emb = timesteps.to(torch.float32)[:, None] * torch.exp(exponent)[None, :]
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
 

@@ -97,8 +97,10 @@ def test_true_width_unet_at_the_bench_latent_128(true_unet):
     """BASELINE.json configs[3] at its OWN size: the 128 x 128 latent of a 1024^2 image, CFG batch 2, 64 context tokens -- the
     shapes bench.py times (M = 32768 / 8192 / 2048 rows at the three levels, 4096-token self-attention at 64^2, 16 K-row
     GroupNorm partial sums, the 256x256-tile convs and their K-sliced 32^2-level siblings).  One forward (first step) against
-    the fp32 restatement on the host (13.5 TFLOP: tens of seconds of host GEMMs / convs), and one full denoise step
-    (scale -> UNet -> cond-first CFG -> Euler) against the restated loop.  Same tolerances as the 32 x 32 tests above."""
+    the fp32 restatement and one full denoise step (scale -> UNet -> cond-first CFG -> Euler) against the restated loop, same
+    tolerances as the 32 x 32 tests above.  The restatement (plain torch code) is evaluated in fp32 ON THE DEVICE here -- 13.5
+    TFLOP of fp32 convs / GEMMs take minutes on the host cores -- and tied to its host evaluation at the 32 x 32 latent, where
+    both are run on the same input (< 1e-4)."""
     import time
     from oracle import unet_ref as U
     eng, Wr, ocfg = true_unet
@@ -114,9 +116,20 @@ def test_true_width_unet_at_the_bench_latent_128(true_unet):
     got = eng.forward(x, 0)
     inp = sch.scale_model_input(torch.cat([x.float()] * 2), 0).to(BF16).float()
     t0 = time.time()
+    Wd_ = {k: v.cuda() for k, v in Wr.items()}
+    text = prompt.float().mean(1).to(BF16).float()
     with torch.no_grad():
-        want = U.unet_forward(inp, sch.timesteps[0], prompt.float(), prompt.float().mean(1).to(BF16).float(), time_ids, Wr, ocfg)
-    print(f"128x128 UNet forward: rel L2 {rel_err(got, want):.4f}, host pass {time.time() - t0:.1f} s")
+        want = U.unet_forward(inp.cuda(), sch.timesteps[0].cuda(), prompt.float().cuda(), text.cuda(), time_ids.cuda(), Wd_, ocfg).cpu()
+        # the device evaluation of the restatement == its host evaluation (32 x 32 latent, same input)
+        small = inp[:, :, :32, :32].contiguous()
+        tid32 = torch.tensor([1024, 1024, 0, 0, 256, 256] * 2)
+        on_dev = U.unet_forward(small.cuda(), sch.timesteps[0].cuda(), prompt.float().cuda(), text.cuda(), tid32.cuda(), Wd_, ocfg).cpu()
+        on_host = U.unet_forward(small, sch.timesteps[0], prompt.float(), text, tid32, Wr, ocfg)
+    del Wd_
+    torch.cuda.empty_cache()
+    print(f"128x128 UNet forward: rel L2 {rel_err(got, want):.4f}; restatement device-vs-host {rel_err(on_dev, on_host):.2e}; "
+          f"oracle passes {time.time() - t0:.1f} s")
+    assert rel_err(on_dev, on_host) < 1e-4
     assert got.shape == want.shape == (2, 4, H, Wd) and bool(torch.isfinite(got.float()).all())
     assert rel_err(got, want) < 3e-2, rel_err(got, want)
     # one CFG + Euler step from the same forward (the restated loop's arithmetic on the oracle's eps), engine eager == graph
