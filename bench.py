@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--no-denoise", action="store_true", help="skip the UNet denoise leg")
     p.add_argument("--denoise-steps", type=int, default=50)
     p.add_argument("--only-denoise", action="store_true", help="profiling aid: run just the UNet leg (prints its object)")
+    p.add_argument("--unet-fusion", type=int, default=-1, help="A/B aid: emu_unet_set_fusion mask for the denoise leg (default: all)")
     p.add_argument("--no-beam", action="store_true", help="skip the extra 5-beam leg (the reference's default decoding mode)")
     p.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weight decode leg (never the headline value)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -141,7 +142,7 @@ def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
 UNET_FLOPS_PER_STEP = 13.48e12      # one denoise step (CFG batch 2) at 128x128 latents, 64 ctx tokens
 
 
-def denoise_leg(ctx, dev, steps, world, dist):
+def denoise_leg(ctx, dev, steps, world, dist, fusion=-1):
     """prompt_embeds randn(2,64,1792) seed 3, latents randn(1,4,128,128) seed 4, 50 Euler steps,
     CFG 3.0, 1024x1024; synthetic UNet weights (2.53 B params) generated on the GPU.  The timed region is exactly the
     `steps`-iteration loop (scale_model_input -> UNet -> CFG -> Euler step per iteration), hipGraph replayed.
@@ -151,6 +152,7 @@ def denoise_leg(ctx, dev, steps, world, dist):
     cfg = UNetCfg()
     eng = UNetEngine(cfg, ctx)
     eng.load_state_dict(synth.iter_synth(unet_param_shapes(cfg), seed=0, device=dev, dtype=torch.bfloat16))
+    fusion = eng.set_fusion(3 if fusion < 0 else fusion)
     g = torch.Generator().manual_seed(3)
     prompt = torch.randn(2, 64, 1792, generator=g).to(torch.bfloat16).to(dev)
     sch = eng.set_timesteps(steps)
@@ -181,6 +183,7 @@ def denoise_leg(ctx, dev, steps, world, dist):
     return {"metric": "diffusion denoise steps/sec (UNet fwd CFG batch 2 + guidance + Euler step, 1024x1024, 64 ctx tokens)",
             "value": per_gpu * world, "unit": "steps/s", "per_gpu": per_gpu, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "scaling": "replicas only (independent images per GPU)", "launch": "hipGraph replay", "finite_output": finite,
+            "fusion": {"mask": fusion, "layernorm_folded_into_gemm": bool(fusion & 1), "v_transpose_in_qkv_epilogue": bool(fusion & 2)},
             "roofline": {"bound": "mfma", "achieved": UNET_FLOPS_PER_STEP * per_gpu / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": UNET_FLOPS_PER_STEP * per_gpu / MFMA_BF16_PEAK,
                          "flops_per_step": UNET_FLOPS_PER_STEP}}
@@ -306,7 +309,7 @@ def main():
 
     ctx = EmuHipContext(dev, rank, world)
     if a.only_denoise:
-        d = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None)
+        d = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None, a.unet_fusion)
         if rank == 0:
             print(json.dumps(d), flush=True)
         return
@@ -531,7 +534,7 @@ def main():
     # ---- second half of the metric: SDXL-style UNet denoise (BASELINE.json configs[3]), replicas only across GPUs
     denoise = None
     if not a.no_denoise:
-        denoise = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None)
+        denoise = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None, a.unet_fusion)
 
     legs = None
     if not a.no_legs and world == 1:

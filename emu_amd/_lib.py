@@ -33,6 +33,12 @@ class VitCfgC(C.Structure):
                 ("head_width", i32), ("mlp_hidden", i32), ("kpad", i32), ("ln_eps", f32), ("prenorm", i32)]
 
 
+class LinearFxC(C.Structure):
+    """emu_linear_fx (include/emu_hip.h): fused epilogues of the UNet transformer GEMMs."""
+    _fields_ = [("row_stats_out", vp), ("ln_c", vp), ("ln_d", vp), ("ln_stats", vp), ("ln_slots", i32), ("ln_eps", f32),
+                ("vt_out", vp), ("vt_col0", i32), ("vt_s", i32), ("vt_spad", i32)]
+
+
 class UNetCfgC(C.Structure):
     _fields_ = [("in_ch", i32), ("out_ch", i32), ("ch", i32 * 3), ("layers_per_block", i32), ("depth", i32 * 3),
                 ("heads", i32 * 3), ("attn", i32 * 3), ("cross_dim", i32), ("groups", i32), ("gn_eps", f32),
@@ -55,6 +61,7 @@ _PROTOS = {
     "emu_tp_p2p_enable": (i32, [vp, i32]),
     "emu_tp_p2p_giveups": (C.c_uint, []),
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
+    "emu_linear_fused_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(LinearFxC), vp]),
     "emu_set_splitk_scratch": (None, [vp, sz]),
     "emu_gemm_force_config": (None, [i32]),
     "emu_quantize_fp8_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, vp]),
@@ -101,6 +108,7 @@ _PROTOS = {
     "emu_unet_destroy": (None, [vp]),
     "emu_unet_set_weight": (i32, [vp, C.c_char_p, vp]),
     "emu_unet_finalize": (i32, [vp]),
+    "emu_unet_set_fusion": (i32, [vp, i32]),
     "emu_unet_temb_total": (i32, [vp]),
     "emu_unet_workspace_bytes": (sz, [vp, i32, i32]),
     "emu_unet_context_bytes": (sz, [vp, i32]),

@@ -210,6 +210,17 @@ int emu_linear_fp8_bf16(const void* A8, const float* a_scale, const void* W8, co
     g.a_scale = a_scale; g.w_scale = w_scale;
     return launch_gemm_fp8(g, S(s));
 }
+int emu_linear_fused_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                          int lda, int ldw, int ldres, int ldc, int epi, const emu_linear_fx* fx, emu_stream_t s) {
+    if (!A || !W || !C || M <= 8) return -22;
+    GemmArgs g{B(A), B(W), B(bias), B(res), B(C), M, N, K, lda, ldw, ldres, ldc, epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+    if (fx) {
+        g.row_stats_out = fx->row_stats_out;
+        g.ln_c = fx->ln_c; g.ln_d = fx->ln_d; g.ln_stats = fx->ln_stats; g.ln_slots = fx->ln_slots; g.ln_eps = fx->ln_eps;
+        g.vt_out = B(fx->vt_out); g.vt_col0 = fx->vt_col0; g.vt_s = fx->vt_s; g.vt_spad = fx->vt_spad;
+    }
+    return launch_gemm(g, S(s));
+}
 int emu_quantize_fp8_rows(const void* w, int ldw, void* q, int ldq, float* scale, int N, int K, emu_stream_t s) {
     if (!w || !q || !scale) return -22;
     return launch_quant_fp8_rows(B(w), ldw, reinterpret_cast<uint8_t*>(q), ldq, scale, N, K, S(s));

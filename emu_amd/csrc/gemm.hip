@@ -48,7 +48,7 @@ struct TileCfg {
     __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 };
 
-template <int EPI, bool CONV, class T>
+template <int EPI, bool CONV, class T, bool FX = false>
 __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
@@ -205,10 +205,13 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::MF + j) * 16 + r) * 64 + lane];
     }
 
+    static_assert(T::NF == 2, "a wave's columns of one row are one 64-column row-statistics slot");
 #pragma unroll
     for (int j = 0; j < T::MF; ++j) {
         const int m = m0 + (wm * T::MF + j) * 32 + l31;
         if (m >= a.M) continue;
+        RowFx fx;
+        if (FX && a.ln_c && nsl == 1) ln_row_stats(a, m, fx);
 #pragma unroll
         for (int i = 0; i < T::NF; ++i)
 #pragma unroll
@@ -223,9 +226,15 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
                                  (size_t)(m - m0) * T::BNv + (nb - n0);
                     *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
                 } else {
-                    store_quad<EPI>(a, m, nb, v);
+                    store_quad<EPI, FX>(a, m, nb, v, fx);
                 }
             }
+        // fused LayerNorm, producer side: lanes l and l + 32 hold the two halves of this wave's 64 columns of row m
+        const int nslot = n0 + wn * 64;
+        if (FX && a.row_stats_out && nsl == 1 && nslot < a.N) {
+            const float s = fx.rs + __shfl_xor(fx.rs, 32, 64), q = fx.rq + __shfl_xor(fx.rq, 32, 64);
+            if (hi == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+        }
     }
 }
 
@@ -248,6 +257,15 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
+    constexpr bool CAN_FX = !CONV && gemm_fx_epi(EPI);
+    if (CAN_FX && gemm_fx(b)) {
+        if constexpr (CAN_FX) {
+            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+            if (tail > 0)
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv, true>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+        }
+        return;
+    }
     hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
     if (tail > 0)
         hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
@@ -322,7 +340,7 @@ inline PpPlan pick_pp(const GemmArgs& a) {
 // (profiles/r02_gemm_ab_v12_hybrid.log) UNet GEGLU 608 (256x128) / 701 (256x256, two rounds) -> 747 TFLOP/s, denoise step
 // 29.1 -> 28.3 ms (same-run A/B); with long K the sliced tail stays ahead (S=1544 gate/up 1124 vs 1066) and at f = 1/2 the plain rounds do.
 inline int plan_hybrid(const GemmArgs& a, bool forced) {
-    if (!gemm256_ok(a) || a.M < 192 || a.K / BK < 8 || a.conv.mode != CONV_NONE) return 0;
+    if (!gemm256_ok(a) || a.M < 192 || a.K / BK < 8 || a.conv.mode != CONV_NONE || a.vt_out) return 0;
     const int CU = 256, tn = (a.N + 255) / 256, tp = gemm256_tiles(a), tm = tp / tn;
     const int r = tp / CU, rem = tp % CU;
     if (r < 1 || rem == 0 || rem > CU / 2) return 0;
@@ -351,6 +369,8 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
             if (a.bias) rest.bias = a.bias + head.N;
             if (a.res) rest.res = a.res + head.N;
             if (a.bias2) rest.bias2 = a.bias2 + head.N;
+            if (a.ln_c) { rest.ln_c = a.ln_c + head.N; rest.ln_d = a.ln_d + head.N; }
+            if (a.row_stats_out) rest.row_stats_out = a.row_stats_out + (size_t)(head.N >> 6) * a.M * 2;
             rest.C = a.C + (GLU ? head.N / 2 : head.N);
             int st = launch_gemm256(head, s, -1, 1);
             if (st != 0) return st;
@@ -422,6 +442,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7)) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
     if (a.bias2 && a.rows_per_batch < 1) return -22;
+    // fused LayerNorm / V^T epilogues: whole quads only, statistics slots of 64 columns
+    if (gemm_fx(a) && !gemm_fx_epi(a.epi)) return -22;
+    if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
+    if (a.row_stats_out && ((a.N & 63) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
+                            (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
+    if (a.vt_out && (a.epi != EPI_NONE || a.conv.mode != CONV_NONE || (a.vt_col0 & 63) || ((a.N - a.vt_col0) & 63) || a.vt_col0 < 0 ||
+                     a.vt_col0 >= a.N || a.vt_s < 1 || a.M % a.vt_s || a.vt_spad < a.vt_s || (a.ldc & 3))) return -22;
     if (a.conv.mode != CONV_NONE) {
         const ConvGeom& g = a.conv;
         if ((g.Cin & 63) || a.K != 9 * g.Cin || a.M % (g.Hout * g.Wout)) return -22;

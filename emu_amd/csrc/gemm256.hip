@@ -73,7 +73,7 @@ constexpr uint32_t OOB = 0x80000000u;    // beyond num_records of the descriptor
 // F8: both operands are OCP fp8 e4m3 bytes (a k tile is still 128 bytes per row = 128 elements), the MFMA is the gfx950
 // block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 rate), and the per-row scales of the
 // two operands (a.a_scale[m] * a.w_scale[n]) multiply the fp32 sums ahead of the epilogue.
-template <int EPI, bool CONV, bool F8>
+template <int EPI, bool CONV, bool F8, bool FX = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * QXB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const int tiles_m = pp_tiles_m(a.M, !CONV && !F8, ext_rows);
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
-    const bool ext = !CONV && !F8 && ext_rows > 0 && tm == tiles_m - 1;  // this workgroup also owns rows m0 + 256 .. M - 1
+    // this workgroup also owns rows m0 + 256 .. M - 1 (never with the fused epilogues: gemm256_ok refuses that combination)
+    const bool ext = !CONV && !F8 && !FX && ext_rows > 0 && tm == tiles_m - 1;
 
     // ---- LDS-DMA sources.  Instruction i (0, 1) of a unit fills LDS rows r = i*64 + srow, srow = wave*8 + lane/8, slot
     // lane%8 <- global chunk slot ^ ((r >> 1) & 7).  P unit s: row r holds weight row n0 + (r >> 6)*128 + s*64 + (r & 63);
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     if (wr == 0) bar();
 
     // ---- epilogue: accumulator (x, y, i): rows n = n0 + wr*128 + x*64 + i*32 + 8*g + 4*hi + e, column m = .. + l31
-    auto emit = [&](int m, int nb, float (&v)[4]) {
+    auto emit = [&](int m, int nb, float (&v)[4], RowFx& fx) {
         if constexpr (F8) {
             if (nsl == 1) {                            // K-sliced: pp_reduce_kernel scales the summed slices
                 const float sa = a.a_scale[m];
@@ -324,15 +325,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             float* dst = a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * SLICE + (size_t)(m - m0) * 256 + (nb - n0);
             *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
         } else {
-            store_quad<EPI>(a, m, nb, v);
+            store_quad<EPI, FX>(a, m, nb, v, fx);
         }
     };
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
         const int m = m0 + wc * 64 + y * 32 + l31;
         if (m >= a.M) continue;
+        RowFx fx;
+        if (FX && a.ln_c && nsl == 1) ln_row_stats(a, m, fx);
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < 2; ++x) {
+            fx.rs = fx.rq = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -342,8 +346,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[x][y][i][4 * g + e];
-                    emit(m, nb, v);
+                    emit(m, nb, v, fx);
                 }
+            // fused LayerNorm, producer side: sub-tile x of this wave = one 64-column slot of row m, halves in lanes l / l + 32
+            const int nslot = n0 + wr * 128 + x * 64;
+            if (FX && a.row_stats_out && nsl == 1 && nslot < a.N) {
+                const float s = fx.rs + __shfl_xor(fx.rs, 32, 64), q = fx.rq + __shfl_xor(fx.rq, 32, 64);
+                if (hi == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+            }
+            if constexpr (FX) __builtin_amdgcn_sched_barrier(0);   // keep the next sub-tile's loads from piling up (256-VGPR kernel)
+        }
     }
     if (ext) {
         const int m = m0 + 256 + l31;
@@ -355,14 +367,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = accx[4 * g + e];
-                emit(m, nb, v);
+                RowFx fx;                              // remainder rows never carry the fused-LayerNorm features (gemm256_ok)
+                emit(m, nb, v, fx);
             }
         }
     }
 }
 
 // second launch of a K-sliced run: sum the slices of every tile (288 x 256 fp32 each: the tile and its remainder rows)
-template <int EPI>
+template <int EPI, bool FX = false>
 __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
     int ext_rows;
     const int tiles_m = pp_tiles_m(a.M, a.conv.mode == CONV_NONE && !a.a_scale, ext_rows);
@@ -372,20 +385,25 @@ __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
     const int rows = (ext_rows > 0 && tm == tiles_m - 1) ? 288 : 256;
     const float* base = a.partial + (size_t)blockIdx.x * a.ksplit * SLICE;
     const int per = rows * 64 / SPLITK_RED_Y;
-    for (int q = blockIdx.y * per + threadIdx.x; q < (blockIdx.y + 1) * per; q += 256) {
+    for (int q = blockIdx.y * per + threadIdx.x; q < (blockIdx.y + 1) * per; q += 256) {      // per % 64 == 0: whole waves
         const int lm = q >> 6, lq = q & 63;
         const int m = m0 + lm, nb = n0 + lq * 4;
-        if (m >= a.M || nb >= a.N) continue;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < a.ksplit; ++ks) {
-            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * SLICE + (size_t)lm * 256 + lq * 4);
-            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        const bool ok = m < a.M && nb < a.N;
+        RowFx fx;
+        if (ok) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * SLICE + (size_t)lm * 256 + lq * 4);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            }
+            if (a.a_scale) {
+                const float sa = a.a_scale[m];
+                for (int e = 0; e < 4; ++e) v[e] *= sa * a.w_scale[nb + e < a.N ? nb + e : a.N - 1];
+            }
+            if (FX && a.ln_c) ln_row_stats(a, m, fx);
+            store_quad<EPI, FX>(a, m, nb, v, fx);
         }
-        if (a.a_scale) {
-            const float sa = a.a_scale[m];
-            for (int e = 0; e < 4; ++e) v[e] *= sa * a.w_scale[nb + e < a.N ? nb + e : a.N - 1];
-        }
-        store_quad<EPI>(a, m, nb, v);
+        if constexpr (FX) emit_row_stats16(a, m, nb, ok, fx);
     }
 }
 
@@ -396,6 +414,14 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
+    constexpr bool CAN_FX = !CONV && !F8 && gemm_fx_epi(EPI);
+    if (CAN_FX && gemm_fx(b)) {
+        if constexpr (CAN_FX) {
+            hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8, true>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
+            if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI, true>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+        }
+        return;
+    }
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
     if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }
@@ -414,6 +440,12 @@ bool gemm256_ok(const GemmArgs& a) {
         return (size_t)a.N * a.ldw < 0x7fffffffull && (size_t)a.M * a.lda < 0x7fffffffull;
     }
     if (a.K & 63) return false;
+    if (gemm_fx(a)) {                                  // the fused epilogues: bf16 plain GEMM, no remainder-row accumulator
+        if (a.a_scale || a.conv.mode != CONV_NONE) return false;
+        int ext_rows;
+        pp_tiles_m(a.M, a.conv.mode == CONV_NONE, ext_rows);
+        if (ext_rows) return false;
+    }
     if (a.conv.mode != CONV_NONE && (a.conv.Hout > 2047 || a.conv.Wout > 2047 || a.M / (a.conv.Hout * a.conv.Wout) > 1023))
         return false;                                  // packed pixel coordinates of the gather
     const size_t wb = (size_t)a.N * a.ldw * 2;

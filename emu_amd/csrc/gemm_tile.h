@@ -34,16 +34,44 @@ __device__ __forceinline__ bool conv_tap(const ConvGeom& g, int py, int px, int 
     return yi >= 0 && yi < g.Hin && xi >= 0 && xi < g.Win;
 }
 
+// Fused-LayerNorm state of one output row inside an epilogue (GemmArgs::ln_* / row_stats_out): the statistics of row m
+// of A for the consumer-side correction, and the running (sum, sum of squares) of the bf16 outputs this lane has written
+// into the current 64-column slot for the producer side.
+struct RowFx {
+    float mean = 0.f, rstd = 1.f;
+    float rs = 0.f, rq = 0.f;
+};
+
+// mean / rstd of row m of A from the producer's per-slot partial sums (fixed order: deterministic)
+__device__ __forceinline__ void ln_row_stats(const GemmArgs& a, int m, RowFx& fx) {
+    const f32x2_t* p = reinterpret_cast<const f32x2_t*>(a.ln_stats) + m;
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < a.ln_slots; ++t) {
+        const f32x2_t v = p[(size_t)t * a.M];
+        s += v[0]; q += v[1];
+    }
+    const float inv = 1.0f / (float)a.K;
+    fx.mean = s * inv;
+    const float var = fmaxf(q * inv - fx.mean * fx.mean, 0.f);
+    fx.rstd = rsqrtf(var + a.ln_eps);
+}
+
 // Epilogue for one accumulator quad: lane-local 4 consecutive output columns nb..nb+3 of row m.
-template <int EPI>
-__device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, float (&v)[4]) {
+// FX = false compiles every fused-LayerNorm / V^T feature out (the instantiations all other callers use are unchanged).
+template <int EPI, bool FX = false>
+__device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, float (&v)[4], RowFx& fx) {
     // 8-byte accesses need every row start 8-byte aligned: ldc (and ldres) % 4 == 0; other strides (a [M, 32274] logits
     // buffer) take the scalar path below
     // (GLU epilogues store one 4-byte pair per quad: an even ldc is enough, and launch_gemm requires it)
     constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
     const bool full = (nb + 3) < a.N && (GLU || ((a.ldc | (EPI == EPI_RESID ? a.ldres : 0)) & 3) == 0);
     if (full) {
-        if (a.bias) {
+        if (FX && a.ln_c) {                            // LayerNorm folded into this GEMM (launch_gemm: N % 4 == 0, no bias)
+            const f32x4_t c = *reinterpret_cast<const f32x4_t*>(a.ln_c + nb);
+            const f32x4_t d = *reinterpret_cast<const f32x4_t*>(a.ln_d + nb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(fx.rstd, v[e] - fx.mean * c[e], d[e]);
+        } else if (a.bias) {
             const u32x2 bv = *reinterpret_cast<const u32x2*>(a.bias + nb);
             v[0] += bflo(bv.x); v[1] += bfhi(bv.x); v[2] += bflo(bv.y); v[3] += bfhi(bv.y);
         }
@@ -82,7 +110,21 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, flo
             u32x2 ov;
             ov.x = packbf(v[0], v[1]);
             ov.y = packbf(v[2], v[3]);
-            *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + nb) = ov;
+            if (FX && a.row_stats_out) {               // statistics of what the next LayerNorm will read: the bf16 values
+                const float r0 = bflo(ov.x), r1 = bfhi(ov.x), r2 = bflo(ov.y), r3 = bfhi(ov.y);
+                fx.rs += (r0 + r1) + (r2 + r3);
+                fx.rq += fmaf(r0, r0, r1 * r1) + fmaf(r2, r2, r3 * r3);
+            }
+            if (FX && a.vt_out && nb >= a.vt_col0) {   // V heads: key-contiguous store for the P.V MFMA (wave-uniform branch)
+                const int b = m / a.vt_s, sidx = m - b * a.vt_s;
+                bf16_t* dst = a.vt_out + ((size_t)b * (a.N - a.vt_col0) + (nb - a.vt_col0)) * a.vt_spad + sidx;
+                dst[0] = (bf16_t)(ov.x & 0xffffu);
+                dst[a.vt_spad] = (bf16_t)(ov.x >> 16);
+                dst[2 * (size_t)a.vt_spad] = (bf16_t)(ov.y & 0xffffu);
+                dst[3 * (size_t)a.vt_spad] = (bf16_t)(ov.y >> 16);
+            } else {
+                *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + nb) = ov;
+            }
         }
         return;
     }
@@ -117,10 +159,19 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, flo
     }
 }
 
+// Reduce kernels: a wave walks 64 consecutive quads = 256 columns of ONE row (QN % 64 == 0 or 16-lane groups inside a row),
+// so the 16-lane DPP sum is the (sum, sum of squares) of one 64-column slot.  Every lane of the wave must call this.
+__device__ __forceinline__ void emit_row_stats16(const GemmArgs& a, int m, int nb, bool ok, RowFx& fx) {
+    if (!a.row_stats_out) return;                      // wave-uniform
+    const float s = row16_sum(ok ? fx.rs : 0.f), q = row16_sum(ok ? fx.rq : 0.f);
+    if (ok && (threadIdx.x & 15) == 0)
+        *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nb >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+}
+
 // second launch of a split-K GEMM: sum the K-slices of every sliced tile in slice order (deterministic) and apply the
 // fused epilogue.  SPLITK_RED_Y workgroups per tile (a handful of tiles must still fill the chip).
 constexpr int SPLITK_RED_Y = 16;
-template <int EPI, int BMv, int BNv>
+template <int EPI, int BMv, int BNv, bool FX = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     const int wg = a.full_tiles + blockIdx.x;
     const int tiles_m = (a.M + BMv - 1) / BMv;
@@ -128,17 +179,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     const float* base = a.partial + (size_t)blockIdx.x * a.ksplit * (BMv * BNv);
     constexpr int QN = BNv / 4;
     constexpr int PER = BMv * QN / SPLITK_RED_Y;                      // quads per workgroup (grid.y chunks of a tile)
+    static_assert(PER % 64 == 0 && QN % 16 == 0, "whole waves per iteration, 16-lane groups inside one 64-column slot");
     for (int q = blockIdx.y * PER + threadIdx.x; q < (blockIdx.y + 1) * PER; q += 256) {
         const int lm = q / QN, lq = q - lm * QN;
         const int m = m0 + lm, nb = n0 + lq * 4;
-        if (m >= a.M || nb >= a.N) continue;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < a.ksplit; ++ks) {
-            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * (BMv * BNv) + (size_t)lm * BNv + lq * 4);
-            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        const bool ok = m < a.M && nb < a.N;
+        RowFx fx;
+        if (ok) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * (BMv * BNv) + (size_t)lm * BNv + lq * 4);
+                v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+            }
+            if (FX && a.ln_c) ln_row_stats(a, m, fx);
+            store_quad<EPI, FX>(a, m, nb, v, fx);
         }
-        store_quad<EPI>(a, m, nb, v);
+        if constexpr (FX) emit_row_stats16(a, m, nb, ok, fx);
     }
 }
+
+// does this launch use the fused epilogue features?  (host side: picks the FX instantiation)
+inline bool gemm_fx(const GemmArgs& a) { return a.ln_c || a.row_stats_out || a.vt_out; }
+constexpr bool gemm_fx_epi(int epi) { return epi == EPI_NONE || epi == EPI_RESID || epi == EPI_GEGLU; }
 
 }  // namespace emu_gemm

@@ -54,6 +54,24 @@ struct GemmArgs {
     int full_tiles = 0;     // set by launch_gemm: tiles [0, full_tiles) run whole-K (workgroups [0, full_tiles)); every
                             // later tile t is cut into ksplit slices (workgroup full_tiles + (t - full_tiles) * ksplit + ks)
                             // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
+    // ---- fused LayerNorm (UNet transformer blocks: removes the LayerNorm launch between two GEMMs)
+    // Producer side: besides C, emit per-row partial (sum, sum of squares) of the bf16-rounded outputs, one pair per
+    // 64-column slot: row_stats_out[(slot * M + m) * 2 + {0, 1}], slot = n / 64 (N % 64 == 0; EPI_NONE / EPI_RESID).
+    float* row_stats_out = nullptr;
+    // Consumer side: A holds the UN-normalised rows x [M, K], W holds W * gamma (bf16), and the epilogue computes
+    //   out[m, n] = rstd_m * (acc[m, n] - mean_m * ln_c[n]) + ln_d[n]
+    // with mean_m / rstd_m from the ln_slots partial pairs of row m (LayerNorm over the K columns of A, eps ln_eps),
+    // ln_c[n] = sum_k float(W'[n, k]) and ln_d[n] = sum_k W[n, k] * beta[k] + bias[n] (fp32; `bias` must be null).
+    const float* ln_c = nullptr;
+    const float* ln_d = nullptr;
+    const float* ln_stats = nullptr;
+    int ln_slots = 0;
+    float ln_eps = 0.f;
+    // ---- V^T epilogue (self-attention qkv projection): output columns n >= vt_col0 are the V heads; instead of row-major C
+    // they are stored key-contiguous for the P.V MFMA: vt_out[((b * (N - vt_col0) + (n - vt_col0)) * vt_spad) + s],
+    // m = b * vt_s + s  (= [B, H, 64, S_pad] with H * 64 = N - vt_col0).  EPI_NONE only.
+    bf16_t* vt_out = nullptr;
+    int vt_col0 = 0, vt_s = 0, vt_spad = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // fp8 x fp8 -> bf16 on the block-scaled MFMA (256x256 ping-pong tile only): K % 128 == 0, a.a_scale / a.w_scale set

@@ -34,8 +34,14 @@ struct Resnet {
     int cin, cout, temb_off;
     const bf16_t *n1g, *n1b, *c1w, *c1b, *n2g, *n2b, *c2w, *c2b, *scw, *scb;
 };
+struct LnW {                        // a LayerNorm folded into its consumer GEMM: W * gamma, fp32 row sums, W @ beta + bias
+    const bf16_t* w = nullptr;
+    const float *c = nullptr, *d = nullptr;
+    bool ok() const { return w && c && d; }
+};
 struct TBlock {
     const bf16_t *ln1g, *ln1b, *qkv, *o1w, *o1b, *ln2g, *ln2b, *q2, *kv2, *o2w, *o2b, *ln3g, *ln3b, *ggw, *ggb, *ffw, *ffb;
+    LnW qkv_ln, q2_ln, gg_ln;       // optional packed tensors of the fused-LayerNorm path
     size_t ctx_off;                 // element offset of this block's {K|V rows, Vt} in the context cache
 };
 struct Transformer {
@@ -54,6 +60,8 @@ struct emu_unet {
     size_t splitk_floats = 0;
     std::map<std::string, const bf16_t*> w;
     bool finalized = false;
+    int fusion = 0;                     // bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv epilogue
+    int fusion_avail = 0;               // what the registered tensors allow (set by emu_unet_finalize)
     // resolved structure
     const bf16_t *conv_in_w, *conv_in_b, *te1w, *te1b, *te2w, *te2b, *ae1w, *ae1b, *ae2w, *ae2b, *tpw, *tpb;
     const bf16_t *cno_g, *cno_b, *cout_w, *cout_b;
@@ -115,6 +123,15 @@ void resolve_transformer(emu_unet* u, Transformer& t, bool* ok) {
         tb.o2w = find(u, b + "attn2.out.w", true, ok); tb.o2b = find(u, b + "attn2.out.b", true, ok);
         tb.ggw = find(u, b + "ff.geglu.w", true, ok); tb.ggb = find(u, b + "ff.geglu.b", true, ok);
         tb.ffw = find(u, b + "ff.out.w", true, ok); tb.ffb = find(u, b + "ff.out.b", true, ok);
+        auto lnw = [&](const std::string& base) {
+            LnW l;
+            l.w = find(u, base + ".wln", false, ok);
+            l.c = reinterpret_cast<const float*>(find(u, base + ".c", false, ok));
+            l.d = reinterpret_cast<const float*>(find(u, base + ".d", false, ok));
+            return l;
+        };
+        tb.qkv_ln = lnw(b + "attn1.qkv"); tb.q2_ln = lnw(b + "attn2.q"); tb.gg_ln = lnw(b + "ff.geglu");
+        if (!(tb.qkv_ln.ok() && tb.q2_ln.ok() && tb.gg_ln.ok())) u->fusion_avail &= ~1;
     }
 }
 
@@ -123,6 +140,7 @@ struct Ws {
     bf16_t *colin, *hA, *hB, *cat, *gn, *t1, *sc, *tokA, *tokB, *ln, *qkv, *vt, *att, *q2, *ff;
     bf16_t* skip[12];
     bf16_t *temb_in, *e1, *emb, *semb, *temb_all, *add1;
+    float* lnstats;         // per-row partial (sum, sum of squares) of the transformer stream, one pair per 64-column slot
     float* gnws;
     float* splitk;          // fp32 K-slices of the split-K GEMMs / convs of the lowest-resolution level
     size_t splitk_floats;
@@ -136,7 +154,7 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
     size_t off = 0;
     auto take = [&](size_t elems, size_t esz = 2) { char* r = p ? p + off : nullptr; off += align_up(elems * esz); return r; };
     const size_t hw[3] = {(size_t)H * W, (size_t)((H + 1) / 2) * ((W + 1) / 2), (size_t)((H + 3) / 4) * ((W + 3) / 4)};
-    size_t max_h = 0, max_cat = 0, max_tok = 0, max_qkv = 0, max_ff = 0, max_vt = 0;
+    size_t max_h = 0, max_cat = 0, max_tok = 0, max_qkv = 0, max_ff = 0, max_vt = 0, max_st = 0;
     for (int i = 0; i < 3; ++i) {
         max_h = std::max(max_h, Bn * hw[i] * c.ch[i]);
         // widest concat at level i: up block (2-i) first resnet input = ch[i] (or ch[i+1]) + skip
@@ -147,6 +165,7 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
             max_qkv = std::max(max_qkv, Bn * hw[i] * 3 * c.ch[i]);
             max_ff = std::max(max_ff, Bn * hw[i] * 4 * c.ch[i]);
             max_vt = std::max(max_vt, (size_t)Bn * c.ch[i] * ((hw[i] + 63) / 64 * 64));
+            max_st = std::max(max_st, (size_t)Bn * hw[i] * (c.ch[i] / 64) * 2);
         }
     }
     // a downsampled/upsampled tensor is written at the next level's size with the previous level's channels
@@ -170,6 +189,7 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
     w.temb_in = (bf16_t*)take(Bn * c.ch[0]); w.e1 = (bf16_t*)take(Bn * c.temb_dim); w.emb = (bf16_t*)take(Bn * c.temb_dim);
     w.semb = (bf16_t*)take(Bn * c.temb_dim); w.temb_all = (bf16_t*)take((size_t)Bn * u->temb_total);
     w.add1 = (bf16_t*)take(Bn * c.temb_dim);
+    w.lnstats = (float*)take(max_st, 4);
     w.gnws = (float*)take(gn_ws_floats(Bn, 2 * c.ch[2] > c.ch[1] + c.ch[0] ? 2 * c.ch[2] : c.ch[1] + c.ch[0], (int)hw[0]), 4);
     w.splitk_floats = EMU_SPLITK_SCRATCH_FLOATS;
     w.splitk = (float*)take(w.splitk_floats, 4);
@@ -177,14 +197,32 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
     return w;
 }
 
+// optional fused epilogues of one GEMM of a transformer block (GemmArgs: row_stats_out / ln_* / vt_*)
+struct Fx {
+    float* stats_out = nullptr;         // producer: per-row partial sums of the output for the next LayerNorm
+    const LnW* ln = nullptr;            // consumer: LayerNorm of A folded in (W = ln->w), statistics from `stats_in`
+    const float* stats_in = nullptr;
+    bf16_t* vt = nullptr;               // qkv projection: V heads (columns >= vt_col0) stored key-contiguous
+    int vt_col0 = 0, vt_s = 0, vt_spad = 0;
+};
+
 int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, const bf16_t* res, bf16_t* C, int M, int N, int K,
-         int lda, int ldres, int ldc, int epi, hipStream_t s) {
+         int lda, int ldres, int ldc, int epi, hipStream_t s, const Fx* fx = nullptr) {
     if (M <= 8) {
+        if (fx) return -22;
         GemvArgs g{A, Wt, nullptr, bias, res, C, M, N, K, lda, K, ldres, ldc, 0.f, epi, 0, nullptr};
         return launch_gemv(g, s);
     }
     GemmArgs g{A, Wt, bias, res, C, M, N, K, lda, K, ldres, ldc, epi, NOCONV, nullptr, 0, 0};
     if (u) { g.partial = u->splitk; g.partial_floats = u->splitk_floats; }    // primitives (u == null): process scratch
+    if (fx) {
+        g.row_stats_out = fx->stats_out;
+        if (fx->ln) {
+            g.W = fx->ln->w; g.bias = nullptr;
+            g.ln_c = fx->ln->c; g.ln_d = fx->ln->d; g.ln_stats = fx->stats_in; g.ln_slots = K / 64; g.ln_eps = 1e-5f;
+        }
+        g.vt_out = fx->vt; g.vt_col0 = fx->vt_col0; g.vt_s = fx->vt_s; g.vt_spad = fx->vt_spad;
+    }
     return launch_gemm(g, s);
 }
 
@@ -218,32 +256,55 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     const int HW = H * W, M = Bn * HW, C = t.c, D = 64;
     const int hwpad = (HW + 63) / 64 * 64, npad = (u->n_ctx + 63) / 64 * 64, n = u->n_ctx;
     const float scale = 0.125f;
+    // Fused path (emu_unet_set_fusion): the three LayerNorms of a block live inside their consumer GEMMs -- the producer of the
+    // stream (proj_in, attn1 / attn2 out-projection, ff-out) emits per-row partial sums from its epilogue, the consumer (qkv,
+    // attn2 q, GEGLU) multiplies the un-normalised rows by W * gamma and corrects with mean / rstd in its epilogue -- and the qkv
+    // projection writes V^T itself.  M <= 8 (toy latents) stays on the unfused GEMV path.
+    const bool fln = (u->fusion & 1) && M > 8 && (C & 63) == 0;
+    const bool fvt = (u->fusion & 2) && M > 8 && HW == hwpad;
+    float* st = w.lnstats;
     UTRY(launch_groupnorm(x, t.gng, t.gnb, w.gn, w.gnws, Bn, HW, C, u->cfg.groups, 1e-6f, 0, s));
-    UTRY(gemm(u, w.gn, t.piw, t.pib, nullptr, w.tokA, M, C, C, C, 0, C, EPI_NONE, s));
+    { Fx fx; fx.stats_out = fln ? st : nullptr;
+      UTRY(gemm(u, w.gn, t.piw, t.pib, nullptr, w.tokA, M, C, C, C, 0, C, EPI_NONE, s, fln ? &fx : nullptr)); }
     bf16_t *a = w.tokA, *b = w.tokB;
-    for (const TBlock& tb : t.blocks) {
+    for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
+        const TBlock& tb = t.blocks[bi];
         // self attention
-        UTRY(launch_layernorm(a, tb.ln1g, tb.ln1b, nullptr, w.ln, M, C, 1e-5f, s));
-        UTRY(gemm(u, w.ln, tb.qkv, nullptr, nullptr, w.qkv, M, 3 * C, C, C, 0, 3 * C, EPI_NONE, s));
-        { TransposeVArgs tv{w.qkv + 2 * C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt, Bn, t.heads, HW, D, hwpad};
-          UTRY(launch_transpose_v(tv, s)); }
+        const bf16_t* lnx = a;
+        if (!fln) { UTRY(launch_layernorm(a, tb.ln1g, tb.ln1b, nullptr, w.ln, M, C, 1e-5f, s)); lnx = w.ln; }
+        { Fx fx;
+          if (fln) { fx.ln = &tb.qkv_ln; fx.stats_in = st; }
+          if (fvt) { fx.vt = w.vt; fx.vt_col0 = 2 * C; fx.vt_s = HW; fx.vt_spad = hwpad; }
+          UTRY(gemm(u, lnx, tb.qkv, nullptr, nullptr, w.qkv, M, 3 * C, C, C, 0, 3 * C, EPI_NONE, s, (fln || fvt) ? &fx : nullptr)); }
+        if (!fvt) {
+            TransposeVArgs tv{w.qkv + 2 * C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt, Bn, t.heads, HW, D, hwpad};
+            UTRY(launch_transpose_v(tv, s));
+        }
         { FlashArgs f{w.qkv, (long)HW * 3 * C, (long)D, (long)3 * C, w.qkv + C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt,
                       w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, HW, hwpad, D, 0, scale};
           UTRY(launch_flash_attn(f, s)); }
-        UTRY(gemm(u, w.att, tb.o1w, tb.o1b, a, b, M, C, C, C, C, C, EPI_RESID, s));
+        { Fx fx; fx.stats_out = st;
+          UTRY(gemm(u, w.att, tb.o1w, tb.o1b, a, b, M, C, C, C, C, C, EPI_RESID, s, fln ? &fx : nullptr)); }
         // cross attention on the cached context K / Vt
-        UTRY(launch_layernorm(b, tb.ln2g, tb.ln2b, nullptr, w.ln, M, C, 1e-5f, s));
-        UTRY(gemm(u, w.ln, tb.q2, nullptr, nullptr, w.q2, M, C, C, C, 0, C, EPI_NONE, s));
+        lnx = b;
+        if (!fln) { UTRY(launch_layernorm(b, tb.ln2g, tb.ln2b, nullptr, w.ln, M, C, 1e-5f, s)); lnx = w.ln; }
+        { Fx fx; fx.ln = &tb.q2_ln; fx.stats_in = st;
+          UTRY(gemm(u, lnx, tb.q2, nullptr, nullptr, w.q2, M, C, C, C, 0, C, EPI_NONE, s, fln ? &fx : nullptr)); }
         { const bf16_t* kv = u->ctx_cache + tb.ctx_off;
           const bf16_t* vt = kv + (size_t)Bn * n * 2 * C;
           FlashArgs f{w.q2, (long)HW * C, (long)D, (long)C, kv, (long)n * 2 * C, (long)D, (long)2 * C, vt,
                       w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, n, npad, D, 0, scale};
           UTRY(launch_flash_attn(f, s)); }
-        UTRY(gemm(u, w.att, tb.o2w, tb.o2b, b, a, M, C, C, C, C, C, EPI_RESID, s));
+        { Fx fx; fx.stats_out = st;
+          UTRY(gemm(u, w.att, tb.o2w, tb.o2b, b, a, M, C, C, C, C, C, EPI_RESID, s, fln ? &fx : nullptr)); }
         // GEGLU feed-forward
-        UTRY(launch_layernorm(a, tb.ln3g, tb.ln3b, nullptr, w.ln, M, C, 1e-5f, s));
-        UTRY(gemm(u, w.ln, tb.ggw, tb.ggb, nullptr, w.ff, M, 8 * C, C, C, 0, 4 * C, EPI_GEGLU, s));
-        UTRY(gemm(u, w.ff, tb.ffw, tb.ffb, a, b, M, C, 4 * C, 4 * C, C, C, EPI_RESID, s));
+        lnx = a;
+        if (!fln) { UTRY(launch_layernorm(a, tb.ln3g, tb.ln3b, nullptr, w.ln, M, C, 1e-5f, s)); lnx = w.ln; }
+        { Fx fx; fx.ln = &tb.gg_ln; fx.stats_in = st;
+          UTRY(gemm(u, lnx, tb.ggw, tb.ggb, nullptr, w.ff, M, 8 * C, C, C, 0, 4 * C, EPI_GEGLU, s, fln ? &fx : nullptr)); }
+        { Fx fx; fx.stats_out = st;                          // feeds the next block's first LayerNorm (none after the last)
+          const bool more = fln && bi + 1 < t.blocks.size();
+          UTRY(gemm(u, w.ff, tb.ffw, tb.ffb, a, b, M, C, 4 * C, 4 * C, C, C, EPI_RESID, s, more ? &fx : nullptr)); }
         std::swap(a, b);
     }
     UTRY(gemm(u, a, t.pow_, t.pob, x, out, M, C, C, C, C, C, EPI_RESID, s));
@@ -292,6 +353,7 @@ int emu_unet_finalize(emu_unet* u) {
     if (!u) return -22;
     const emu_unet_cfg& c = u->cfg;
     bool ok = true;
+    u->fusion_avail = 3;                               // resolve_transformer clears bit 0 when a packed tensor is missing
     int toff = 0;
     auto mk_res = [&](const std::string& name, int cin, int cout) {
         Resnet r{}; r.name = name; r.cin = cin; r.cout = cout; r.temb_off = toff; toff += cout;
@@ -350,8 +412,15 @@ int emu_unet_finalize(emu_unet* u) {
     (void)coff;
     u->temb_total = toff;
     if (!ok) return emu_ctx_fail(u->ctx, -2, u->err.c_str());
+    u->fusion = u->fusion_avail;
     u->finalized = true;
     return 0;
+}
+
+int emu_unet_set_fusion(emu_unet* u, int mask) {
+    if (!u || !u->finalized) return -22;
+    u->fusion = mask & u->fusion_avail;
+    return u->fusion;
 }
 
 int emu_unet_temb_total(const emu_unet* u) { return u ? u->temb_total : 0; }

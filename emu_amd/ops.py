@@ -60,6 +60,37 @@ def linear(x, w, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = 
     return out
 
 
+def linear_fused(x, w, bias=None, res=None, epi: int = EPI_NONE, out=None, stats_out=None, ln=None, vt=None):
+    """emu_linear_fused_bf16: ``linear`` (M > 8) with the fused epilogues of the UNet transformer blocks.
+    ``stats_out`` fp32 [N/64, M, 2]: per-row partial (sum, sum of squares) of the output per 64-column slot.
+    ``ln`` = (c fp32 [N], d fp32 [N], stats fp32 [K/64, M, 2], eps): x is the un-normalised activation, w = W * gamma.
+    ``vt`` = (vt_out bf16 [B, N - col0, S_pad], col0, S): columns >= col0 are stored key-contiguous instead of row-major."""
+    import ctypes as C
+    from ._lib import LinearFxC
+    _req(x, "x"); _req(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epi in (EPI_SWIGLU, EPI_GEGLU) else N
+    if out is None:
+        out = torch.empty(M, n_out, device=x.device, dtype=BF16)
+    fx = LinearFxC()
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() == (N // 64) * M * 2
+        fx.row_stats_out = stats_out.data_ptr()
+    if ln is not None:
+        c, d, stats, eps = ln
+        assert c.dtype == d.dtype == stats.dtype == torch.float32 and c.numel() == d.numel() == N and stats.is_contiguous()
+        fx.ln_c, fx.ln_d, fx.ln_stats, fx.ln_slots, fx.ln_eps = c.data_ptr(), d.data_ptr(), stats.data_ptr(), stats.shape[0], float(eps)
+    if vt is not None:
+        vt_out, col0, S = vt
+        _req(vt_out, "vt_out")
+        fx.vt_out, fx.vt_col0, fx.vt_s, fx.vt_spad = vt_out.data_ptr(), int(col0), int(S), vt_out.shape[-1]
+    check(lib().emu_linear_fused_bf16(_p(x), _p(w), _p(bias), _p(res), _p(out), M, N, K, x.stride(0), w.stride(0),
+                                      res.stride(0) if res is not None else 0, out.stride(0), int(epi), C.byref(fx), stream(x)),
+          "emu_linear_fused_bf16")
+    return out
+
+
 def quantize_fp8_rows(w):
     """Per-row symmetric OCP e4m3fn quantisation of a packed bf16 weight [N, K]: returns (bytes uint8 [N, K], scale fp32
     [N]) with w ~= fp8(bytes) * scale[:, None]; see emu_quantize_fp8_rows."""

@@ -9,6 +9,10 @@ Weights keep diffusers' state-dict names (what the reference checkpoint stores u
     computed once per generation, not per step)
   * GEGLU proj [8C, C] -> rows interleaved (hidden_j, gate_j) so ``hidden * gelu(gate)`` is a lane-local GEMM epilogue
   * every resnet's time_emb_proj concatenated into one [sum(Cout), 1280] matrix (one GEMV per step)
+  * the three LayerNorms of every BasicTransformerBlock folded into their consumer projections (norm1 -> attn1 qkv, norm2 ->
+    attn2 to_q, norm3 -> GEGLU proj): ``<name>.wln`` = W * gamma (bf16), ``<name>.c`` = fp32 row sums of that rounded matrix,
+    ``<name>.d`` = W @ beta + bias (fp32).  With them LayerNorm(x) @ W^T + b = rstd * (x @ Wln^T - mean * c) + d, which the
+    GEMM epilogue evaluates from per-row sums its producer emitted -- no LayerNorm launch (csrc/unet_engine.hip)
 
 PARITY UNPINNED: diffusers is not available to run (see oracle/unet_ref.py); tests compare against that restatement.
 """
@@ -187,6 +191,20 @@ class UNetEngine:
         self._keep[name] = t
         check(lib().emu_unet_set_weight(self.handle, name.encode(), t.data_ptr()), "emu_unet_set_weight")
 
+    def _reg_f32(self, name: str, t: torch.Tensor):
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep[name] = t
+        check(lib().emu_unet_set_weight(self.handle, name.encode(), t.data_ptr()), "emu_unet_set_weight")
+
+    def set_fusion(self, mask: int) -> int:
+        """Launch fusions of the transformer blocks (bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv
+        epilogue); 0 = the unfused launch sequence.  Invalidates a captured hipGraph.  Returns the mask in effect."""
+        self._graph = None
+        r = lib().emu_unet_set_fusion(self.handle, int(mask))
+        if r < 0:
+            check(r, "emu_unet_set_fusion", self.ctx.handle)
+        return r
+
     @staticmethod
     def _conv(w: torch.Tensor) -> torch.Tensor:
         return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)             # [Cout, (ky, kx, ci)]
@@ -205,19 +223,37 @@ class UNetEngine:
         temb_b: Dict[str, torch.Tensor] = {}
         dev = lambda t: t.to(self.device, BF16)
 
+        def reg_ln(name: str, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor]):
+            """LayerNorm(gamma, beta) folded into the projection w [N, K] (+ bias): packed tensors of the fused path."""
+            wln = (w.float() * gamma.float()[None, :]).to(BF16)
+            d = (w.float() * beta.float()[None, :]).sum(dim=1)
+            if bias is not None:
+                d = d + bias.float()
+            self._reg(name + ".wln", wln)
+            self._reg_f32(name + ".c", wln.float().sum(dim=1))
+            self._reg_f32(name + ".d", d)
+
         def flush_block(b: str, c: int):
             g = lambda k: dev(pend.pop(b + k))
-            self._reg(b + "attn1.qkv.w", torch.cat([g("attn1.to_q.weight"), g("attn1.to_k.weight"), g("attn1.to_v.weight")]))
+            nw = {n: (g(n + ".weight"), g(n + ".bias")) for n in ("norm1", "norm2", "norm3")}
+            for n, (gw, gb) in nw.items():
+                self._reg(b + n + ".g", gw); self._reg(b + n + ".b", gb)
+            qkv = torch.cat([g("attn1.to_q.weight"), g("attn1.to_k.weight"), g("attn1.to_v.weight")])
+            self._reg(b + "attn1.qkv.w", qkv)
+            reg_ln(b + "attn1.qkv", qkv, *nw["norm1"], None)
+            q2 = g("attn2.to_q.weight")
+            self._reg(b + "attn2.q.w", q2)
+            reg_ln(b + "attn2.q", q2, *nw["norm2"], None)
+            wg, bg = g("ff.net.0.proj.weight"), g("ff.net.0.proj.bias")
+            wgi = torch.stack([wg[:4 * c], wg[4 * c:]], dim=1).reshape(8 * c, c)
+            bgi = torch.stack([bg[:4 * c], bg[4 * c:]], dim=1).reshape(8 * c)
+            self._reg(b + "ff.geglu.w", wgi); self._reg(b + "ff.geglu.b", bgi)
+            reg_ln(b + "ff.geglu", wgi, *nw["norm3"], bgi)
             self._reg(b + "attn1.out.w", g("attn1.to_out.0.weight")); self._reg(b + "attn1.out.b", g("attn1.to_out.0.bias"))
-            self._reg(b + "attn2.q.w", g("attn2.to_q.weight"))
             self._reg(b + "attn2.kv.w", torch.cat([g("attn2.to_k.weight"), g("attn2.to_v.weight")]))
             self._reg(b + "attn2.out.w", g("attn2.to_out.0.weight")); self._reg(b + "attn2.out.b", g("attn2.to_out.0.bias"))
-            w, bb = g("ff.net.0.proj.weight"), g("ff.net.0.proj.bias")
-            self._reg(b + "ff.geglu.w", torch.stack([w[:4 * c], w[4 * c:]], dim=1).reshape(8 * c, c))
-            self._reg(b + "ff.geglu.b", torch.stack([bb[:4 * c], bb[4 * c:]], dim=1).reshape(8 * c))
             self._reg(b + "ff.out.w", g("ff.net.2.weight")); self._reg(b + "ff.out.b", g("ff.net.2.bias"))
-            for n in ("norm1", "norm2", "norm3"):
-                self._reg(b + n + ".g", g(n + ".weight")); self._reg(b + n + ".b", g(n + ".bias"))
+            return
 
         block_keys = {}
         for p, c, depth in transformers:

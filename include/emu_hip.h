@@ -97,6 +97,30 @@ int emu_linear_fp8_bf16(const void* A8, const float* a_scale, const void* W8, co
 int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, const void* bias, const void* res,
                          const void* norm_w, void* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc,
                          float eps, int epi, emu_stream_t s);
+/* emu_linear_bf16 (M > 8, epi in {NONE, RESID, GEGLU}) with the fused epilogues of the UNet transformer blocks -- what
+ * diffusers' BasicTransformerBlock computes as LayerNorm -> Linear (norm1/2/3 ahead of attn1.to_q/k/v, attn2.to_q,
+ * ff.net.0.proj; Emu2/emu/diffusion.py:136-141), without a LayerNorm launch in between:
+ *   row_stats_out  producer side: besides C, per-row partial (sum, sum of squares) of the bf16 outputs, one fp32 pair per
+ *                  64-column slot: row_stats_out[(slot * M + m) * 2 + {0,1}], slot = n / 64   (N % 64 == 0)
+ *   ln_c/ln_d/ln_stats/ln_slots/ln_eps  consumer side: A is the UN-normalised activation, W = W0 * gamma, and
+ *                  C[m,n] = epi(bf16(rstd_m * (sum_k A[m,k] W[n,k] - mean_m * ln_c[n]) + ln_d[n])) with mean / rstd of row m
+ *                  from its ln_slots partial pairs, ln_c[n] = sum_k W[n,k], ln_d[n] = sum_k W0[n,k] beta[k] + bias[n]
+ *   vt_out/vt_col0/vt_s/vt_spad  output columns n >= vt_col0 (the V heads of a fused qkv projection) are stored
+ *                  key-contiguous, vt_out[(b * (N - vt_col0) + n - vt_col0) * vt_spad + s] for row m = b * vt_s + s,
+ *                  instead of row-major (what the attention kernel's P.V MFMA reads; replaces a transpose launch)
+ * All pointers optional (NULL = feature off). */
+typedef struct {
+    float* row_stats_out;
+    const float* ln_c;
+    const float* ln_d;
+    const float* ln_stats;
+    int ln_slots;
+    float ln_eps;
+    void* vt_out;
+    int vt_col0, vt_s, vt_spad;
+} emu_linear_fx;
+int emu_linear_fused_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                          int lda, int ldw, int ldres, int ldc, int epi, const emu_linear_fx* fx, emu_stream_t s);
 
 /* LlamaRMSNorm (transformers; emu.py:133-138): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) */
 int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, int ldx, int ldy, float eps,
@@ -250,6 +274,11 @@ int emu_unet_create(emu_ctx* ctx, const emu_unet_cfg* cfg, emu_unet** out);
 void emu_unet_destroy(emu_unet* u);
 int emu_unet_set_weight(emu_unet* u, const char* name, const void* ptr);
 int emu_unet_finalize(emu_unet* u);                       /* -2 + emu_last_error: first missing tensor        */
+/* Launch fusions of the transformer blocks (default: every one whose packed tensors are registered).  Bit 0: LayerNorm folded
+ * into the consumer GEMM (needs "<block>attn1.qkv.wln/.c/.d", "attn2.q.wln/.c/.d", "ff.geglu.wln/.c/.d": W * gamma, its fp32
+ * row sums, W @ beta + bias); bit 1: V^T written by the qkv projection's epilogue (no transpose launch).  0 = the unfused
+ * launch sequence (A/B timing, parity of fused vs unfused).  Returns the mask in effect. */
+int emu_unet_set_fusion(emu_unet* u, int mask);
 int emu_unet_temb_total(const emu_unet* u);               /* rows of temb_proj_all (sum of resnet out channels) */
 size_t emu_unet_workspace_bytes(const emu_unet* u, int H, int W);
 size_t emu_unet_context_bytes(const emu_unet* u, int n_ctx);

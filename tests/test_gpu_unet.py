@@ -172,6 +172,36 @@ def test_denoise_loop_cfg_euler_and_graph(tiny_unet):
     assert abs(sch.init_noise_sigma - U.EulerSchedule().set_timesteps(steps).init_noise_sigma) < 1e-6
 
 
+def test_fused_transformer_launches_equal_the_unfused_sequence(tiny_unet):
+    """emu_unet_set_fusion: LayerNorm folded into the consumer GEMMs + V^T from the qkv epilogue (the default) against the
+    unfused launch sequence (mask 0) on the same weights and inputs -- both within the stated tolerance of the restatement,
+    and close to each other; every fusion bit on its own as well."""
+    from oracle import unet_ref as U
+    eng, Wr, ocfg = tiny_unet
+    H = Wd = 16
+    prompt = rnd(2, 8, 128, seed=61)
+    lat = rnd(1, 4, H, Wd, seed=62)
+    eng.set_timesteps(10)
+    eng.set_context(prompt.cuda(), 8 * H, 8 * Wd)
+    sch = U.EulerSchedule().set_timesteps(10)
+    time_ids = torch.tensor([1024, 1024, 0, 0, 8 * H, 8 * Wd] * 2)
+    x = (lat.float() * sch.init_noise_sigma).to(BF16)
+    inp = sch.scale_model_input(torch.cat([x.float()] * 2), 0).to(BF16).float()
+    want = U.unet_forward(inp, sch.timesteps[0], prompt.float(), prompt.float().mean(1).to(BF16).float(), time_ids, Wr, ocfg)
+    outs = {}
+    try:
+        assert eng.set_fusion(3) == 3, "the packed LayerNorm-fold tensors are registered by load_state_dict"
+        for mask in (3, 0, 1, 2):
+            assert eng.set_fusion(mask) == mask
+            outs[mask] = eng.forward(x, 0)
+            assert rel_err(outs[mask], want) < 3e-2, (mask, rel_err(outs[mask], want))
+    finally:
+        eng.set_fusion(3)
+    assert torch.equal(outs[2].cpu(), outs[0].cpu())                 # the V^T epilogue changes no arithmetic at all
+    assert rel_err(outs[3], outs[0]) < 1.5e-2, rel_err(outs[3], outs[0])
+    assert torch.equal(outs[3].cpu(), outs[1].cpu())
+
+
 @pytest.fixture(scope="module")
 def tiny_vae():
     from emu_amd import synth

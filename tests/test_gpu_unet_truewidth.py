@@ -72,6 +72,28 @@ def test_true_width_unet_forward(true_unet):
         assert rel_err(got, want) < 3e-2, (i, rel_err(got, want))
 
 
+def test_true_width_fused_vs_unfused_transformer_launches(true_unet):
+    """At the true 2.53 B configuration: the fused transformer launches (LayerNorm folded into qkv / to_q / GEGLU, V^T from the
+    qkv epilogue -- the default) against the unfused sequence on the same input: relative L2 < 1.5e-2 of each other (both are
+    held to 3e-2 of the restatement by the tests around this one); V^T alone is bit-identical."""
+    eng, Wr, ocfg = true_unet
+    H = Wd = 32
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.randn(2, 64, 1792, generator=g).to(BF16)
+    x = (torch.randn(1, 4, H, Wd, generator=g) * 13.0).to(BF16)
+    eng.set_timesteps(50)
+    eng.set_context(prompt.cuda(), 8 * H, 8 * Wd)
+    outs = {}
+    try:
+        for mask in (3, 0, 2):
+            assert eng.set_fusion(mask) == mask
+            outs[mask] = eng.forward(x, 0)
+    finally:
+        eng.set_fusion(3)
+    assert torch.equal(outs[2].cpu(), outs[0].cpu())
+    assert rel_err(outs[3], outs[0]) < 1.5e-2, rel_err(outs[3], outs[0])
+
+
 def test_true_width_denoise_steps_graph_equals_eager(true_unet):
     """Two full denoise steps (scale -> UNet -> CFG -> Euler) at true width: hipGraph replay is bit-identical to eager
     launches and follows the restated loop within 5e-2 (stated tolerance for image latents)."""
