@@ -48,7 +48,9 @@ struct TileCfg {
     __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 };
 
-template <int EPI, bool CONV, class T, bool FX = false>
+// ILV: the LDS-DMA of tile kt + NSTG - 1 is issued in KSTEPS shares BEHIND the MFMAs of each k-step instead of in one block
+// ahead of them, so the DMA issue slots (60-180 cycles each) overlap matrix-pipe time instead of preceding it.
+template <int EPI, bool CONV, class T, bool FX = false, bool ILV = false>
 __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
@@ -107,19 +109,21 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     const int nk_all = (a.K + BK - 1) / BK;
     const int kt0 = (int)((long)ks * nk_all / nsl);
     const int nk = (int)((long)(ks + 1) * nk_all / nsl) - kt0;
-    auto issue = [&](int kt, int stage) {
+    auto issue = [&](int kt, int stage, int part = 0, int nparts = 1) {
+        auto mine = [&](int idx) { return nparts == 1 || (idx % nparts) == part; };      // share `part` of the tile's pieces
         kt = kt < nk ? kt : nk - 1;                    // past-the-end tiles re-load the last one (keeps vmcnt counts uniform)
         const int k0 = (kt0 + kt) * BK;
         char* base = smem + stage * T::ST_BYTES + wave * 1024;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
         if constexpr (CONV) {
 #pragma unroll
-            for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
+            for (int i = 0; i < T::NLW; ++i) if (mine(i)) glds16(gW[i] + k0, base + i * NW * 1024);
             // a 64-wide k tile lies inside one filter tap because Cin % 64 == 0
             const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int i = 0; i < T::NLA; ++i) {
+                if (!mine(T::NLW + i)) continue;
                 int yi, xi;
                 const bool ok = conv_tap(a.conv, py[i], px[i], ky, kx, yi, xi);
                 const size_t off = (((size_t)pb[i] * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin + ci0 + ck;
@@ -127,15 +131,15 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
             }
         } else if (k0 + BK <= a.K) {
 #pragma unroll
-            for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
+            for (int i = 0; i < T::NLW; ++i) if (mine(i)) glds16(gW[i] + k0, base + i * NW * 1024);
 #pragma unroll
-            for (int i = 0; i < T::NLA; ++i) glds16(gA[i] + k0, base + T::W_BYTES + i * NW * 1024);
+            for (int i = 0; i < T::NLA; ++i) if (mine(T::NLW + i)) glds16(gA[i] + k0, base + T::W_BYTES + i * NW * 1024);
         } else {                                       // ragged last k tile (K % 64 != 0): chunks beyond K read zeros
             const bool in = (k0 + ck) < a.K;
 #pragma unroll
-            for (int i = 0; i < T::NLW; ++i) glds16(in ? gW[i] + k0 : zero, base + i * NW * 1024);
+            for (int i = 0; i < T::NLW; ++i) if (mine(i)) glds16(in ? gW[i] + k0 : zero, base + i * NW * 1024);
 #pragma unroll
-            for (int i = 0; i < T::NLA; ++i) glds16(in ? gA[i] + k0 : zero, base + T::W_BYTES + i * NW * 1024);
+            for (int i = 0; i < T::NLA; ++i) if (mine(T::NLW + i)) glds16(in ? gA[i] + k0 : zero, base + T::W_BYTES + i * NW * 1024);
         }
     };
 
@@ -149,10 +153,24 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
 
 #pragma unroll
     for (int t = 0; t < T::NSTG - 1; ++t) issue(t, t);
+    // fused LayerNorm, consumer side: the statistics of this lane's rows, fetched behind the first tiles' LDS-DMA (hipcc waits
+    // for everything outstanding at their first use, which the first k tile needs anyway) and kept for the epilogue
+    RowFx rowfx[T::MF];
+    if constexpr (FX) {
+        if (a.ln_c && nsl == 1) {
+            int mr[T::MF];
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j) {
+                const int m = m0 + (wm * T::MF + j) * 32 + l31;
+                mr[j] = m < a.M ? m : a.M - 1;
+            }
+            ln_rows_stats<T::MF>(a, mr, rowfx);
+        }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<(T::NSTG - 2) * T::LPT>();          // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                  // ... and everyone's; everyone is also done reading tile kt-1
-        issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
+        if constexpr (!ILV) issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
         const char* sW = smem + (kt % T::NSTG) * T::ST_BYTES;
         const char* sA = sW + T::W_BYTES;
         // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are in flight under the MFMAs of kk
@@ -179,6 +197,10 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
                 for (int j = 0; j < T::MF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], af[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ILV) {
+                issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG, kk, KSTEPS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
@@ -210,8 +232,7 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     for (int j = 0; j < T::MF; ++j) {
         const int m = m0 + (wm * T::MF + j) * 32 + l31;
         if (m >= a.M) continue;
-        RowFx fx;
-        if (FX && a.ln_c && nsl == 1) ln_row_stats(a, m, fx);
+        RowFx fx = rowfx[j];
 #pragma unroll
         for (int i = 0; i < T::NF; ++i)
 #pragma unroll
@@ -251,12 +272,21 @@ int g_force_cfg = 0;                     // emu_gemm_force_config: tests / bench
 
 // full_tiles whole-K workgroups followed by (tiles - full_tiles) * ksplit slice workgroups, one launch (+ the reduce)
 template <int EPI, bool CONV, class T>
-void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int ksplit = 1) {
+void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int ksplit = 1, bool ilv = false) {
     const int tiles = ((a.M + T::BMv - 1) / T::BMv) * ((a.N + T::BNv - 1) / T::BNv);
     GemmArgs b = a;
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
+    constexpr bool CAN_ILV = !CONV && gemm_fx_epi(EPI);                  // schedule experiment: plain GEMMs of the UNet epilogues
+    if (CAN_ILV && ilv && !gemm_fx(b)) {
+        if constexpr (CAN_ILV) {
+            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, false, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+            if (tail > 0)
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+        }
+        return;
+    }
     constexpr bool CAN_FX = !CONV && gemm_fx_epi(EPI);
     if (CAN_FX && gemm_fx(b)) {
         if constexpr (CAN_FX) {
@@ -402,6 +432,8 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
         else cfg = 'K';
     }
+    const bool ilv = cfg >= 'a' && cfg <= 'z';         // lower-case letter: the interleaved-DMA variant of the same tile
+    if (ilv) cfg -= 'a' - 'A';
     switch (cfg) {
         case 'Q': return launch_gemm256(a, s, -1, 1);  // 256x256 ping-pong, never K-sliced (A/B)
         case 'P': {                                   // 256x256 ping-pong with the planned K-slices, whatever the shape
@@ -411,13 +443,13 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         case 'S': {
             const int tc = tiles_of(a, 256, 128);
             const int ksplit = tc < 256 ? pick_ksplit<EPI>(a, tc, 256 * 128, g_force_cfg ? 8 : 16) : 0;
-            if (ksplit) launch_cfg<EPI, CONV, CfgC>(a, s, 0, ksplit);
-            else launch_cfg<EPI, CONV, CfgC>(a, s);
+            if (ksplit) launch_cfg<EPI, CONV, CfgC>(a, s, 0, ksplit, ilv);
+            else launch_cfg<EPI, CONV, CfgC>(a, s, -1, 1, ilv);
             break;
         }
-        case 'C': launch_cfg<EPI, CONV, CfgC>(a, s); break;
-        case 'K': launch_cfg<EPI, CONV, CfgK>(a, s); break;
-        default:  launch_cfg<EPI, CONV, CfgB>(a, s); break;
+        case 'C': launch_cfg<EPI, CONV, CfgC>(a, s, -1, 1, ilv); break;
+        case 'K': launch_cfg<EPI, CONV, CfgK>(a, s, -1, 1, ilv); break;
+        default:  launch_cfg<EPI, CONV, CfgB>(a, s, -1, 1, ilv); break;
     }
     EMU_CHECK_LAUNCH();
     return 0;

@@ -328,12 +328,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             store_quad<EPI, FX>(a, m, nb, v, fx);
         }
     };
+    RowFx rowfx[2];
+    if constexpr (FX) {                                // fused LayerNorm, consumer side: both rows of this lane in one batch of loads
+        if (a.ln_c && nsl == 1) {
+            int mr[2];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) { const int m = m0 + wc * 64 + y * 32 + l31; mr[y] = m < a.M ? m : a.M - 1; }
+            ln_rows_stats<2>(a, mr, rowfx);
+        }
+    }
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
         const int m = m0 + wc * 64 + y * 32 + l31;
         if (m >= a.M) continue;
-        RowFx fx;
-        if (FX && a.ln_c && nsl == 1) ln_row_stats(a, m, fx);
+        RowFx fx = rowfx[y];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             fx.rs = fx.rq = 0.f;

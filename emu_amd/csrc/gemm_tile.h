@@ -42,18 +42,46 @@ struct RowFx {
     float rs = 0.f, rq = 0.f;
 };
 
-// mean / rstd of row m of A from the producer's per-slot partial sums (fixed order: deterministic)
-__device__ __forceinline__ void ln_row_stats(const GemmArgs& a, int m, RowFx& fx) {
-    const f32x2_t* p = reinterpret_cast<const f32x2_t*>(a.ln_stats) + m;
-    float s = 0.f, q = 0.f;
-    for (int t = 0; t < a.ln_slots; ++t) {
-        const f32x2_t v = p[(size_t)t * a.M];
-        s += v[0]; q += v[1];
+// mean / rstd of NR rows of A from the producer's per-slot partial sums.  The loads of a batch (10 slots x NR rows) are
+// issued together and only then summed, in slot order (deterministic): one L2 round trip per batch instead of one per slot
+// (a plain `for slot: s += p[slot]` loop makes hipcc wait for every load before it issues the next: +10-20 us per GEMM).
+// Rows past M are clamped by the caller; every lane runs the same trip count.
+template <int NR>
+__device__ __forceinline__ void ln_rows_stats(const GemmArgs& a, const int (&m)[NR], RowFx (&fx)[NR]) {
+    constexpr int BATCH = 10;                          // K / 64 of the UNet widths: 5, 10, 20
+    const f32x2_t* p = reinterpret_cast<const f32x2_t*>(a.ln_stats);
+    const int ns = a.ln_slots;
+    float s[NR], q[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s[r] = q[r] = 0.f;
+    for (int t0 = 0; t0 < ns; t0 += BATCH) {
+        f32x2_t v[NR][BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int t = t0 + j < ns ? t0 + j : ns - 1;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[r][j] = p[(size_t)t * a.M + m[r]];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const bool in = t0 + j < ns;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { s[r] += in ? v[r][j][0] : 0.f; q[r] += in ? v[r][j][1] : 0.f; }
+        }
     }
     const float inv = 1.0f / (float)a.K;
-    fx.mean = s * inv;
-    const float var = fmaxf(q * inv - fx.mean * fx.mean, 0.f);
-    fx.rstd = rsqrtf(var + a.ln_eps);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        fx[r].mean = s[r] * inv;
+        const float var = fmaxf(q[r] * inv - fx[r].mean * fx[r].mean, 0.f);
+        fx[r].rstd = rsqrtf(var + a.ln_eps);
+    }
+}
+__device__ __forceinline__ void ln_row_stats(const GemmArgs& a, int m, RowFx& fx) {
+    const int mm[1] = {m};
+    RowFx f[1];
+    ln_rows_stats<1>(a, mm, f);
+    fx.mean = f[0].mean; fx.rstd = f[0].rstd;
 }
 
 // Epilogue for one accumulator quad: lane-local 4 consecutive output columns nb..nb+3 of row m.
