@@ -7,22 +7,25 @@
 
 namespace {
 
-constexpr int GN_DEPTH = 16;         // pixel rows each thread walks serially in the partial-sum pass
+constexpr int GN_DEPTH = 16;         // pixel rows each thread walks serially in the statistics pass
+constexpr int GN_MAXC = 2560;        // widest activation of the SDXL topology (first resnet of the up path: 1280 + 1280)
+constexpr int GN_MAXG = 64;
 
-// How the 256 threads of a partial-sum workgroup are laid out for C channels: nv 16-byte channel vectors per pixel row,
+// How the 256 threads of a statistics workgroup are laid out for C channels: nv 16-byte channel vectors per pixel row,
 // RG row groups side by side (all 256 threads busy for C = 320 as well as 1280), GN_DEPTH rows per thread.
 __host__ __device__ inline int gn_row_groups(int C) { const int nv = C >> 3; return nv >= 256 ? 1 : 256 / nv; }
 __host__ __device__ inline int gn_rows_per_block(int C) { return GN_DEPTH * gn_row_groups(C); }
 
-// partial sums per (b, chunk, channel): ws[((b*nchunk + chunk)*2 + {0,1})*C + c]; row groups meet in LDS in a fixed
-// order (deterministic sums)
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C) {
-    __shared__ float sm[256 * 16];
+// Pass 1 of 2: per (batch, pixel chunk) the fp32 (sum, sum of squares) of every GROUP: ws[((b * nchunk + chunk) * G + g) * 2].
+// Channel sums of the chunk meet in LDS and are folded to groups in a fixed order (deterministic).  One launch of the former
+// three (per-channel partials / finalize / apply) is gone: the apply pass derives mean / rstd itself from these few floats.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G) {
+    __shared__ float csum[2 * GN_MAXC];               // per-channel (sum | sum of squares) of this chunk
+    __shared__ float part[256 * 16];                  // row groups side by side (narrow rows)
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int nv = C >> 3;
     const int RG = gn_row_groups(C), rows = GN_DEPTH * RG;
     const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
-    float* out = ws + ((size_t)(b * nchunk + chunk) * 2) * C;
     const int tid = threadIdx.x;
     if (RG == 1) {                                   // wide rows: one thread per channel vector (loop when nv > 256)
         for (int vi = tid; vi < nv; vi += 256) {
@@ -35,87 +38,94 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { out[vi * 8 + e] = s[e]; out[C + vi * 8 + e] = q[e]; }
+            for (int e = 0; e < 8; ++e) { csum[vi * 8 + e] = s[e]; csum[C + vi * 8 + e] = q[e]; }
         }
-        return;
-    }
-    const int tr = tid / nv, vi = tid - tr * nv;
-    const bool on = tr < RG;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (on) {
+    } else {
+        const int tr = tid / nv, vi = tid - tr * nv;
+        if (tr < RG) {
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
-        for (int r = r0 + tr; r < r1; r += RG) {
-            float f[8];
-            unpack8(ld16(x + ((size_t)b * HW + r) * C + vi * 8), f);
+            for (int r = r0 + tr; r < r1; r += RG) {
+                float f[8];
+                unpack8(ld16(x + ((size_t)b * HW + r) * C + vi * 8), f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { part[tid * 16 + e] = s[e]; part[tid * 16 + 8 + e] = q[e]; }
         }
+        __syncthreads();
+        if (tid < nv) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sm[tid * 16 + e] = s[e]; sm[tid * 16 + 8 + e] = q[e]; }
+            for (int e = 0; e < 8; ++e) {
+                float ts = 0.f, tq = 0.f;
+                for (int g = 0; g < RG; ++g) { ts += part[(g * nv + tid) * 16 + e]; tq += part[(g * nv + tid) * 16 + 8 + e]; }
+                csum[tid * 8 + e] = ts;
+                csum[C + tid * 8 + e] = tq;
+            }
+        }
     }
     __syncthreads();
-    if (tid < nv) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float ts = 0.f, tq = 0.f;
-            for (int g = 0; g < RG; ++g) { ts += sm[(g * nv + tid) * 16 + e]; tq += sm[(g * nv + tid) * 16 + 8 + e]; }
-            out[tid * 8 + e] = ts;
-            out[C + tid * 8 + e] = tq;
-        }
+    if (tid < G) {
+        const int cg = C / G;
+        float ts = 0.f, tq = 0.f;
+        for (int i = 0; i < cg; ++i) { ts += csum[tid * cg + i]; tq += csum[C + tid * cg + i]; }
+        float* out = ws + ((size_t)(b * nchunk + chunk) * G + tid) * 2;
+        out[0] = ts; out[1] = tq;
     }
 }
 
-// one workgroup per (b, group): reduce chunks and channels in double, emit scale/shift per channel
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ gamma,
-                                                         const bf16_t* __restrict__ beta, float* __restrict__ ab, int nchunk, int HW,
-                                                         int C, int groups, float eps) {
-    __shared__ double red[2][4];
-    const int b = blockIdx.y, g = blockIdx.x, cg = C / groups, tid = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int i = tid; i < nchunk * cg; i += 256) {
-        const int chunk = i / cg, c = g * cg + i % cg;
-        const float* p = ws + ((size_t)(b * nchunk + chunk) * 2) * C;
-        s += (double)p[c];
-        q += (double)p[C + c];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
-    __syncthreads();
-    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    const double n = (double)HW * cg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float* A = ab + (size_t)b * 2 * C;
-    for (int i = tid; i < cg; i += 256) {
-        const int c = g * cg + i;
-        const float ga = bf2f(gamma[c]) * rstd;
-        A[c] = ga;
-        A[C + c] = bf2f(beta[c]) - (float)mean * ga;
-    }
-}
-
+// Pass 2 of 2: every workgroup first folds the chunk partials of its batch into (mean, rstd) per group (double accumulation,
+// fixed order; a few KB from L2), then applies y = x * (gamma * rstd) + (beta - mean * gamma * rstd) (+ SiLU) over its rows.
 template <bool SILU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
-                                                       bf16_t* __restrict__ y, int HW, int C, size_t total_vec) {
-    const int nv = C >> 3;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (size_t)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ws,
+                                                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, int HW, int C, int G, int nchunk, float eps) {
+    __shared__ double red[2][8][GN_MAXG];
+    __shared__ float stat[2][GN_MAXG];                 // mean | rstd per group
+    const int b = blockIdx.y, tid = threadIdx.x;
+    {   // 8 slices of the chunk list x G groups: thread (slice, g) sums its chunks, slices meet in LDS
+        const int g = tid % GN_MAXG, sl = tid / GN_MAXG;          // 256 threads = 4 slices of 64 group slots
+        double s = 0.0, q = 0.0;
+        if (g < G) {
+            const float* p = ws + ((size_t)b * nchunk * G + g) * 2;
+            for (int c = sl; c < nchunk; c += 4) { s += (double)p[(size_t)c * G * 2]; q += (double)p[(size_t)c * G * 2 + 1]; }
+        }
+        red[0][sl][g] = s; red[1][sl][g] = q;
+        __syncthreads();
+        if (tid < G) {
+            const double ts = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+            const double tq = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            const double n = (double)HW * (C / G);
+            const double mean = ts / n;
+            double var = tq / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            stat[0][tid] = (float)mean;
+            stat[1][tid] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+    }
+    const int nv = C >> 3, cg = C / G;
+    const size_t total = (size_t)HW * nv;
+    const bf16_t* xb = x + (size_t)b * HW * C;
+    bf16_t* yb = y + (size_t)b * HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / nv;
         const int vi = (int)(i - row * nv);
-        const int b = (int)(row / HW);
-        const float* A = ab + (size_t)b * 2 * C + vi * 8;
-        float f[8];
-        unpack8(ld16(x + row * C + vi * 8), f);
+        float f[8], ga[8], be[8];
+        unpack8(ld16(xb + row * C + vi * 8), f);
+        unpack8(ld16(gamma + vi * 8), ga);
+        unpack8(ld16(beta + vi * 8), be);
+        const int c0 = vi * 8, g0 = c0 / cg, left = (g0 + 1) * cg - c0;      // channels of this vector still inside group g0
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float v = f[e] * A[e] + A[C + e];
+            const int g = cg >= 8 ? g0 + (e >= left ? 1 : 0) : (c0 + e) / cg;    // groups of >= 8 channels: at most one boundary
+            const float A = ga[e] * stat[1][g];
+            float v = f[e] * A + (be[e] - stat[0][g] * A);
             if (SILU) v = silu(bfround(v));               // GroupNorm output is a bf16 tensor before F.silu
             f[e] = v;
         }
-        st16(y + row * C + vi * 8, pack8(f));
+        st16(yb + row * C + vi * 8, pack8(f));
     }
 }
 
@@ -190,22 +200,23 @@ __global__ __launch_bounds__(256) void gather_step_row_kernel(const bf16_t* __re
 
 size_t gn_ws_floats(int B, int C, int HW) {
     const int rows = gn_rows_per_block(C);
-    const int nchunk = (HW + rows - 1) / rows;         // monotone in C and HW: sizing for (max C, max HW) covers every use
-    return (size_t)B * nchunk * 2 * C + (size_t)B * 2 * C;
+    const int nchunk = (HW + rows - 1) / rows;         // monotone in HW, non-increasing rows in C: sized for the narrowest C in use
+    (void)nchunk;
+    // worst case over the channel widths a caller may pass with this HW: the narrowest rows give the most chunks
+    const int max_chunks = (HW + GN_DEPTH - 1) / GN_DEPTH;
+    return (size_t)B * max_chunks * GN_MAXG * 2;
 }
 
 int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, float* ws, int B, int HW, int C,
                      int groups, float eps, int do_silu, hipStream_t s) {
-    if (B < 1 || HW < 1 || (C & 7) || C % groups) return -22;
+    if (B < 1 || HW < 1 || (C & 7) || C % groups || groups > GN_MAXG || C > GN_MAXC) return -22;
     const int rows = gn_rows_per_block(C);
     const int nchunk = (HW + rows - 1) / rows;
-    float* ab = ws + (size_t)B * nchunk * 2 * C;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, s, ws, gamma, beta, ab, nchunk, HW, C, groups, eps);
-    const size_t total = (size_t)B * HW * (C >> 3);
-    const int grid = (int)min((size_t)8192, (total + 255) / 256);
-    if (do_silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid), dim3(256), 0, s, x, ab, y, HW, C, total);
-    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid), dim3(256), 0, s, x, ab, y, HW, C, total);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C, groups);
+    const size_t total = (size_t)HW * (C >> 3);
+    const int grid = (int)min((size_t)4096, (total + 255) / 256);
+    if (do_silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid, B), dim3(256), 0, s, x, ws, gamma, beta, y, HW, C, groups, nchunk, eps);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(grid, B), dim3(256), 0, s, x, ws, gamma, beta, y, HW, C, groups, nchunk, eps);
     EMU_CHECK_LAUNCH();
     return 0;
 }
