@@ -34,6 +34,9 @@ template <int WN_, int WM_, int NF_, int MF_, int NSTG_, int KG_ = 1>
 struct TileCfg {
     static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_, KG = KG_;
     static constexpr int THREADS = WN * WM * KG * 64;
+    // waves per SIMD the register allocation must leave room for: the 128 x 64 two-k-group tile lives on TWO workgroups per
+    // CU (72 KiB of LDS each), i.e. 4 waves per SIMD = at most 128 VGPRs; the others run 2 waves per SIMD
+    static constexpr int MINW = (KG == 2 && NSTG_ * (WN_ * NF_ + WM_ * MF_) * 32 * 128 <= 80 * 1024) ? 4 : 2;
     static_assert(KG == 1 || KG == 2, "k-groups: 1 or 2");
     static constexpr int BNv = WN * NF * 32, BMv = WM * MF * 32;
     static constexpr int ROWB = BK * 2;                                       // bytes per LDS row (128)
@@ -51,7 +54,7 @@ struct TileCfg {
 // ILV: the LDS-DMA of tile kt + NSTG - 1 is issued in KSTEPS shares BEHIND the MFMAs of each k-step instead of in one block
 // ahead of them, so the DMA issue slots (60-180 cycles each) overlap matrix-pipe time instead of preceding it.
 template <int EPI, bool CONV, class T, bool FX = false, bool ILV = false>
-__global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
     constexpr int SMEM_BYTES = T::NSTG * T::ST_BYTES > RED_BYTES ? T::NSTG * T::ST_BYTES : RED_BYTES;
@@ -151,22 +154,22 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#pragma unroll
-    for (int t = 0; t < T::NSTG - 1; ++t) issue(t, t);
-    // fused LayerNorm, consumer side: the statistics of this lane's rows, fetched behind the first tiles' LDS-DMA (hipcc waits
-    // for everything outstanding at their first use, which the first k tile needs anyway) and kept for the epilogue
-    RowFx rowfx[T::MF];
+    // fused LayerNorm, consumer side: the partial sums of this lane's rows are requested here and summed in the epilogue
+    LnRaw<T::MF> lnraw;
+    const bool ln_on = FX && a.ln_c && nsl == 1;
     if constexpr (FX) {
-        if (a.ln_c && nsl == 1) {
+        if (ln_on) {
             int mr[T::MF];
 #pragma unroll
             for (int j = 0; j < T::MF; ++j) {
                 const int m = m0 + (wm * T::MF + j) * 32 + l31;
                 mr[j] = m < a.M ? m : a.M - 1;
             }
-            ln_rows_stats<T::MF>(a, mr, rowfx);
+            ln_rows_load<T::MF>(a, mr, lnraw);
         }
     }
+#pragma unroll
+    for (int t = 0; t < T::NSTG - 1; ++t) issue(t, t);
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<(T::NSTG - 2) * T::LPT>();          // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                  // ... and everyone's; everyone is also done reading tile kt-1
@@ -228,13 +231,37 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
     }
 
     static_assert(T::NF == 2, "a wave's columns of one row are one 64-column row-statistics slot");
+    RowFx rowfx[T::MF];
+    if constexpr (FX) {
+        if (ln_on) ln_rows_finish<T::MF>(a, lnraw, rowfx);
+    }
+    // Memory operands of the epilogue are fetched ahead of the stores (gemm_tile.h::QuadIn), one 32-column fragment i at a
+    // time so the 128 x 64 tile stays inside 128 VGPRs (two workgroups per CU): the column-only operands of its 4 quads once,
+    // the per-row ones for all 4 quads of a row before that row's first store.
+    RowFx rows[T::MF];
 #pragma unroll
-    for (int j = 0; j < T::MF; ++j) {
-        const int m = m0 + (wm * T::MF + j) * 32 + l31;
-        if (m >= a.M) continue;
-        RowFx fx = rowfx[j];
+    for (int j = 0; j < T::MF; ++j) rows[j] = rowfx[j];
 #pragma unroll
-        for (int i = 0; i < T::NF; ++i)
+    for (int i = 0; i < T::NF; ++i) {
+        QuadIn qin[4];
+        if (nsl == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi;
+                if (nb < a.N) quad_load_cols<EPI, FX>(a, nb, qin[g]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T::MF; ++j) {
+            const int m = m0 + (wm * T::MF + j) * 32 + l31;
+            if (m >= a.M) continue;
+            if (nsl == 1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi;
+                    if (nb < a.N) quad_load_row<EPI>(a, m, nb, qin[g]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nb = n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi;
@@ -247,14 +274,22 @@ __global__ __launch_bounds__(T::THREADS) void gemm2_kernel(const GemmArgs a) {
                                  (size_t)(m - m0) * T::BNv + (nb - n0);
                     *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
                 } else {
-                    store_quad<EPI, FX>(a, m, nb, v, fx);
+                    store_quad<EPI, FX>(a, m, nb, v, rows[j], qin[g]);
                 }
             }
-        // fused LayerNorm, producer side: lanes l and l + 32 hold the two halves of this wave's 64 columns of row m
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // fused LayerNorm, producer side: lanes l and l + 32 hold the two halves of this wave's 64 columns of a row
+    if constexpr (FX) {
         const int nslot = n0 + wn * 64;
-        if (FX && a.row_stats_out && nsl == 1 && nslot < a.N) {
-            const float s = fx.rs + __shfl_xor(fx.rs, 32, 64), q = fx.rq + __shfl_xor(fx.rq, 32, 64);
-            if (hi == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+        if (a.row_stats_out && nsl == 1 && nslot < a.N) {
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j) {
+                const int m = m0 + (wm * T::MF + j) * 32 + l31;
+                const float s = rows[j].rs + __shfl_xor(rows[j].rs, 32, 64), q = rows[j].rq + __shfl_xor(rows[j].rq, 32, 64);
+                if (hi == 0 && m < a.M) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+            }
         }
     }
 }
@@ -476,7 +511,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.bias2 && a.rows_per_batch < 1) return -22;
     // fused LayerNorm / V^T epilogues: whole quads only, statistics slots of 64 columns
     if (gemm_fx(a) && !gemm_fx_epi(a.epi)) return -22;
-    if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
+    if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
     if (a.row_stats_out && ((a.N & 63) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
     if (a.vt_out && (a.epi != EPI_NONE || a.conv.mode != CONV_NONE || (a.vt_col0 & 63) || ((a.N - a.vt_col0) & 63) || a.vt_col0 < 0 ||

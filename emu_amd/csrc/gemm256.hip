@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     if (wr == 0) bar();
 
     // ---- epilogue: accumulator (x, y, i): rows n = n0 + wr*128 + x*64 + i*32 + 8*g + 4*hi + e, column m = .. + l31
-    auto emit = [&](int m, int nb, float (&v)[4], RowFx& fx) {
+    auto emit = [&](int m, int nb, float (&v)[4], RowFx& fx, const QuadIn& q) {
         if constexpr (F8) {
             if (nsl == 1) {                            // K-sliced: pp_reduce_kernel scales the summed slices
                 const float sa = a.a_scale[m];
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             float* dst = a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * SLICE + (size_t)(m - m0) * 256 + (nb - n0);
             *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
         } else {
-            store_quad<EPI, FX>(a, m, nb, v, fx);
+            store_quad<EPI, FX>(a, m, nb, v, fx, q);
         }
     };
     RowFx rowfx[2];
@@ -334,17 +334,39 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             int mr[2];
 #pragma unroll
             for (int y = 0; y < 2; ++y) { const int m = m0 + wc * 64 + y * 32 + l31; mr[y] = m < a.M ? m : a.M - 1; }
-            ln_rows_stats<2>(a, mr, rowfx);
+            LnRaw<2> raw;                              // one batch: a single L2 round trip at the head of the epilogue
+            ln_rows_load<2>(a, mr, raw);
+            ln_rows_finish<2>(a, raw, rowfx);
         }
     }
+    // Sub-tile x (64 columns) at a time: its column-only operands (bias / fused-LayerNorm vectors) are fetched once for both row
+    // blocks y, a row block's residual / per-batch bias for all of its 8 quads before its first store (gemm_tile.h::QuadIn).
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-        const int m = m0 + wc * 64 + y * 32 + l31;
-        if (m >= a.M) continue;
-        RowFx fx = rowfx[y];
+    for (int x = 0; x < 2; ++x) {
+        QuadIn qin[2][4];
+        if (nsl == 1) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            fx.rs = fx.rq = 0.f;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = n0 + wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi;
+                    if (nb < a.N) quad_load_cols<EPI, FX>(a, nb, qin[i][g]);
+                }
+        }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int m = m0 + wc * 64 + y * 32 + l31;
+            if (m >= a.M) continue;
+            RowFx fx = rowfx[y];
+            if (nsl == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = n0 + wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi;
+                        if (nb < a.N) quad_load_row<EPI>(a, m, nb, qin[i][g]);
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[x][y][i][4 * g + e];
-                    emit(m, nb, v, fx);
+                    emit(m, nb, v, fx, qin[i][g]);
                 }
             // fused LayerNorm, producer side: sub-tile x of this wave = one 64-column slot of row m, halves in lanes l / l + 32
             const int nslot = n0 + wr * 128 + x * 64;
@@ -362,12 +384,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 const float s = fx.rs + __shfl_xor(fx.rs, 32, 64), q = fx.rq + __shfl_xor(fx.rq, 32, 64);
                 if (hi == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
             }
-            if constexpr (FX) __builtin_amdgcn_sched_barrier(0);   // keep the next sub-tile's loads from piling up (256-VGPR kernel)
         }
+        __builtin_amdgcn_sched_barrier(0);             // keep the next sub-tile's loads from piling up (256-VGPR kernel)
     }
     if (ext) {
         const int m = m0 + 256 + l31;
         if (m < a.M) {
+            QuadIn qx[4];
+            if (nsl == 1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = n0 + wr * 128 + wc * 32 + 8 * g + 4 * hi;
+                    if (nb < a.N) { quad_load_cols<EPI, FX>(a, nb, qx[g]); quad_load_row<EPI>(a, m, nb, qx[g]); }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nb = n0 + wr * 128 + wc * 32 + 8 * g + 4 * hi;
@@ -376,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = accx[4 * g + e];
                 RowFx fx;                              // remainder rows never carry the fused-LayerNorm features (gemm256_ok)
-                emit(m, nb, v, fx);
+                emit(m, nb, v, fx, qx[g]);
             }
         }
     }
@@ -408,8 +438,11 @@ __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
                 const float sa = a.a_scale[m];
                 for (int e = 0; e < 4; ++e) v[e] *= sa * a.w_scale[nb + e < a.N ? nb + e : a.N - 1];
             }
+            QuadIn qi;
+            quad_load_cols<EPI, FX>(a, nb, qi);
+            quad_load_row<EPI>(a, m, nb, qi);
             if (FX && a.ln_c) ln_row_stats(a, m, fx);
-            store_quad<EPI, FX>(a, m, nb, v, fx);
+            store_quad<EPI, FX>(a, m, nb, v, fx, qi);
         }
         if constexpr (FX) emit_row_stats16(a, m, nb, ok, fx);
     }

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--filter", default="")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--shapes", default="", help="extra GEMM cases M,N,K,epi;M,N,K,epi;... (run instead of the built-in list)")
     a = ap.parse_args()
     L = lib()
     sk = torch.zeros(512 * 288 * 256, dtype=torch.float32, device="cuda")
@@ -93,6 +94,9 @@ def main():
     convs = [("conv lvl2", 2, 32, 1280, 1280, 1), ("conv lvl2 cat", 2, 32, 2560, 1280, 1), ("conv lvl1", 2, 64, 640, 640, 1),
              ("conv lvl1 cat", 2, 64, 1280, 640, 1), ("conv lvl0", 2, 128, 320, 320, 1), ("conv lvl0 cat", 2, 128, 960, 320, 1),
              ("conv up", 2, 32, 1280, 1280, 3), ("conv down", 2, 64, 640, 640, 2)]
+    if a.shapes:
+        gemms = [("custom",) + tuple(int(v) for v in sh.split(",")) for sh in a.shapes.split(";")]
+        convs = []
     names = a.cfgs.split(",")
     cfgs = [0 if c == "0" else (ord(c[0]) | (int(c[1:] or 0) << 8)) for c in names]
     print(f"{'case':40s} " + " ".join(f"{('auto' if c == '0' else c):>14s}" for c in names))
