@@ -121,6 +121,7 @@ def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
                 best = (dt, dtype, th)
         _, dtype, th = best
         torch.set_num_threads(th)
+        W = W32
         one_layer, head = make(dtype)
         one_layer(); head()
         t0 = time.perf_counter(); n = 0
@@ -133,10 +134,63 @@ def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
         t_head = (time.perf_counter() - t0) / m
     tok_s = 1.0 / (60 * t_layer + t_head)
     dn = "fp32" if dtype == torch.float32 else "bf16"
-    return {"value": tok_s, "unit": "tokens/s", "cores": th, "kind": "port",
+    port = {"value": tok_s, "unit": "tokens/s", "cores": th, "kind": "port",
             "sample": f"1 true-shape LLaMA-33B decoder layer x{n} + lm_head x{m} ({dn}, ctx {ctx_len}, batch 1) on {th} of "
                       f"{ncpu} host threads (fastest of a dtype/thread calibration); tokens/s = 1/(60*{t_layer * 1e3:.1f} ms "
                       f"+ {t_head * 1e3:.1f} ms)"}
+    # the layer the REFERENCE executes: transformers' own LlamaDecoderLayer (Emu2/emu/lm.py builds LlamaForCausalLM; the
+    # arithmetic is the library's), same shapes / dtype / threads / cached context, timed beside the port
+    try:
+        t_ref, n_ref = _reference_layer_time(W, dtype, cfg, ctx_len, k0, v0, x0, seconds * 0.5)
+        ref_tok_s = 1.0 / (60 * t_ref + t_head)
+        return {"value": ref_tok_s, "unit": "tokens/s", "cores": th, "kind": "reference",
+                "sample": f"transformers {__import__('transformers').__version__} LlamaDecoderLayer (eager attention, DynamicCache with {ctx_len} "
+                          f"cached positions) at the LLaMA-33B shape x{n_ref} + lm_head x{m} ({dn}, batch 1) on {th} of {ncpu} host threads; "
+                          f"tokens/s = 1/(60*{t_ref * 1e3:.1f} ms + {t_head * 1e3:.1f} ms)",
+                "port": port}
+    except Exception as e:                                  # library API drift: keep the port
+        port["reference_note"] = f"transformers layer not timed: {type(e).__name__}: {e}"
+        return port
+
+
+def _reference_layer_time(W32, dtype, cfg, ctx_len, k0, v0, x0, seconds):
+    """Seconds per cached decode step of transformers' LlamaDecoderLayer holding the port's weights."""
+    import inspect
+    from transformers import LlamaConfig
+    from transformers.cache_utils import DynamicCache
+    from transformers.models.llama import modeling_llama as ML
+    lc = LlamaConfig(hidden_size=cfg.hidden, intermediate_size=cfg.ffn, num_attention_heads=cfg.heads, num_key_value_heads=cfg.heads,
+                     num_hidden_layers=1, vocab_size=cfg.vocab, max_position_embeddings=cfg.max_pos, rms_norm_eps=cfg.rms_eps,
+                     rope_theta=cfg.rope_theta)
+    lc._attn_implementation = "eager"
+    layer = ML.LlamaDecoderLayer(lc, 0).eval()
+    pre = "decoder.lm.model.layers.0."
+    sd = {k[len(pre):]: v for k, v in W32.items() if k.startswith(pre)}
+    layer.load_state_dict(sd, strict=True)
+    layer = layer.to(dtype)
+    rot = ML.LlamaRotaryEmbedding(lc)
+    x = x0.to(dtype)
+    pos = torch.tensor([[ctx_len]])
+    cos, sin = rot(x, pos)
+    kk, vv = k0.to(dtype), v0.to(dtype)
+
+    def fresh():
+        c = DynamicCache(config=lc) if "config" in inspect.signature(DynamicCache.__init__).parameters else DynamicCache()
+        c.update(kk, vv, 0)
+        return c
+
+    def step():
+        c = fresh()                                         # the layer appends one position per call
+        t0 = time.perf_counter()
+        layer(x, attention_mask=None, position_ids=pos, past_key_values=c, use_cache=True, position_embeddings=(cos, sin))
+        return time.perf_counter() - t0
+    with torch.no_grad():
+        step()
+        tot, n = 0.0, 0
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end or n < 2:
+            tot += step(); n += 1
+    return tot / n, n
 
 
 UNET_FLOPS_PER_STEP = 13.48e12      # BASELINE.md section 2: one denoise step (CFG batch 2) at 128x128 latents, 64 ctx tokens

@@ -456,7 +456,9 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // scratch, a second launch sums them in order and applies the epilogue.  (Slicing only the tail round of a
         // multi-round problem measured flat: a thin last round simply runs faster.)
         const int tc = tiles_of(a, 256, 128);
-        if (k64 && tc < 256 && pick_ksplit<EPI>(a, tc, 256 * 128, 16)) cfg = 'S';
+        // (>= 24 k tiles per slice: with fewer the reduce launch costs more than the slices save -- the ViT's proj at 16 per
+        // slice ran 284 TFLOP/s sliced, 381 on the 128 x 64 tile; profiles/r03_gemm_ilv_ab.log)
+        if (k64 && tc < 256 && pick_ksplit<EPI>(a, tc, 256 * 128, 24)) cfg = 'S';
         // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so the largest problems take the
         // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
         // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
@@ -477,7 +479,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         }
         case 'S': {
             const int tc = tiles_of(a, 256, 128);
-            const int ksplit = tc < 256 ? pick_ksplit<EPI>(a, tc, 256 * 128, g_force_cfg ? 8 : 16) : 0;
+            const int ksplit = tc < 256 ? pick_ksplit<EPI>(a, tc, 256 * 128, g_force_cfg ? 8 : 24) : 0;
             if (ksplit) launch_cfg<EPI, CONV, CfgC>(a, s, 0, ksplit, ilv);
             else launch_cfg<EPI, CONV, CfgC>(a, s, -1, 1, ilv);
             break;

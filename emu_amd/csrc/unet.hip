@@ -9,7 +9,8 @@ namespace {
 
 constexpr int GN_DEPTH = 16;         // pixel rows each thread walks serially in the statistics pass
 constexpr int GN_MAXC = 2560;        // widest activation of the SDXL topology (first resnet of the up path: 1280 + 1280)
-constexpr int GN_MAXG = 64;
+constexpr int GN_MAXG = 32;         // groups (the reference: norm_num_groups 32)
+constexpr int GN_MAXCHUNK = 32;     // pixel chunks per batch element in the statistics pass
 
 // How the 256 threads of a statistics workgroup are laid out for C channels: nv 16-byte channel vectors per pixel row,
 // RG row groups side by side (all 256 threads busy for C = 320 as well as 1280), GN_DEPTH rows per thread.
@@ -19,12 +20,13 @@ __host__ __device__ inline int gn_rows_per_block(int C) { return GN_DEPTH * gn_r
 // Pass 1 of 2: per (batch, pixel chunk) the fp32 (sum, sum of squares) of every GROUP: ws[((b * nchunk + chunk) * G + g) * 2].
 // Channel sums of the chunk meet in LDS and are folded to groups in a fixed order (deterministic).  One launch of the former
 // three (per-channel partials / finalize / apply) is gone: the apply pass derives mean / rstd itself from these few floats.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
+                                                       int rows) {
     __shared__ float csum[2 * GN_MAXC];               // per-channel (sum | sum of squares) of this chunk
     __shared__ float part[256 * 16];                  // row groups side by side (narrow rows)
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int nv = C >> 3;
-    const int RG = gn_row_groups(C), rows = GN_DEPTH * RG;
+    const int RG = gn_row_groups(C);
     const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
     const int tid = threadIdx.x;
     if (RG == 1) {                                   // wide rows: one thread per channel vector (loop when nv > 256)
@@ -84,18 +86,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     __shared__ double red[2][8][GN_MAXG];
     __shared__ float stat[2][GN_MAXG];                 // mean | rstd per group
     const int b = blockIdx.y, tid = threadIdx.x;
-    {   // 8 slices of the chunk list x G groups: thread (slice, g) sums its chunks, slices meet in LDS
-        const int g = tid % GN_MAXG, sl = tid / GN_MAXG;          // 256 threads = 4 slices of 64 group slots
-        double s = 0.0, q = 0.0;
-        if (g < G) {
-            const float* p = ws + ((size_t)b * nchunk * G + g) * 2;
-            for (int c = sl; c < nchunk; c += 4) { s += (double)p[(size_t)c * G * 2]; q += (double)p[(size_t)c * G * 2 + 1]; }
+    {   // at most GN_MAXCHUNK chunks x GN_MAXG groups: thread (slice, g) fetches its 4 chunk pairs in ONE batch of loads (indices
+        // clamped, no branch around a load) and sums them; the 8 slices meet in LDS in a fixed order
+        const int g = tid & (GN_MAXG - 1), sl = tid >> 5;
+        const float* p = ws + ((size_t)b * nchunk * G + (g < G ? g : 0)) * 2;
+        f32x2_t v[GN_MAXCHUNK / 8];
+#pragma unroll
+        for (int k = 0; k < GN_MAXCHUNK / 8; ++k) {
+            const int c = sl + 8 * k;
+            v[k] = *reinterpret_cast<const f32x2_t*>(p + (size_t)(c < nchunk ? c : 0) * G * 2);
         }
-        red[0][sl][g] = s; red[1][sl][g] = q;
+        double sd = 0.0, qd = 0.0;
+#pragma unroll
+        for (int k = 0; k < GN_MAXCHUNK / 8; ++k) {
+            const bool in = sl + 8 * k < nchunk && g < G;
+            sd += in ? (double)v[k][0] : 0.0;
+            qd += in ? (double)v[k][1] : 0.0;
+        }
+        red[0][sl][g] = sd; red[1][sl][g] = qd;
         __syncthreads();
         if (tid < G) {
-            const double ts = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
-            const double tq = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
+            double ts = 0.0, tq = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ts += red[0][k][tid]; tq += red[1][k][tid]; }
             const double n = (double)HW * (C / G);
             const double mean = ts / n;
             double var = tq / n - mean * mean;
@@ -199,20 +212,21 @@ __global__ __launch_bounds__(256) void gather_step_row_kernel(const bf16_t* __re
 }  // namespace
 
 size_t gn_ws_floats(int B, int C, int HW) {
-    const int rows = gn_rows_per_block(C);
-    const int nchunk = (HW + rows - 1) / rows;         // monotone in HW, non-increasing rows in C: sized for the narrowest C in use
-    (void)nchunk;
-    // worst case over the channel widths a caller may pass with this HW: the narrowest rows give the most chunks
-    const int max_chunks = (HW + GN_DEPTH - 1) / GN_DEPTH;
-    return (size_t)B * max_chunks * GN_MAXG * 2;
+    (void)C; (void)HW;
+    return (size_t)B * GN_MAXCHUNK * GN_MAXG * 2;
 }
 
 int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, float* ws, int B, int HW, int C,
                      int groups, float eps, int do_silu, hipStream_t s) {
     if (B < 1 || HW < 1 || (C & 7) || C % groups || groups > GN_MAXG || C > GN_MAXC) return -22;
-    const int rows = gn_rows_per_block(C);
-    const int nchunk = (HW + rows - 1) / rows;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C, groups);
+    // GN_MAXCHUNK chunks of whole thread-layout passes per batch element (fewer for small maps): the apply pass folds exactly
+    // one batch of loads per thread
+    const int unit = gn_rows_per_block(C);
+    int nchunk = (HW + unit - 1) / unit;
+    if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
+    const int rows = (HW + nchunk - 1) / nchunk;
+    nchunk = (HW + rows - 1) / rows;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C, groups, rows);
     const size_t total = (size_t)HW * (C >> 3);
     const int grid = (int)min((size_t)4096, (total + 255) / 256);
     if (do_silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid, B), dim3(256), 0, s, x, ws, gamma, beta, y, HW, C, groups, nchunk, eps);
