@@ -53,7 +53,7 @@ struct TileCfg {
 
 // ILV: the LDS-DMA of tile kt + NSTG - 1 is issued in KSTEPS shares BEHIND the MFMAs of each k-step instead of in one block
 // ahead of them, so the DMA issue slots (60-180 cycles each) overlap matrix-pipe time instead of preceding it.
-template <int EPI, bool CONV, class T, bool FX = false, bool ILV = false>
+template <int EPI, bool CONV, class T, int FX = 0, bool ILV = false>
 __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
@@ -154,20 +154,6 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fused LayerNorm, consumer side: the partial sums of this lane's rows are requested here and summed in the epilogue
-    LnRaw<T::MF> lnraw;
-    const bool ln_on = FX && a.ln_c && nsl == 1;
-    if constexpr (FX) {
-        if (ln_on) {
-            int mr[T::MF];
-#pragma unroll
-            for (int j = 0; j < T::MF; ++j) {
-                const int m = m0 + (wm * T::MF + j) * 32 + l31;
-                mr[j] = m < a.M ? m : a.M - 1;
-            }
-            ln_rows_load<T::MF>(a, mr, lnraw);
-        }
-    }
 #pragma unroll
     for (int t = 0; t < T::NSTG - 1; ++t) issue(t, t);
     for (int kt = 0; kt < nk; ++kt) {
@@ -206,6 +192,22 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
             }
         }
     }
+    // fused LayerNorm, consumer side: the partial sums of this lane's rows are requested BEHIND the tail LDS-DMA (past-the-end
+    // re-loads that keep the counted waits uniform) so the one L2 round trip overlaps their drain, and summed in the epilogue;
+    // requested at the top of the kernel they cost 40-80 registers through the main loop (spills on the 128-VGPR tile)
+    LnRaw<T::MF> lnraw;
+    const bool ln_on = (FX & FX_LN) != 0 && nsl == 1;
+    if constexpr ((FX & FX_LN) != 0) {
+        if (ln_on) {
+            int mr[T::MF];
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j) {
+                const int m = m0 + (wm * T::MF + j) * 32 + l31;
+                mr[j] = m < a.M ? m : a.M - 1;
+            }
+            ln_rows_load<T::MF>(a, mr, lnraw);
+        }
+    }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
 
     if constexpr (T::KG > 1) {
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
 
     static_assert(T::NF == 2, "a wave's columns of one row are one 64-column row-statistics slot");
     RowFx rowfx[T::MF];
-    if constexpr (FX) {
+    if constexpr ((FX & FX_LN) != 0) {
         if (ln_on) ln_rows_finish<T::MF>(a, lnraw, rowfx);
     }
     // Memory operands of the epilogue are fetched ahead of the stores (gemm_tile.h::QuadIn), one 32-column fragment i at a
@@ -281,9 +283,9 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         __builtin_amdgcn_sched_barrier(0);
     }
     // fused LayerNorm, producer side: lanes l and l + 32 hold the two halves of this wave's 64 columns of a row
-    if constexpr (FX) {
+    if constexpr ((FX & FX_STATS) != 0) {
         const int nslot = n0 + wn * 64;
-        if (a.row_stats_out && nsl == 1 && nslot < a.N) {
+        if (nsl == 1 && nslot < a.N) {
 #pragma unroll
             for (int j = 0; j < T::MF; ++j) {
                 const int m = m0 + (wm * T::MF + j) * 32 + l31;
@@ -313,21 +315,24 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
-    constexpr bool CAN_ILV = !CONV && gemm_fx_epi(EPI);                  // schedule experiment: plain GEMMs of the UNet epilogues
-    if (CAN_ILV && ilv && !gemm_fx(b)) {
+    constexpr bool CAN_ILV = !CONV && (EPI == EPI_NONE || EPI == EPI_RESID || EPI == EPI_GEGLU);   // schedule experiment
+    const int fx = gemm_fx(b);
+    if (CAN_ILV && ilv && !fx) {
         if constexpr (CAN_ILV) {
-            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, false, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, 0, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
             if (tail > 0)
                 hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
         }
         return;
     }
-    constexpr bool CAN_FX = !CONV && gemm_fx_epi(EPI);
-    if (CAN_FX && gemm_fx(b)) {
-        if constexpr (CAN_FX) {
-            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
-            if (tail > 0)
-                hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv, true>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+    if (fx) {                                           // launch_gemm has checked gemm_fx_ok(epi, fx)
+        if constexpr (!CONV) {
+            gemm_fx_dispatch<EPI>(fx, [&](auto m) {
+                constexpr int FXM = decltype(m)::value;
+                hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+                if (tail > 0)
+                    hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv, FXM>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+            });
         }
         return;
     }
@@ -512,7 +517,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
     if (a.bias2 && a.rows_per_batch < 1) return -22;
     // fused LayerNorm / V^T epilogues: whole quads only, statistics slots of 64 columns
-    if (gemm_fx(a) && !gemm_fx_epi(a.epi)) return -22;
+    if (!gemm_fx_ok(a.epi, gemm_fx(a))) return -22;
     if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
     if (a.row_stats_out && ((a.N & 63) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;

@@ -73,7 +73,7 @@ constexpr uint32_t OOB = 0x80000000u;    // beyond num_records of the descriptor
 // F8: both operands are OCP fp8 e4m3 bytes (a k tile is still 128 bytes per row = 128 elements), the MFMA is the gfx950
 // block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 rate), and the per-row scales of the
 // two operands (a.a_scale[m] * a.w_scale[n]) multiply the fp32 sums ahead of the epilogue.
-template <int EPI, bool CONV, bool F8, bool FX = false>
+template <int EPI, bool CONV, bool F8, int FX = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * QXB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
     // this workgroup also owns rows m0 + 256 .. M - 1 (never with the fused epilogues: gemm256_ok refuses that combination)
-    const bool ext = !CONV && !F8 && !FX && ext_rows > 0 && tm == tiles_m - 1;
+    const bool ext = !CONV && !F8 && FX == 0 && ext_rows > 0 && tm == tiles_m - 1;
 
     // ---- LDS-DMA sources.  Instruction i (0, 1) of a unit fills LDS rows r = i*64 + srow, srow = wave*8 + lane/8, slot
     // lane%8 <- global chunk slot ^ ((r >> 1) & 7).  P unit s: row r holds weight row n0 + (r >> 6)*128 + s*64 + (r & 63);
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         }
     };
     RowFx rowfx[2];
-    if constexpr (FX) {                                // fused LayerNorm, consumer side: both rows of this lane in one batch of loads
-        if (a.ln_c && nsl == 1) {
+    if constexpr ((FX & FX_LN) != 0) {                 // fused LayerNorm, consumer side: both rows of this lane in one batch of loads
+        if (nsl == 1) {
             int mr[2];
 #pragma unroll
             for (int y = 0; y < 2; ++y) { const int m = m0 + wc * 64 + y * 32 + l31; mr[y] = m < a.M ? m : a.M - 1; }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 }
             // fused LayerNorm, producer side: sub-tile x of this wave = one 64-column slot of row m, halves in lanes l / l + 32
             const int nslot = n0 + wr * 128 + x * 64;
-            if (FX && a.row_stats_out && nsl == 1 && nslot < a.N) {
+            if ((FX & FX_STATS) != 0 && nsl == 1 && nslot < a.N) {
                 const float s = fx.rs + __shfl_xor(fx.rs, 32, 64), q = fx.rq + __shfl_xor(fx.rq, 32, 64);
                 if (hi == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
             }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 }
 
 // second launch of a K-sliced run: sum the slices of every tile (288 x 256 fp32 each: the tile and its remainder rows)
-template <int EPI, bool FX = false>
+template <int EPI, int FX = 0>
 __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
     int ext_rows;
     const int tiles_m = pp_tiles_m(a.M, a.conv.mode == CONV_NONE && !a.a_scale, ext_rows);
@@ -441,10 +441,10 @@ __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
             QuadIn qi;
             quad_load_cols<EPI, FX>(a, nb, qi);
             quad_load_row<EPI>(a, m, nb, qi);
-            if (FX && a.ln_c) ln_row_stats(a, m, fx);
+            if constexpr ((FX & FX_LN) != 0) ln_row_stats(a, m, fx);
             store_quad<EPI, FX>(a, m, nb, v, fx, qi);
         }
-        if constexpr (FX) emit_row_stats16(a, m, nb, ok, fx);
+        if constexpr ((FX & FX_STATS) != 0) emit_row_stats16(a, m, nb, ok, fx);
     }
 }
 
@@ -455,11 +455,14 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
-    constexpr bool CAN_FX = !CONV && !F8 && gemm_fx_epi(EPI);
-    if (CAN_FX && gemm_fx(b)) {
-        if constexpr (CAN_FX) {
-            hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8, true>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
-            if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI, true>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+    const int fx = gemm_fx(b);
+    if (fx) {                                           // gemm256_ok: bf16 plain GEMM; launch_gemm: an instantiated (epi, mask) pair
+        if constexpr (!CONV && !F8) {
+            gemm_fx_dispatch<EPI>(fx, [&](auto m) {
+                constexpr int FXM = decltype(m)::value;
+                hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
+                if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI, FXM>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+            });
         }
         return;
     }

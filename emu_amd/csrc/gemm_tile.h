@@ -2,6 +2,8 @@
 // ping-pong tile): the fused epilogue of one accumulator quad, LDS-DMA and counted-wait helpers, the implicit-GEMM 3x3
 // gather and the split-K reduce launch.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -37,6 +39,13 @@ __device__ __forceinline__ bool conv_tap(const ConvGeom& g, int py, int px, int 
 // Fused-LayerNorm state of one output row inside an epilogue (GemmArgs::ln_* / row_stats_out): the statistics of row m
 // of A for the consumer-side correction, and the running (sum, sum of squares) of the bf16 outputs this lane has written
 // into the current 64-column slot for the producer side.
+// Compile-time feature mask of the fused epilogues (template parameter FX of the kernels and of store_quad): every
+// combination the UNet launches has its own instantiation, so a producer that only emits row statistics carries none of the
+// consumer's registers (its 20 statistics pairs, the fp32 ln_c / ln_d quads) and vice versa.
+constexpr int FX_LN = 1;            // GemmArgs::ln_*: LayerNorm of A folded into this GEMM
+constexpr int FX_STATS = 2;         // GemmArgs::row_stats_out: emit per-row partial sums of C
+constexpr int FX_VT = 4;            // GemmArgs::vt_out: V heads stored key-contiguous
+
 struct RowFx {
     float mean = 0.f, rstd = 1.f;
     float rs = 0.f, rq = 0.f;
@@ -109,10 +118,10 @@ __device__ __forceinline__ bool quad_full(const GemmArgs& a, int nb) {
     return (nb + 3) < a.N && (GLU || ((a.ldc | (EPI == EPI_RESID ? a.ldres : 0)) & 3) == 0);
 }
 // operands that depend on the column only: one fetch serves every row of the lane
-template <int EPI, bool FX>
+template <int EPI, int FX>
 __device__ __forceinline__ void quad_load_cols(const GemmArgs& a, int nb, QuadIn& q) {
     if (!quad_full<EPI>(a, nb)) return;
-    if (FX && a.ln_c) {
+    if constexpr ((FX & FX_LN) != 0) {
         q.c = *reinterpret_cast<const f32x4_t*>(a.ln_c + nb);
         q.d = *reinterpret_cast<const f32x4_t*>(a.ln_d + nb);
     } else if (a.bias) {
@@ -128,11 +137,11 @@ __device__ __forceinline__ void quad_load_row(const GemmArgs& a, int m, int nb, 
 }
 
 // Epilogue for one accumulator quad: lane-local 4 consecutive output columns nb..nb+3 of row m; q = its memory operands.
-// FX = false compiles every fused-LayerNorm / V^T feature out (the instantiations all other callers use are unchanged).
-template <int EPI, bool FX = false>
+// FX = 0 compiles every fused-LayerNorm / V^T feature out (the instantiations all other callers use are unchanged).
+template <int EPI, int FX = 0>
 __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, float (&v)[4], RowFx& fx, const QuadIn& q) {
     if (quad_full<EPI>(a, nb)) {
-        if (FX && a.ln_c) {                            // LayerNorm folded into this GEMM (launch_gemm: N % 4 == 0, no bias)
+        if constexpr ((FX & FX_LN) != 0) {             // LayerNorm folded into this GEMM (launch_gemm: N % 4 == 0, no bias)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(fx.rstd, v[e] - fx.mean * q.c[e], q.d[e]);
         } else if (a.bias) {
@@ -171,12 +180,12 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, flo
             u32x2 ov;
             ov.x = packbf(v[0], v[1]);
             ov.y = packbf(v[2], v[3]);
-            if (FX && a.row_stats_out) {               // statistics of what the next LayerNorm will read: the bf16 values
+            if constexpr ((FX & FX_STATS) != 0) {      // statistics of what the next LayerNorm will read: the bf16 values
                 const float r0 = bflo(ov.x), r1 = bfhi(ov.x), r2 = bflo(ov.y), r3 = bfhi(ov.y);
                 fx.rs += (r0 + r1) + (r2 + r3);
                 fx.rq += fmaf(r0, r0, r1 * r1) + fmaf(r2, r2, r3 * r3);
             }
-            if (FX && a.vt_out && nb >= a.vt_col0) {   // V heads: key-contiguous store for the P.V MFMA (wave-uniform branch)
+            if ((FX & FX_VT) != 0 && nb >= a.vt_col0) {   // V heads: key-contiguous store for the P.V MFMA (wave-uniform branch)
                 const int b = m / a.vt_s, sidx = m - b * a.vt_s;
                 bf16_t* dst = a.vt_out + ((size_t)b * (a.N - a.vt_col0) + (nb - a.vt_col0)) * a.vt_spad + sidx;
                 dst[0] = (bf16_t)(ov.x & 0xffffu);
@@ -232,7 +241,7 @@ __device__ __forceinline__ void emit_row_stats16(const GemmArgs& a, int m, int n
 // second launch of a split-K GEMM: sum the K-slices of every sliced tile in slice order (deterministic) and apply the
 // fused epilogue.  SPLITK_RED_Y workgroups per tile (a handful of tiles must still fill the chip).
 constexpr int SPLITK_RED_Y = 16;
-template <int EPI, int BMv, int BNv, bool FX = false>
+template <int EPI, int BMv, int BNv, int FX = 0>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     const int wg = a.full_tiles + blockIdx.x;
     const int tiles_m = (a.M + BMv - 1) / BMv;
@@ -255,15 +264,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
             QuadIn qi;
             quad_load_cols<EPI, FX>(a, nb, qi);
             quad_load_row<EPI>(a, m, nb, qi);
-            if (FX && a.ln_c) ln_row_stats(a, m, fx);
+            if constexpr ((FX & FX_LN) != 0) ln_row_stats(a, m, fx);
             store_quad<EPI, FX>(a, m, nb, v, fx, qi);
         }
-        if constexpr (FX) emit_row_stats16(a, m, nb, ok, fx);
+        if constexpr ((FX & FX_STATS) != 0) emit_row_stats16(a, m, nb, ok, fx);
     }
 }
 
-// does this launch use the fused epilogue features?  (host side: picks the FX instantiation)
-inline bool gemm_fx(const GemmArgs& a) { return a.ln_c || a.row_stats_out || a.vt_out; }
-constexpr bool gemm_fx_epi(int epi) { return epi == EPI_NONE || epi == EPI_RESID || epi == EPI_GEGLU; }
+// the feature mask of a launch (host side: picks the FX instantiation), and the (epilogue, mask) pairs that are instantiated:
+// what the UNet transformer blocks launch -- proj_in / to_q producers and consumers, the qkv projection (+ V^T), the residual
+// out-projections and ff-out as producers, the GEGLU projection as a consumer
+inline int gemm_fx(const GemmArgs& a) { return (a.ln_c ? FX_LN : 0) | (a.row_stats_out ? FX_STATS : 0) | (a.vt_out ? FX_VT : 0); }
+constexpr bool gemm_fx_ok(int epi, int fx) {
+    return fx == 0 || (epi == EPI_NONE && (fx == FX_LN || fx == FX_STATS || fx == FX_VT || fx == (FX_LN | FX_VT))) ||
+           (epi == EPI_RESID && fx == FX_STATS) || (epi == EPI_GEGLU && fx == FX_LN);
+}
+// calls f(std::integral_constant<int, FX>) for the instantiated mask of this epilogue; false when the pair does not exist
+template <int EPI, class F>
+inline bool gemm_fx_dispatch(int fx, F&& f) {
+    if constexpr (EPI == EPI_NONE) {
+        switch (fx) {
+            case FX_LN: f(std::integral_constant<int, FX_LN>{}); return true;
+            case FX_STATS: f(std::integral_constant<int, FX_STATS>{}); return true;
+            case FX_VT: f(std::integral_constant<int, FX_VT>{}); return true;
+            case FX_LN | FX_VT: f(std::integral_constant<int, FX_LN | FX_VT>{}); return true;
+        }
+    } else if constexpr (EPI == EPI_RESID) {
+        if (fx == FX_STATS) { f(std::integral_constant<int, FX_STATS>{}); return true; }
+    } else if constexpr (EPI == EPI_GEGLU) {
+        if (fx == FX_LN) { f(std::integral_constant<int, FX_LN>{}); return true; }
+    }
+    return false;
+}
 
 }  // namespace emu_gemm
