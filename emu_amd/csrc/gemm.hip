@@ -57,7 +57,13 @@ template <int EPI, bool CONV, class T, int FX = 0, bool ILV = false>
 __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
-    constexpr int SMEM_BYTES = T::NSTG * T::ST_BYTES > RED_BYTES ? T::NSTG * T::ST_BYTES : RED_BYTES;
+    // row-statistics exchange between the two waves of a 128-column slot: behind the k-group sums where those exist (the ring is
+    // dead by then), else 8 KiB of its own behind the ring (other waves may still be reading tiles when the first one arrives)
+    constexpr int EX_BYTES = (FX & FX_STATS) != 0 ? T::WN * T::WM * T::MF * 64 * 8 : 0;
+    constexpr int EX_OFF = T::KG > 1 ? RED_BYTES : T::NSTG * T::ST_BYTES;
+    constexpr int RING_BYTES = T::NSTG * T::ST_BYTES > RED_BYTES ? T::NSTG * T::ST_BYTES : RED_BYTES;
+    constexpr int SMEM_BYTES = RING_BYTES > EX_OFF + EX_BYTES ? RING_BYTES : EX_OFF + EX_BYTES;
+    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,6 +160,23 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // fused LayerNorm, consumer side: the partial sums of this lane's rows (<= 10 pairs per row) are requested here, ahead of
+    // everything else, and only summed in the epilogue: hipcc waits at the first USE of a loaded value, the main loop's waits
+    // are our counted asm ones (older loads complete first), so the L2 / fabric round trip (~4 us when it is paid at the end
+    // of the kernel: the producer's lines sit in another XCD's L2 or in memory) costs nothing
+    LnRaw<T::MF> lnraw;
+    const bool ln_on = (FX & FX_LN) != 0 && nsl == 1;
+    if constexpr ((FX & FX_LN) != 0) {
+        if (ln_on) {
+            int mr[T::MF];
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j) {
+                const int m = m0 + (wm * T::MF + j) * 32 + l31;
+                mr[j] = m < a.M ? m : a.M - 1;
+            }
+            ln_rows_load<T::MF>(a, mr, lnraw);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < T::NSTG - 1; ++t) issue(t, t);
     for (int kt = 0; kt < nk; ++kt) {
@@ -192,22 +215,6 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
             }
         }
     }
-    // fused LayerNorm, consumer side: the partial sums of this lane's rows are requested BEHIND the tail LDS-DMA (past-the-end
-    // re-loads that keep the counted waits uniform) so the one L2 round trip overlaps their drain, and summed in the epilogue;
-    // requested at the top of the kernel they cost 40-80 registers through the main loop (spills on the 128-VGPR tile)
-    LnRaw<T::MF> lnraw;
-    const bool ln_on = (FX & FX_LN) != 0 && nsl == 1;
-    if constexpr ((FX & FX_LN) != 0) {
-        if (ln_on) {
-            int mr[T::MF];
-#pragma unroll
-            for (int j = 0; j < T::MF; ++j) {
-                const int m = m0 + (wm * T::MF + j) * 32 + l31;
-                mr[j] = m < a.M ? m : a.M - 1;
-            }
-            ln_rows_load<T::MF>(a, mr, lnraw);
-        }
-    }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
 
     if constexpr (T::KG > 1) {
@@ -223,7 +230,12 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
                     for (int r = 0; r < 16; ++r) red[((i * T::MF + j) * 16 + r) * 64 + lane] = acc[i][j][r];
         }
         __syncthreads();
-        if (kg == 1) return;
+        if (kg == 1) {
+            if constexpr ((FX & FX_STATS) != 0) {
+                if (nsl == 1) __syncthreads();         // the statistics exchange of the epilogue below (workgroup-wide barrier)
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < T::NF; ++i)
 #pragma unroll
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::MF + j) * 16 + r) * 64 + lane];
     }
 
-    static_assert(T::NF == 2, "a wave's columns of one row are one 64-column row-statistics slot");
+    static_assert(T::NF == 2, "a wave's columns of one row are half a 128-column row-statistics slot");
     RowFx rowfx[T::MF];
     if constexpr ((FX & FX_LN) != 0) {
         if (ln_on) ln_rows_finish<T::MF>(a, lnraw, rowfx);
@@ -282,15 +294,29 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // fused LayerNorm, producer side: lanes l and l + 32 hold the two halves of this wave's 64 columns of a row
+    // fused LayerNorm, producer side: a 128-column statistics slot of a row = the 64 columns of wave (wn, wm) + those of wave
+    // (wn + 1, wm), each split over lanes l and l + 32.  Odd wn hands its sums to its even neighbour through LDS.
     if constexpr ((FX & FX_STATS) != 0) {
-        const int nslot = n0 + wn * 64;
-        if (nsl == 1 && nslot < a.N) {
+        static_assert(T::WN % 2 == 0, "waves pair up along n");
+        if (nsl == 1) {                                // workgroup-uniform
+            f32x2_t* ex = reinterpret_cast<f32x2_t*>(smem + EX_OFF);
+            if (wn & 1) {
 #pragma unroll
-            for (int j = 0; j < T::MF; ++j) {
-                const int m = m0 + (wm * T::MF + j) * 32 + l31;
-                const float s = rows[j].rs + __shfl_xor(rows[j].rs, 32, 64), q = rows[j].rq + __shfl_xor(rows[j].rq, 32, 64);
-                if (hi == 0 && m < a.M) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+                for (int j = 0; j < T::MF; ++j) ex[(wtile * T::MF + j) * 64 + lane] = f32x2_t{rows[j].rs, rows[j].rq};
+            }
+            __syncthreads();
+            const int nslot = n0 + wn * 64;
+            if (!(wn & 1) && nslot < a.N) {
+#pragma unroll
+                for (int j = 0; j < T::MF; ++j) {
+                    const int m = m0 + (wm * T::MF + j) * 32 + l31;
+                    const f32x2_t o = ex[((wtile + T::WM) * T::MF + j) * 64 + lane];
+                    float sm = rows[j].rs + o[0], q = rows[j].rq + o[1];
+                    sm += __shfl_xor(sm, 32, 64);
+                    q += __shfl_xor(q, 32, 64);
+                    if (hi == 0 && m < a.M)
+                        *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot / LN_SLOT_COLS) * a.M + m) * 2) = f32x2_t{sm, q};
+                }
             }
         }
     }
@@ -519,7 +545,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     // fused LayerNorm / V^T epilogues: whole quads only, statistics slots of 64 columns
     if (!gemm_fx_ok(a.epi, gemm_fx(a))) return -22;
     if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
-    if (a.row_stats_out && ((a.N & 63) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
+    if (a.row_stats_out && ((a.N & 127) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
     if (a.vt_out && (a.epi != EPI_NONE || a.conv.mode != CONV_NONE || (a.vt_col0 & 63) || ((a.N - a.vt_col0) & 63) || a.vt_col0 < 0 ||
                      a.vt_col0 >= a.N || a.vt_s < 1 || a.M % a.vt_s || a.vt_spad < a.vt_s || (a.ldc & 3))) return -22;

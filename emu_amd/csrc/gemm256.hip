@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         for (int y = 0; y < 2; ++y) {
             const int m = m0 + wc * 64 + y * 32 + l31;
             if (m >= a.M) continue;
-            RowFx fx = rowfx[y];
+            RowFx& fx = rowfx[y];                      // statistics accumulate over both sub-tiles x of the row
             if (nsl == 1) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -378,14 +378,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                     for (int e = 0; e < 4; ++e) v[e] = acc[x][y][i][4 * g + e];
                     emit(m, nb, v, fx, qin[i][g]);
                 }
-            // fused LayerNorm, producer side: sub-tile x of this wave = one 64-column slot of row m, halves in lanes l / l + 32
-            const int nslot = n0 + wr * 128 + x * 64;
-            if ((FX & FX_STATS) != 0 && nsl == 1 && nslot < a.N) {
-                const float s = fx.rs + __shfl_xor(fx.rs, 32, 64), q = fx.rq + __shfl_xor(fx.rq, 32, 64);
-                if (hi == 0) *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot >> 6) * a.M + m) * 2) = f32x2_t{s, q};
-            }
         }
         __builtin_amdgcn_sched_barrier(0);             // keep the next sub-tile's loads from piling up (256-VGPR kernel)
+    }
+    // fused LayerNorm, producer side: this wave's 128 columns of a row = one statistics slot, halves in lanes l / l + 32
+    if constexpr ((FX & FX_STATS) != 0) {
+        const int nslot = n0 + wr * 128;
+        if (nsl == 1 && nslot < a.N) {
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int m = m0 + wc * 64 + y * 32 + l31;
+                const float sm = rowfx[y].rs + __shfl_xor(rowfx[y].rs, 32, 64), q = rowfx[y].rq + __shfl_xor(rowfx[y].rq, 32, 64);
+                if (hi == 0 && m < a.M)
+                    *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nslot / LN_SLOT_COLS) * a.M + m) * 2) = f32x2_t{sm, q};
+            }
+        }
     }
     if (ext) {
         const int m = m0 + 256 + l31;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
             if constexpr ((FX & FX_LN) != 0) ln_row_stats(a, m, fx);
             store_quad<EPI, FX>(a, m, nb, v, fx, qi);
         }
-        if constexpr ((FX & FX_STATS) != 0) emit_row_stats16(a, m, nb, ok, fx);
+        if constexpr ((FX & FX_STATS) != 0) emit_row_stats32(a, m, nb, ok, fx);
     }
 }
 

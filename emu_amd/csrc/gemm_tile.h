@@ -58,7 +58,8 @@ struct RowFx {
 // loaded value, so the main loop (whose only vector-memory waits are our counted asm ones; older loads complete first) never
 // stalls on them and the L2 round trip costs nothing.  (A plain `for slot: s += p[slot]` loop made every consumer GEMM 4-6 us
 // slower: hipcc waits for each load before issuing the next.)  Rows past M are clamped by the caller.
-constexpr int LN_MAX_SLOTS = 20;                       // K / 64 for K <= 1280 (the widest UNet level)
+constexpr int LN_SLOT_COLS = 128;                      // columns per row-statistics slot
+constexpr int LN_MAX_SLOTS = 10;                       // K / 128 for K <= 1280 (the widest UNet level)
 template <int NR>
 struct LnRaw { f32x2_t v[NR][LN_MAX_SLOTS]; };
 
@@ -229,13 +230,14 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, flo
     }
 }
 
-// Reduce kernels: a wave walks 64 consecutive quads = 256 columns of ONE row (QN % 64 == 0 or 16-lane groups inside a row),
-// so the 16-lane DPP sum is the (sum, sum of squares) of one 64-column slot.  Every lane of the wave must call this.
-__device__ __forceinline__ void emit_row_stats16(const GemmArgs& a, int m, int nb, bool ok, RowFx& fx) {
-    if (!a.row_stats_out) return;                      // wave-uniform
-    const float s = row16_sum(ok ? fx.rs : 0.f), q = row16_sum(ok ? fx.rq : 0.f);
-    if (ok && (threadIdx.x & 15) == 0)
-        *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nb >> 6) * a.M + m) * 2) = f32x2_t{s, q};
+// Reduce kernels: consecutive lanes walk consecutive quads of a row, so an aligned 32-lane half-wave holds 128 columns = one
+// statistics slot of one row: 16-lane DPP sums, then the two 16-lane groups meet.  Every lane of the wave must call this.
+__device__ __forceinline__ void emit_row_stats32(const GemmArgs& a, int m, int nb, bool ok, RowFx& fx) {
+    float s = row16_sum(ok ? fx.rs : 0.f), q = row16_sum(ok ? fx.rq : 0.f);
+    s += __shfl_xor(s, 16, 64);
+    q += __shfl_xor(q, 16, 64);
+    if (ok && (threadIdx.x & 31) == 0)
+        *reinterpret_cast<f32x2_t*>(a.row_stats_out + ((size_t)(nb / LN_SLOT_COLS) * a.M + m) * 2) = f32x2_t{s, q};
 }
 
 // second launch of a split-K GEMM: sum the K-slices of every sliced tile in slice order (deterministic) and apply the
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     const float* base = a.partial + (size_t)blockIdx.x * a.ksplit * (BMv * BNv);
     constexpr int QN = BNv / 4;
     constexpr int PER = BMv * QN / SPLITK_RED_Y;                      // quads per workgroup (grid.y chunks of a tile)
-    static_assert(PER % 64 == 0 && QN % 16 == 0, "whole waves per iteration, 16-lane groups inside one 64-column slot");
+    static_assert(PER % 64 == 0 && QN % 32 == 0, "whole waves per iteration, 32-lane halves inside one 128-column slot");
     for (int q = blockIdx.y * PER + threadIdx.x; q < (blockIdx.y + 1) * PER; q += 256) {
         const int lm = q / QN, lq = q - lm * QN;
         const int m = m0 + lm, nb = n0 + lq * 4;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
             if constexpr ((FX & FX_LN) != 0) ln_row_stats(a, m, fx);
             store_quad<EPI, FX>(a, m, nb, v, fx, qi);
         }
-        if constexpr ((FX & FX_STATS) != 0) emit_row_stats16(a, m, nb, ok, fx);
+        if constexpr ((FX & FX_STATS) != 0) emit_row_stats32(a, m, nb, ok, fx);
     }
 }
 

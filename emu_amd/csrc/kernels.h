@@ -56,7 +56,7 @@ struct GemmArgs {
                             // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
     // ---- fused LayerNorm (UNet transformer blocks: removes the LayerNorm launch between two GEMMs)
     // Producer side: besides C, emit per-row partial (sum, sum of squares) of the bf16-rounded outputs, one pair per
-    // 64-column slot: row_stats_out[(slot * M + m) * 2 + {0, 1}], slot = n / 64 (N % 64 == 0; EPI_NONE / EPI_RESID).
+    // 128-column slot: row_stats_out[(slot * M + m) * 2 + {0, 1}], slot = n / 128 (N % 128 == 0; EPI_NONE / EPI_RESID).
     float* row_stats_out = nullptr;
     // Consumer side: A holds the UN-normalised rows x [M, K], W holds W * gamma (bf16), and the epilogue computes
     //   out[m, n] = rstd_m * (acc[m, n] - mean_m * ln_c[n]) + ln_d[n]

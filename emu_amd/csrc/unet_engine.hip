@@ -140,7 +140,7 @@ struct Ws {
     bf16_t *colin, *hA, *hB, *cat, *gn, *t1, *sc, *tokA, *tokB, *ln, *qkv, *vt, *att, *q2, *ff;
     bf16_t* skip[12];
     bf16_t *temb_in, *e1, *emb, *semb, *temb_all, *add1;
-    float* lnstats;         // per-row partial (sum, sum of squares) of the transformer stream, one pair per 64-column slot
+    float* lnstats;         // per-row partial (sum, sum of squares) of the transformer stream, one pair per 128-column slot
     float* gnws;
     float* splitk;          // fp32 K-slices of the split-K GEMMs / convs of the lowest-resolution level
     size_t splitk_floats;
@@ -165,7 +165,7 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
             max_qkv = std::max(max_qkv, Bn * hw[i] * 3 * c.ch[i]);
             max_ff = std::max(max_ff, Bn * hw[i] * 4 * c.ch[i]);
             max_vt = std::max(max_vt, (size_t)Bn * c.ch[i] * ((hw[i] + 63) / 64 * 64));
-            max_st = std::max(max_st, (size_t)Bn * hw[i] * (c.ch[i] / 64) * 2);
+            max_st = std::max(max_st, (size_t)Bn * hw[i] * ((c.ch[i] + 127) / 128) * 2);
         }
     }
     // a downsampled/upsampled tensor is written at the next level's size with the previous level's channels
@@ -219,7 +219,7 @@ int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, con
         g.row_stats_out = fx->stats_out;
         if (fx->ln) {
             g.W = fx->ln->w; g.bias = nullptr;
-            g.ln_c = fx->ln->c; g.ln_d = fx->ln->d; g.ln_stats = fx->stats_in; g.ln_slots = K / 64; g.ln_eps = 1e-5f;
+            g.ln_c = fx->ln->c; g.ln_d = fx->ln->d; g.ln_stats = fx->stats_in; g.ln_slots = K / 128; g.ln_eps = 1e-5f;
         }
         g.vt_out = fx->vt; g.vt_col0 = fx->vt_col0; g.vt_s = fx->vt_s; g.vt_spad = fx->vt_spad;
     }
@@ -260,7 +260,7 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     // stream (proj_in, attn1 / attn2 out-projection, ff-out) emits per-row partial sums from its epilogue, the consumer (qkv,
     // attn2 q, GEGLU) multiplies the un-normalised rows by W * gamma and corrects with mean / rstd in its epilogue -- and the qkv
     // projection writes V^T itself.  M <= 8 (toy latents) stays on the unfused GEMV path.
-    const bool fln = (u->fusion & 1) && M > 8 && (C & 63) == 0;
+    const bool fln = (u->fusion & 1) && M > 8 && (C & 127) == 0;     // statistics slots are 128 columns wide
     const bool fvt = (u->fusion & 2) && M > 8 && HW == hwpad;
     float* st = w.lnstats;
     UTRY(launch_groupnorm(x, t.gng, t.gnb, w.gn, w.gnws, Bn, HW, C, u->cfg.groups, 1e-6f, 0, s));

@@ -62,8 +62,8 @@ def linear(x, w, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = 
 
 def linear_fused(x, w, bias=None, res=None, epi: int = EPI_NONE, out=None, stats_out=None, ln=None, vt=None):
     """emu_linear_fused_bf16: ``linear`` (M > 8) with the fused epilogues of the UNet transformer blocks.
-    ``stats_out`` fp32 [N/64, M, 2]: per-row partial (sum, sum of squares) of the output per 64-column slot.
-    ``ln`` = (c fp32 [N], d fp32 [N], stats fp32 [K/64, M, 2], eps): x is the un-normalised activation, w = W * gamma.
+    ``stats_out`` fp32 [N/128, M, 2]: per-row partial (sum, sum of squares) of the output per 128-column slot.
+    ``ln`` = (c fp32 [N], d fp32 [N], stats fp32 [K/128, M, 2], eps): x is the un-normalised activation, w = W * gamma.
     ``vt`` = (vt_out bf16 [B, N - col0, S_pad], col0, S): columns >= col0 are stored key-contiguous instead of row-major."""
     import ctypes as C
     from ._lib import LinearFxC
@@ -75,7 +75,7 @@ def linear_fused(x, w, bias=None, res=None, epi: int = EPI_NONE, out=None, stats
         out = torch.empty(M, n_out, device=x.device, dtype=BF16)
     fx = LinearFxC()
     if stats_out is not None:
-        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() == (N // 64) * M * 2
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() == (N // 128) * M * 2
         fx.row_stats_out = stats_out.data_ptr()
     if ln is not None:
         c, d, stats, eps = ln

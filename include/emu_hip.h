@@ -101,10 +101,10 @@ int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, con
  * diffusers' BasicTransformerBlock computes as LayerNorm -> Linear (norm1/2/3 ahead of attn1.to_q/k/v, attn2.to_q,
  * ff.net.0.proj; Emu2/emu/diffusion.py:136-141), without a LayerNorm launch in between:
  *   row_stats_out  producer side: besides C, per-row partial (sum, sum of squares) of the bf16 outputs, one fp32 pair per
- *                  64-column slot: row_stats_out[(slot * M + m) * 2 + {0,1}], slot = n / 64   (N % 64 == 0)
+ *                  128-column slot: row_stats_out[(slot * M + m) * 2 + {0,1}], slot = n / 128   (N % 128 == 0)
  *   ln_c/ln_d/ln_stats/ln_slots/ln_eps  consumer side: A is the UN-normalised activation, W = W0 * gamma, and
  *                  C[m,n] = epi(bf16(rstd_m * (sum_k A[m,k] W[n,k] - mean_m * ln_c[n]) + ln_d[n])) with mean / rstd of row m
- *                  from its ln_slots partial pairs, ln_c[n] = sum_k W[n,k], ln_d[n] = sum_k W0[n,k] beta[k] + bias[n]
+ *                  from its ln_slots (= K / 128 <= 10) partial pairs, ln_c[n] = sum_k W[n,k], ln_d[n] = sum_k W0[n,k] beta[k] + bias[n]
  *   vt_out/vt_col0/vt_s/vt_spad  output columns n >= vt_col0 (the V heads of a fused qkv projection) are stored
  *                  key-contiguous, vt_out[(b * (N - vt_col0) + n - vt_col0) * vt_spad + s] for row m = b * vt_s + s,
  *                  instead of row-major (what the attention kernel's P.V MFMA reads; replaces a transpose launch)

@@ -1,7 +1,7 @@
 """The fused epilogues of the UNet transformer GEMMs (emu_linear_fused_bf16 / GemmArgs::row_stats_out, ln_*, vt_*), which
 replace the LayerNorm and V-transpose launches of diffusers' BasicTransformerBlock (norm1/2/3 -> Linear, attn1 V):
 
-  * producer side: per-row (sum, sum of squares) of the bf16 outputs per 64-column slot, from every tile configuration's
+  * producer side: per-row (sum, sum of squares) of the bf16 outputs per 128-column slot, from every tile configuration's
     epilogue and from both K-slice reduce kernels -- compared with torch sums of the kernel's own output, and the output
     itself must be BIT-identical to the plain launch of the same configuration;
   * consumer side: LayerNorm folded into the GEMM (W * gamma, mean / rstd correction in the epilogue) -- against
@@ -40,14 +40,14 @@ def rel(got, want):
 
 
 def slot_stats(y):
-    """[N/64, M, 2] fp32: (sum, sum of squares) of every 64-column slot of every row of the bf16 tensor y."""
+    """[N/128, M, 2] fp32: (sum, sum of squares) of every 128-column slot of every row of the bf16 tensor y."""
     M, N = y.shape
-    v = y.float().view(M, N // 64, 64)
+    v = y.float().view(M, N // 128, 128)
     return torch.stack((v.sum(-1), (v * v).sum(-1)), dim=-1).permute(1, 0, 2).contiguous()
 
 
 # (M, N, K): attn out / to_q at 32^2, ff-out (K-sliced), proj at 64^2, ff-out at 64^2, a toy latent
-PRODUCER_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (8192, 640, 640), (8192, 640, 2560), (128, 1280, 1280), (512, 320, 320)]
+PRODUCER_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (8192, 640, 640), (8192, 640, 2560), (128, 1280, 1280), (512, 384, 320)]
 
 
 @pytest.mark.parametrize("M,N,K", PRODUCER_SHAPES)
@@ -59,7 +59,7 @@ def test_row_stats_from_every_epilogue(force, M, N, K, epi):
     for c in CFGS:
         force(c)
         plain = ops.linear(x, w, bias=bias, res=res, epi=epi)
-        st = torch.full((N // 64, M, 2), float("nan"), device="cuda", dtype=torch.float32)
+        st = torch.full((N // 128, M, 2), float("nan"), device="cuda", dtype=torch.float32)
         out = ops.linear_fused(x, w, bias=bias, res=res, epi=epi, stats_out=st)
         torch.cuda.synchronize()
         assert torch.equal(out, plain), f"cfg {c}: output changed by the statistics epilogue"
@@ -72,7 +72,7 @@ def test_row_stats_from_every_epilogue(force, M, N, K, epi):
 
 # (M, N, K, epi): qkv / to_q / GEGLU at 32^2 and 64^2, toy latents
 CONSUMER_SHAPES = [(2048, 3840, 1280, 0), (2048, 1280, 1280, 0), (2048, 10240, 1280, 5), (8192, 1920, 640, 0), (8192, 5120, 640, 5),
-                   (128, 3840, 1280, 0), (512, 2560, 320, 5)]
+                   (128, 3840, 1280, 0), (512, 2560, 384, 5)]
 
 
 def fold(w, gamma, beta, bias):
@@ -137,7 +137,7 @@ def test_producer_consumer_chain_equals_unfused_sequence(force, M, C):
     wg, bg = rnd(8 * C, C, seed=26, scale=C ** -0.5), rnd(8 * C, seed=27, scale=0.1)
     wln, c, d = fold(wg, gamma, beta, bg)
     force("0")
-    st = torch.zeros(C // 64, M, 2, device="cuda", dtype=torch.float32)
+    st = torch.zeros(C // 128, M, 2, device="cuda", dtype=torch.float32)
     h = ops.linear_fused(att, wo, bias=bo, res=res, epi=1, stats_out=st)
     fused = ops.linear_fused(h, wln, epi=5, ln=(c, d, st, eps))
     h2 = ops.linear(att, wo, bias=bo, res=res, epi=1)

@@ -82,7 +82,7 @@ def test_conv3x3_split_k(splitk_scratch):
     the time-embedding bias and the residual applied once, after the reduction."""
     from emu_amd import ops
     from emu_amd._lib import lib
-    B, Cin, Cout, H, W = 2, 256, 1280, 32, 32                            # K = 2304 -> 36 K-tiles -> 2 slices
+    B, Cin, Cout, H, W = 2, 384, 1280, 32, 32                            # K = 3456 -> 54 K-tiles -> 2 slices of 27
     x, w = rnd(B, Cin, H, W, seed=31), rnd(Cout, Cin, 3, 3, seed=32, scale=0.03)
     bias, temb, res = rnd(Cout, seed=33), rnd(B, Cout, seed=34), rnd(B, Cout, H, W, seed=35)
     xs, ws = x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda()
