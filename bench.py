@@ -193,6 +193,7 @@ def _reference_layer_time(W32, dtype, cfg, ctx_len, k0, v0, x0, seconds):
     return tot / n, n
 
 
+VIT_FLOPS_PER_IMAGE = 9.39e12       # BASELINE.md section 2 / SURVEY 8d: EVA-CLIP 64 blocks x 1025 tokens x 1792
 UNET_FLOPS_PER_STEP = 13.48e12      # one denoise step (CFG batch 2) at 128x128 latents, 64 ctx tokens
 
 
@@ -637,6 +638,14 @@ def main():
                          "measured": f"HIP events on the launch stream around each GEMV, eager replay of {n_prof} decode steps",
                          "token_level_frac": (lm.weight_bytes_per_token() + kv_bytes) * tok_s / HBM_PEAK},
             "extra": {"vit_encode_ms": min(vit_ms, vit_ms2), "prefill_ms": min(prefill_ms, prefill_ms2),
+                      "prefill_roofline": {"bound": "mfma", "achieved": prefill_flops / world / (min(prefill_ms, prefill_ms2) * 1e-3) / 1e12,
+                                           "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                                           "frac": prefill_flops / world / (min(prefill_ms, prefill_ms2) * 1e-3) / MFMA_BF16_PEAK,
+                                           "flops": prefill_flops / world, "traffic": None},
+                      "vit_roofline": {"bound": "mfma", "achieved": VIT_FLOPS_PER_IMAGE / (min(vit_ms, vit_ms2) * 1e-3) / 1e12,
+                                       "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                                       "frac": VIT_FLOPS_PER_IMAGE / (min(vit_ms, vit_ms2) * 1e-3) / MFMA_BF16_PEAK,
+                                       "flops": VIT_FLOPS_PER_IMAGE, "traffic": None},
                       "prefill_tflops": prefill_flops / world / (min(prefill_ms, prefill_ms2) * 1e-3) / 1e12,
                       "prefill_mfma_frac": prefill_flops / world / (min(prefill_ms, prefill_ms2) * 1e-3) / MFMA_BF16_PEAK,
                       "weight_bytes_per_token_per_gpu": lm.weight_bytes_per_token(), "kv_bytes_per_token_per_gpu": kv_bytes,

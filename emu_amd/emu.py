@@ -136,10 +136,33 @@ class EmuModel:
     @torch.no_grad()
     def encode_image(self, image: torch.Tensor, *, n_query=None):
         n_query = n_query if n_query is not None else self.n_query
-        tokens = self.visual(image)                                   # [B, 1+g*g, C]
         g = self.vision_cfg.grid
         stride = int(g // (n_query ** 0.5))
-        return ops.avgpool_tokens(tokens, g, stride)                  # [B, n_query, C]
+
+        def enc(img):
+            return ops.avgpool_tokens(self.visual(img), g, stride)    # [k, 1+g*g, C] -> [k, n_query, C]
+        # tensor-parallel ranks split the IMAGES of a prompt between them (the ViT is replicated) and all-gather the pooled tokens
+        if self.ctx.tp_size > 1 and image.shape[0] >= 2 and self._image_parallel_ok():
+            from .tp import image_parallel_encode
+            return image_parallel_encode(image, enc, self.ctx.tp_rank, self.ctx.tp_size, self._all_gather)
+        return enc(image)
+
+    def _image_parallel_ok(self) -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.ctx.tp_size
+
+    @staticmethod
+    def _all_gather(t: torch.Tensor):
+        """torch.distributed.all_gather of a device tensor: RCCL over xGMI; under a gloo group (ranks sharing one GPU in the
+        validation runs) the exchange goes through the host."""
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo":
+            parts = [torch.empty_like(t, device="cpu") for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, t.cpu())
+            return [p.to(t.device) for p in parts]
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        return parts
 
     def _project(self, x2d: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
         return ops.linear(x2d.contiguous(), w)

@@ -60,3 +60,45 @@ def test_tp2_gloo_layer_matches_unsharded():
     [p.join(60) for p in procs]
     assert sorted(r for r, _ in res) == [0, 1]
     assert all(err < 1e-4 for _, err in res), res
+
+
+def _img_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_amd.tp import image_parallel_encode
+        g = torch.Generator().manual_seed(9)
+        res = {}
+        for n in (1, 2, 3, 4, 5):
+            imgs = torch.randn(n, 3, 8, 8, generator=g)
+            calls = []
+
+            def enc(x):                                              # stand-in for ViT + pooling: a fixed map per image
+                calls.append(x.shape[0])
+                return torch.stack([x[i].reshape(-1)[:12].reshape(4, 3) * 2.0 + 1.0 for i in range(x.shape[0])])
+
+            def gather(t):
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                return parts
+            out = image_parallel_encode(imgs, enc, rank, world, gather)
+            want = torch.stack([imgs[i].reshape(-1)[:12].reshape(4, 3) * 2.0 + 1.0 for i in range(n)])
+            res[n] = (bool(torch.equal(out, want)), calls[0])
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_vit_image_parallel_over_two_ranks():
+    """BASELINE configs[2] (several images per prompt) under tensor parallelism: every rank encodes ceil(n / world) images and
+    the all-gather restores the tokens of all n images, in order, on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_img_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in procs]
+    [p.join(60) for p in procs]
+    for rank, r in res:
+        assert all(ok for ok, _ in r.values()), (rank, r)
+        assert {n: k for n, (_, k) in r.items()} == {1: 1, 2: 1, 3: 2, 4: 2, 5: 3}, r       # images encoded per rank
