@@ -17,30 +17,34 @@ constexpr int GN_MAXCHUNK = 32;     // pixel chunks per batch element in the sta
 __host__ __device__ inline int gn_row_groups(int C) { const int nv = C >> 3; return nv >= 256 ? 1 : 256 / nv; }
 __host__ __device__ inline int gn_rows_per_block(int C) { return GN_DEPTH * gn_row_groups(C); }
 
-// Pass 1 of 2: per (batch, pixel chunk) the fp32 (sum, sum of squares) of every GROUP: ws[((b * nchunk + chunk) * G + g) * 2].
-// Channel sums of the chunk meet in LDS and are folded to groups in a fixed order (deterministic).  One launch of the former
-// three (per-channel partials / finalize / apply) is gone: the apply pass derives mean / rstd itself from these few floats.
+// Pass 1 of 2: per (batch, pixel chunk, channel slice) the fp32 (sum, sum of squares) of every GROUP of the slice:
+// ws[((b * nchunk + chunk) * G + g) * 2].  The channel axis is cut into gridDim.z slices of whole groups so that even the small
+// maps (32 chunks x 2 batch rows) put >= 256 workgroups on the chip.  Channel sums of the chunk meet in LDS and are folded to
+// groups in a fixed order (deterministic).  One launch of the former three (per-channel partials / finalize / apply) is gone:
+// the apply pass derives mean / rstd itself from these few floats.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ ws, int HW, int C, int G,
                                                        int rows) {
-    __shared__ float csum[2 * GN_MAXC];               // per-channel (sum | sum of squares) of this chunk
+    __shared__ float csum[2 * GN_MAXC];               // per-channel (sum | sum of squares) of this chunk and slice
     __shared__ float part[256 * 16];                  // row groups side by side (narrow rows)
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int nv = C >> 3;
-    const int RG = gn_row_groups(C);
+    const int Cs = C / gridDim.z, c0 = blockIdx.z * Cs, Gs = G / gridDim.z;
+    const int nv = Cs >> 3;
+    const int RG = gn_row_groups(Cs);
     const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
     const int tid = threadIdx.x;
+    const bf16_t* xs = x + (size_t)b * HW * C + c0;
     if (RG == 1) {                                   // wide rows: one thread per channel vector (loop when nv > 256)
         for (int vi = tid; vi < nv; vi += 256) {
             float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
             for (int r = r0; r < r1; ++r) {
                 float f[8];
-                unpack8(ld16(x + ((size_t)b * HW + r) * C + vi * 8), f);
+                unpack8(ld16(xs + (size_t)r * C + vi * 8), f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { csum[vi * 8 + e] = s[e]; csum[C + vi * 8 + e] = q[e]; }
+            for (int e = 0; e < 8; ++e) { csum[vi * 8 + e] = s[e]; csum[Cs + vi * 8 + e] = q[e]; }
         }
     } else {
         const int tr = tid / nv, vi = tid - tr * nv;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll 4
             for (int r = r0 + tr; r < r1; r += RG) {
                 float f[8];
-                unpack8(ld16(x + ((size_t)b * HW + r) * C + vi * 8), f);
+                unpack8(ld16(xs + (size_t)r * C + vi * 8), f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
@@ -63,28 +67,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                 float ts = 0.f, tq = 0.f;
                 for (int g = 0; g < RG; ++g) { ts += part[(g * nv + tid) * 16 + e]; tq += part[(g * nv + tid) * 16 + 8 + e]; }
                 csum[tid * 8 + e] = ts;
-                csum[C + tid * 8 + e] = tq;
+                csum[Cs + tid * 8 + e] = tq;
             }
         }
     }
     __syncthreads();
-    if (tid < G) {
+    if (tid < Gs) {
         const int cg = C / G;
         float ts = 0.f, tq = 0.f;
-        for (int i = 0; i < cg; ++i) { ts += csum[tid * cg + i]; tq += csum[C + tid * cg + i]; }
-        float* out = ws + ((size_t)(b * nchunk + chunk) * G + tid) * 2;
+        for (int i = 0; i < cg; ++i) { ts += csum[tid * cg + i]; tq += csum[Cs + tid * cg + i]; }
+        float* out = ws + ((size_t)(b * nchunk + chunk) * G + blockIdx.z * Gs + tid) * 2;
         out[0] = ts; out[1] = tq;
     }
 }
 
 // Pass 2 of 2: every workgroup first folds the chunk partials of its batch into (mean, rstd) per group (double accumulation,
-// fixed order; a few KB from L2), then applies y = x * (gamma * rstd) + (beta - mean * gamma * rstd) (+ SiLU) over its rows.
+// fixed order; a few KB from L2) and from them the per-channel scale / shift table y = x * A[c] + B[c] in LDS, then applies it
+// (+ SiLU) over its rows.
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ws,
                                                        const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                                        bf16_t* __restrict__ y, int HW, int C, int G, int nchunk, float eps) {
     __shared__ double red[2][8][GN_MAXG];
     __shared__ float stat[2][GN_MAXG];                 // mean | rstd per group
+    __shared__ __attribute__((aligned(16))) float ab[2][GN_MAXC];     // scale | shift per channel
     const int b = blockIdx.y, tid = threadIdx.x;
     {   // at most GN_MAXCHUNK chunks x GN_MAXG groups: thread (slice, g) fetches its 4 chunk pairs in ONE batch of loads (indices
         // clamped, no branch around a load) and sums them; the 8 slices meet in LDS in a fixed order
@@ -117,24 +123,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
             stat[1][tid] = (float)(1.0 / sqrt(var + (double)eps));
         }
         __syncthreads();
+        const int cg = C / G;
+        for (int c = tid; c < C; c += 256) {
+            const int gi = c / cg;
+            const float A = bf2f(gamma[c]) * stat[1][gi];
+            ab[0][c] = A;
+            ab[1][c] = bf2f(beta[c]) - stat[0][gi] * A;
+        }
+        __syncthreads();
     }
-    const int nv = C >> 3, cg = C / G;
+    const int nv = C >> 3;
     const size_t total = (size_t)HW * nv;
     const bf16_t* xb = x + (size_t)b * HW * C;
     bf16_t* yb = y + (size_t)b * HW * C;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / nv;
         const int vi = (int)(i - row * nv);
-        float f[8], ga[8], be[8];
+        float f[8];
         unpack8(ld16(xb + row * C + vi * 8), f);
-        unpack8(ld16(gamma + vi * 8), ga);
-        unpack8(ld16(beta + vi * 8), be);
-        const int c0 = vi * 8, g0 = c0 / cg, left = (g0 + 1) * cg - c0;      // channels of this vector still inside group g0
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(&ab[0][vi * 8]), a1 = *reinterpret_cast<const f32x4_t*>(&ab[0][vi * 8 + 4]);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(&ab[1][vi * 8]), b1 = *reinterpret_cast<const f32x4_t*>(&ab[1][vi * 8 + 4]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = cg >= 8 ? g0 + (e >= left ? 1 : 0) : (c0 + e) / cg;    // groups of >= 8 channels: at most one boundary
-            const float A = ga[e] * stat[1][g];
-            float v = f[e] * A + (be[e] - stat[0][g] * A);
+            float v = f[e] * (e < 4 ? a0[e & 3] : a1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
             if (SILU) v = silu(bfround(v));               // GroupNorm output is a bf16 tensor before F.silu
             f[e] = v;
         }
@@ -221,12 +232,15 @@ int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, b
     if (B < 1 || HW < 1 || (C & 7) || C % groups || groups > GN_MAXG || C > GN_MAXC) return -22;
     // GN_MAXCHUNK chunks of whole thread-layout passes per batch element (fewer for small maps): the apply pass folds exactly
     // one batch of loads per thread
-    const int unit = gn_rows_per_block(C);
+    // channel slices of whole groups and whole 16-byte vectors (4, 2 or 1): more workgroups for the statistics pass
+    int cs = 4;
+    while (cs > 1 && (groups % cs || ((C / cs) & 7) || C / cs < 64)) cs >>= 1;
+    const int unit = gn_rows_per_block(C / cs);
     int nchunk = (HW + unit - 1) / unit;
     if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
     const int rows = (HW + nchunk - 1) / nchunk;
     nchunk = (HW + rows - 1) / rows;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ws, HW, C, groups, rows);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B, cs), dim3(256), 0, s, x, ws, HW, C, groups, rows);
     const size_t total = (size_t)HW * (C >> 3);
     const int grid = (int)min((size_t)4096, (total + 255) / 256);
     if (do_silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(grid, B), dim3(256), 0, s, x, ws, gamma, beta, y, HW, C, groups, nchunk, eps);
