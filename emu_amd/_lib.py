@@ -64,6 +64,7 @@ _PROTOS = {
     "emu_linear_fused_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(LinearFxC), vp]),
     "emu_set_splitk_scratch": (None, [vp, sz]),
     "emu_gemm_force_config": (None, [i32]),
+    "emu_gemm_tune": (None, [i32]),
     "emu_quantize_fp8_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, vp]),
     "emu_linear_fp8w_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_linear_fp8_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -78,6 +78,7 @@ int emu_version(void) { return 1; }
 
 void emu_set_splitk_scratch(void* ptr, size_t bytes) { emu_gemm_set_splitk_scratch(reinterpret_cast<float*>(ptr), bytes / sizeof(float)); }
 void emu_gemm_force_config(int cfg) { emu_gemm_force_config_set(cfg); }
+void emu_gemm_tune(int mask) { emu_gemm_tune_set(mask); }
 
 int emu_profile_gemv(int enable) {
     g_prof.on = enable != 0;

@@ -332,6 +332,7 @@ using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves
 float* g_splitk_scratch = nullptr;
 size_t g_splitk_floats = 0;
 int g_force_cfg = 0;                     // emu_gemm_force_config: tests / benches pin one tile configuration
+int g_tune = 0;                          // emu_gemm_tune: A/B switches of single dispatch decisions (tools/unet_ab.py)
 
 // full_tiles whole-K workgroups followed by (tiles - full_tiles) * ksplit slice workgroups, one launch (+ the reduce)
 template <int EPI, bool CONV, class T>
@@ -455,7 +456,10 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
     if (cfg == 'S' && !k64) cfg = 0;
     if ((cfg == 'P' || cfg == 'Q') && !gemm256_ok(a)) cfg = 0;
     if (!cfg || cfg == 'H') {
-        const int n1 = CONV ? 0 : plan_hybrid(a, cfg == 'H');
+        int n1 = CONV ? 0 : plan_hybrid(a, cfg == 'H');
+        // A/B switch 1: a GLU problem the hybrid would split in two launches runs as ONE launch of 128 x 128 tiles instead
+        constexpr bool GLU_EPI = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
+        if (GLU_EPI && n1 > 0 && !cfg && (g_tune & 1) && tiles_of(a, 128, 128) >= 1024) { n1 = 0; cfg = 'B'; }
         if (n1 > 0) {
             constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
             GemmArgs head = a, rest = a;
@@ -476,7 +480,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
             g_force_cfg = keep;
             return st;
         }
-        cfg = 0;
+        if (cfg == 'H') cfg = 0;
     }
     if (!cfg) {
         const PpPlan pp = pick_pp(a);
@@ -527,6 +531,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
 
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
 void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; }
+void emu_gemm_tune_set(int mask) { g_tune = mask; }
 
 int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;

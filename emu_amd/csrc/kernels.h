@@ -88,6 +88,8 @@ constexpr size_t EMU_SPLITK_SCRATCH_FLOATS = (size_t)512 * 288 * 256;
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
 // test / bench hook: pin the tile configuration ('B', 'C', 'K', 'S', 'P'; 0 = heuristic)
 void emu_gemm_force_config_set(int cfg);
+// A/B switches of single dispatch decisions (bit 0: GLU GEMMs the hybrid would split run as one launch of 128 x 128 tiles)
+void emu_gemm_tune_set(int mask);
 
 // ---- row-wise / elementwise (elementwise.hip)
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);

@@ -66,6 +66,9 @@ void emu_set_splitk_scratch(void* ptr, size_t bytes);
  * GEMM (where the tile count allows, else the heuristic).  The parity tests walk every configuration over the
  * bench's true shapes with it (tests/test_gpu_ops.py); production code never calls it. */
 void emu_gemm_force_config(int cfg);
+/* Bench hook: A/B switches of single dispatch decisions (0 = the shipped heuristic).  Bit 0: GLU GEMMs that the heuristic
+ * splits into whole rounds of the 256x256 tile + a remainder GEMM run as ONE launch of 128x128 tiles. */
+void emu_gemm_tune(int mask);
 
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while
  * enabled (eager launches only, not inside stream capture).  read: sum of launch durations (ms), algorithmic

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Same-run A/B of the UNet denoise step under different launch-fusion masks (emu_unet_set_fusion): one engine, one set of
 weights, the variants alternated inside one process (box-to-box variance of the MFMA-bound legs is ~12 %, so only same-run
-comparisons are evidence).  Usage: python tools/unet_ab.py [steps] [mask,mask,...] [rounds]"""
+comparisons are evidence).  A variant is a fusion mask, optionally followed by "t<N>" = emu_gemm_tune(N) (e.g. "3t1").
+Usage: python tools/unet_ab.py [steps] [variant,variant,...] [rounds]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +11,7 @@ from emu_amd.llama import EmuHipContext
 from emu_amd.unet import UNetCfg, UNetEngine, unet_param_shapes
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-masks = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 3]
+masks = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "3"]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda", 0)
 eng = UNetEngine(UNetCfg(), EmuHipContext(dev))
@@ -22,7 +23,10 @@ best = {}
 with torch.no_grad():
     for r in range(rounds):
         for m in masks:
-            got = eng.set_fusion(m)
+            fm, _, tn = m.partition("t")
+            from emu_amd._lib import lib
+            lib().emu_gemm_tune(int(tn or 0))
+            got = eng.set_fusion(int(fm))
             eng.set_timesteps(50)
             eng.set_context(prompt, 1024, 1024)
             lat = lat0.clone()
