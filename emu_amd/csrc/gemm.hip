@@ -342,24 +342,29 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
-    constexpr bool CAN_ILV = !CONV && (EPI == EPI_NONE || EPI == EPI_RESID || EPI == EPI_GEGLU);   // schedule experiment
+    // ILV (LDS-DMA issued behind the MFMAs of each k-step): forced by a lower-case configuration letter, or for every launch of
+    // the lock-step tiles by emu_gemm_tune bit 1 (in-situ A/B)
+    constexpr bool CAN_ILV = EPI == EPI_NONE || EPI == EPI_RESID || EPI == EPI_GEGLU;
+    const bool use_ilv = CAN_ILV && (ilv || (g_tune & 2));
     const int fx = gemm_fx(b);
-    if (CAN_ILV && ilv && !fx) {
-        if constexpr (CAN_ILV) {
-            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, 0, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
-            if (tail > 0)
-                hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
-        }
-        return;
-    }
+    const dim3 grid(b.full_tiles + tail * ksplit), block(T::THREADS);
     if (fx) {                                           // launch_gemm has checked gemm_fx_ok(epi, fx)
         if constexpr (!CONV) {
             gemm_fx_dispatch<EPI>(fx, [&](auto m) {
                 constexpr int FXM = decltype(m)::value;
-                hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+                if (use_ilv) hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM, true>), grid, block, 0, s, b);
+                else hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), grid, block, 0, s, b);
                 if (tail > 0)
                     hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv, FXM>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
             });
+        }
+        return;
+    }
+    if (use_ilv) {
+        if constexpr (CAN_ILV) {
+            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, 0, true>), grid, block, 0, s, b);
+            if (tail > 0)
+                hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
         }
         return;
     }

@@ -10,7 +10,7 @@ namespace {
 constexpr int GN_DEPTH = 16;         // pixel rows each thread walks serially in the statistics pass
 constexpr int GN_MAXC = 2560;        // widest activation of the SDXL topology (first resnet of the up path: 1280 + 1280)
 constexpr int GN_MAXG = 32;         // groups (the reference: norm_num_groups 32)
-constexpr int GN_MAXCHUNK = 32;     // pixel chunks per batch element in the statistics pass
+constexpr int GN_MAXCHUNK = 256;    // pixel chunks per batch element in the statistics pass (32 per fold batch of the apply pass)
 
 // How the 256 threads of a statistics workgroup are laid out for C channels: nv 16-byte channel vectors per pixel row,
 // RG row groups side by side (all 256 threads busy for C = 320 as well as 1280), GN_DEPTH rows per thread.
@@ -92,22 +92,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     __shared__ float stat[2][GN_MAXG];                 // mean | rstd per group
     __shared__ __attribute__((aligned(16))) float ab[2][GN_MAXC];     // scale | shift per channel
     const int b = blockIdx.y, tid = threadIdx.x;
-    {   // at most GN_MAXCHUNK chunks x GN_MAXG groups: thread (slice, g) fetches its 4 chunk pairs in ONE batch of loads (indices
-        // clamped, no branch around a load) and sums them; the 8 slices meet in LDS in a fixed order
+    {   // chunks x GN_MAXG groups: thread (slice, g) fetches 4 chunk pairs per batch of loads (indices clamped, no branch around a
+        // load) and sums them; the 8 slices meet in LDS in a fixed order
         const int g = tid & (GN_MAXG - 1), sl = tid >> 5;
         const float* p = ws + ((size_t)b * nchunk * G + (g < G ? g : 0)) * 2;
-        f32x2_t v[GN_MAXCHUNK / 8];
-#pragma unroll
-        for (int k = 0; k < GN_MAXCHUNK / 8; ++k) {
-            const int c = sl + 8 * k;
-            v[k] = *reinterpret_cast<const f32x2_t*>(p + (size_t)(c < nchunk ? c : 0) * G * 2);
-        }
         double sd = 0.0, qd = 0.0;
+        for (int base = 0; base < nchunk; base += 32) {      // one trip for the UNet's maps; the VAE's megapixel maps take a few
+            f32x2_t v[4];
 #pragma unroll
-        for (int k = 0; k < GN_MAXCHUNK / 8; ++k) {
-            const bool in = sl + 8 * k < nchunk && g < G;
-            sd += in ? (double)v[k][0] : 0.0;
-            qd += in ? (double)v[k][1] : 0.0;
+            for (int k = 0; k < 4; ++k) {
+                const int c = base + sl + 8 * k;
+                v[k] = *reinterpret_cast<const f32x2_t*>(p + (size_t)(c < nchunk ? c : 0) * G * 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = base + sl + 8 * k < nchunk && g < G;
+                sd += in ? (double)v[k][0] : 0.0;
+                qd += in ? (double)v[k][1] : 0.0;
+            }
         }
         red[0][sl][g] = sd; red[1][sl][g] = qd;
         __syncthreads();
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void gather_step_row_kernel(const bf16_t* __re
 
 size_t gn_ws_floats(int B, int C, int HW) {
     (void)C; (void)HW;
-    return (size_t)B * GN_MAXCHUNK * GN_MAXG * 2;
+    return (size_t)B * GN_MAXCHUNK * GN_MAXG * 2;      // 128 KiB per batch element: every chunking launch_groupnorm may choose
 }
 
 int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, float* ws, int B, int HW, int C,
@@ -237,7 +239,11 @@ int launch_groupnorm(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, b
     while (cs > 1 && (groups % cs || ((C / cs) & 7) || C / cs < 64)) cs >>= 1;
     const int unit = gn_rows_per_block(C / cs);
     int nchunk = (HW + unit - 1) / unit;
-    if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
+    // 32 chunks (one fold batch in the apply pass) unless the map is so large that 32 x B x cs workgroups would each walk more
+    // than ~2 MB (the VAE's 512^2 / 1024^2 maps): then up to GN_MAXCHUNK
+    int cap = 32;
+    while (cap < GN_MAXCHUNK && (size_t)HW * (C / cs) * 2 / cap > (2u << 20)) cap <<= 1;
+    if (nchunk > cap) nchunk = cap;
     const int rows = (HW + nchunk - 1) / nchunk;
     nchunk = (HW + rows - 1) / rows;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B, cs), dim3(256), 0, s, x, ws, HW, C, groups, rows);
