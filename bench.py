@@ -207,7 +207,7 @@ def denoise_leg(ctx, dev, steps, world, dist, fusion=-1):
     cfg = UNetCfg()
     eng = UNetEngine(cfg, ctx)
     eng.load_state_dict(synth.iter_synth(unet_param_shapes(cfg), seed=0, device=dev, dtype=torch.bfloat16))
-    fusion = eng.set_fusion(3 if fusion < 0 else fusion)
+    fusion = eng.set_fusion(7 if fusion < 0 else fusion)
     g = torch.Generator().manual_seed(3)
     prompt = torch.randn(2, 64, 1792, generator=g).to(torch.bfloat16).to(dev)
     sch = eng.set_timesteps(steps)
@@ -238,7 +238,8 @@ def denoise_leg(ctx, dev, steps, world, dist, fusion=-1):
     return {"metric": "diffusion denoise steps/sec (UNet fwd CFG batch 2 + guidance + Euler step, 1024x1024, 64 ctx tokens)",
             "value": per_gpu * world, "unit": "steps/s", "per_gpu": per_gpu, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "scaling": "replicas only (independent images per GPU)", "launch": "hipGraph replay", "finite_output": finite,
-            "fusion": {"mask": fusion, "layernorm_folded_into_gemm": bool(fusion & 1), "v_transpose_in_qkv_epilogue": bool(fusion & 2)},
+            "fusion": {"mask": fusion, "layernorm_folded_into_gemm": bool(fusion & 1), "v_transpose_in_qkv_epilogue": bool(fusion & 2),
+                       "cross_attention_in_to_q_epilogue": bool(fusion & 4)},
             "roofline": {"bound": "mfma", "achieved": UNET_FLOPS_PER_STEP * per_gpu / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": UNET_FLOPS_PER_STEP * per_gpu / MFMA_BF16_PEAK,
                          "flops_per_step": UNET_FLOPS_PER_STEP}}

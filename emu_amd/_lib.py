@@ -36,7 +36,9 @@ class VitCfgC(C.Structure):
 class LinearFxC(C.Structure):
     """emu_linear_fx (include/emu_hip.h): fused epilogues of the UNet transformer GEMMs."""
     _fields_ = [("row_stats_out", vp), ("ln_c", vp), ("ln_d", vp), ("ln_stats", vp), ("ln_slots", i32), ("ln_eps", f32),
-                ("vt_out", vp), ("vt_col0", i32), ("vt_s", i32), ("vt_spad", i32)]
+                ("vt_out", vp), ("vt_col0", i32), ("vt_s", i32), ("vt_spad", i32),
+                ("cross_k", vp), ("cross_vt", vp), ("cross_ldk", i32), ("cross_n", i32), ("cross_npad", i32), ("cross_rows", i32),
+                ("cross_scale", f32)]
 
 
 class UNetCfgC(C.Structure):

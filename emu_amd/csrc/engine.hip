@@ -219,6 +219,8 @@ int emu_linear_fused_bf16(const void* A, const void* W, const void* bias, const 
         g.row_stats_out = fx->row_stats_out;
         g.ln_c = fx->ln_c; g.ln_d = fx->ln_d; g.ln_stats = fx->ln_stats; g.ln_slots = fx->ln_slots; g.ln_eps = fx->ln_eps;
         g.vt_out = B(fx->vt_out); g.vt_col0 = fx->vt_col0; g.vt_s = fx->vt_s; g.vt_spad = fx->vt_spad;
+        g.cross_k = B(fx->cross_k); g.cross_vt = B(fx->cross_vt); g.cross_ldk = fx->cross_ldk; g.cross_n = fx->cross_n;
+        g.cross_npad = fx->cross_npad; g.cross_rows = fx->cross_rows; g.cross_scale = fx->cross_scale;
     }
     return launch_gemm(g, S(s));
 }

@@ -51,9 +51,7 @@ struct TileCfg {
     __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 };
 
-// ILV: the LDS-DMA of tile kt + NSTG - 1 is issued in KSTEPS shares BEHIND the MFMAs of each k-step instead of in one block
-// ahead of them, so the DMA issue slots (60-180 cycles each) overlap matrix-pipe time instead of preceding it.
-template <int EPI, bool CONV, class T, int FX = 0, bool ILV = false>
+template <int EPI, bool CONV, class T, int FX = 0>
 __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
@@ -118,21 +116,19 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     const int nk_all = (a.K + BK - 1) / BK;
     const int kt0 = (int)((long)ks * nk_all / nsl);
     const int nk = (int)((long)(ks + 1) * nk_all / nsl) - kt0;
-    auto issue = [&](int kt, int stage, int part = 0, int nparts = 1) {
-        auto mine = [&](int idx) { return nparts == 1 || (idx % nparts) == part; };      // share `part` of the tile's pieces
+    auto issue = [&](int kt, int stage) {
         kt = kt < nk ? kt : nk - 1;                    // past-the-end tiles re-load the last one (keeps vmcnt counts uniform)
         const int k0 = (kt0 + kt) * BK;
         char* base = smem + stage * T::ST_BYTES + wave * 1024;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
         if constexpr (CONV) {
 #pragma unroll
-            for (int i = 0; i < T::NLW; ++i) if (mine(i)) glds16(gW[i] + k0, base + i * NW * 1024);
+            for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
             // a 64-wide k tile lies inside one filter tap because Cin % 64 == 0
             const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int i = 0; i < T::NLA; ++i) {
-                if (!mine(T::NLW + i)) continue;
                 int yi, xi;
                 const bool ok = conv_tap(a.conv, py[i], px[i], ky, kx, yi, xi);
                 const size_t off = (((size_t)pb[i] * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin + ci0 + ck;
@@ -140,15 +136,15 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
             }
         } else if (k0 + BK <= a.K) {
 #pragma unroll
-            for (int i = 0; i < T::NLW; ++i) if (mine(i)) glds16(gW[i] + k0, base + i * NW * 1024);
+            for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
 #pragma unroll
-            for (int i = 0; i < T::NLA; ++i) if (mine(T::NLW + i)) glds16(gA[i] + k0, base + T::W_BYTES + i * NW * 1024);
+            for (int i = 0; i < T::NLA; ++i) glds16(gA[i] + k0, base + T::W_BYTES + i * NW * 1024);
         } else {                                       // ragged last k tile (K % 64 != 0): chunks beyond K read zeros
             const bool in = (k0 + ck) < a.K;
 #pragma unroll
-            for (int i = 0; i < T::NLW; ++i) if (mine(i)) glds16(in ? gW[i] + k0 : zero, base + i * NW * 1024);
+            for (int i = 0; i < T::NLW; ++i) glds16(in ? gW[i] + k0 : zero, base + i * NW * 1024);
 #pragma unroll
-            for (int i = 0; i < T::NLA; ++i) if (mine(T::NLW + i)) glds16(in ? gA[i] + k0 : zero, base + T::W_BYTES + i * NW * 1024);
+            for (int i = 0; i < T::NLA; ++i) glds16(in ? gA[i] + k0 : zero, base + T::W_BYTES + i * NW * 1024);
         }
     };
 
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<(T::NSTG - 2) * T::LPT>();          // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                  // ... and everyone's; everyone is also done reading tile kt-1
-        if constexpr (!ILV) issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
+        issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
         const char* sW = smem + (kt % T::NSTG) * T::ST_BYTES;
         const char* sA = sW + T::W_BYTES;
         // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are in flight under the MFMAs of kk
@@ -209,10 +205,6 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
                 for (int j = 0; j < T::MF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], af[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ILV) {
-                issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG, kk, KSTEPS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
     }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
@@ -248,6 +240,117 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     RowFx rowfx[T::MF];
     if constexpr ((FX & FX_LN) != 0) {
         if (ln_on) ln_rows_finish<T::MF>(a, lnraw, rowfx);
+    }
+    // ---- cross-attention epilogue (FX_CROSS, 128 x 64 tile): wave (wn, wm) holds q of ONE head (64 d = acc[0] | acc[1]) for 32
+    // queries (lane l31; d = 32 i + (r & 3) + 8 (r >> 2) + 4 hi in register r of acc[i]).  Both MFMAs of the attention take
+    // their B operand straight from accumulator registers: a k-step's 8 slots per lane hold whatever contraction indices the
+    // lane owns (registers 8 s .. 8 s + 7), and the A operand (K rows / V^T rows from the prompt cache) is gathered with the same
+    // permutation -- two 8-byte pieces per fragment -- so no lane exchange and no LDS pass is needed.
+    if constexpr ((FX & FX_CROSS) != 0 && T::MF == 1 && T::NF == 2) {
+        const int m = m0 + wm * 32 + l31;
+        const int ncol = n0 + wn * 64;                 // first column of this wave = head * 64
+        if (ncol < a.N) {                              // wave-uniform
+            // q, with the LayerNorm correction where it is folded in, rounded to bf16 as the reference's to_q output is
+            const RowFx qfx = rowfx[0];
+            bf16x8_t qf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = ncol + i * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = acc[i][0][4 * g + e];
+                    if constexpr ((FX & FX_LN) != 0) {
+                        const f32x4_t c = *reinterpret_cast<const f32x4_t*>(a.ln_c + nb);
+                        const f32x4_t d = *reinterpret_cast<const f32x4_t*>(a.ln_d + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(qfx.rstd, v[4 * g + e] - qfx.mean * c[e], d[e]);
+                    }
+                }
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    u32x4 w;
+                    w.x = packbf(v[8 * sb + 0], v[8 * sb + 1]); w.y = packbf(v[8 * sb + 2], v[8 * sb + 3]);
+                    w.z = packbf(v[8 * sb + 4], v[8 * sb + 5]); w.w = packbf(v[8 * sb + 6], v[8 * sb + 7]);
+                    qf[i][sb] = __builtin_bit_cast(bf16x8_t, w);
+                }
+            }
+            const int bidx = m0 / a.cross_rows, head = ncol >> 6;
+            // slot j of k-step (i, sb) on lane-half hi = contraction index 32 i + 16 sb + 4 hi + (j & 3) + 8 (j >> 2)
+            auto gather = [&](const bf16_t* row, int i, int sb) {
+                const bf16_t* p = row + 32 * i + 16 * sb + 4 * hi;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(p), up = *reinterpret_cast<const u32x2*>(p + 8);
+                return __builtin_bit_cast(bf16x8_t, u32x4{lo.x, lo.y, up.x, up.y});
+            };
+            // S^T[key, query] = sum_d K[key, d] q[query, d]: key = 32 kb + l31 as the A row
+            f32x16_t sacc[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                int key = 32 * kb + l31; key = key < a.cross_n ? key : a.cross_n - 1;
+                const bf16_t* krow = a.cross_k + ((size_t)bidx * a.cross_n + key) * a.cross_ldk + head * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather(krow, i, sb), qf[i][sb], sacc[kb], 0, 0, 0);
+            }
+            // softmax over the keys of this lane's query: 32 scores here, 32 on lane l ^ 32 (exp2 domain, like the flash kernel)
+            const float sc = a.cross_scale * 1.4426950408889634f;
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float v = key < a.cross_n ? sacc[kb][r] : -INFINITY;
+                    sacc[kb][r] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * sc;
+            const float nm = -mloc;
+            float psum = 0.f;
+            bf16x8_t pf[2][2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    float pv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { pv[j] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * sb + j], sc, nm)); psum += pv[j]; }
+                    u32x4 w;
+                    w.x = packbf(pv[0], pv[1]); w.y = packbf(pv[2], pv[3]); w.z = packbf(pv[4], pv[5]); w.w = packbf(pv[6], pv[7]);
+                    pf[kb][sb] = __builtin_bit_cast(bf16x8_t, w);
+                }
+            const float ltot = psum + __shfl_xor(psum, 32, 64);
+            const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+            // O^T[d, query] = sum_key V^T[d, key] P[query, key]: d = 32 db + l31 as the A row
+            const bf16_t* vbase = a.cross_vt + ((size_t)bidx * (a.N >> 6) + head) * 64 * a.cross_npad;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                f32x16_t o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+                const bf16_t* vrow = vbase + (size_t)(32 * db + l31) * a.cross_npad;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather(vrow, kb, sb), pf[kb][sb], o, 0, 0, 0);
+                if (m < a.M) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        u32x2 ov;
+                        ov.x = packbf(o[4 * g] * inv, o[4 * g + 1] * inv);
+                        ov.y = packbf(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                        *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + ncol + db * 32 + 8 * g + 4 * hi) = ov;
+                    }
+                }
+            }
+        }
+        return;
     }
     // Memory operands of the epilogue are fetched ahead of the stores (gemm_tile.h::QuadIn), one 32-column fragment i at a
     // time so the 128 x 64 tile stays inside 128 VGPRs (two workgroups per CU): the column-only operands of its 4 quads once,
@@ -336,35 +439,21 @@ int g_tune = 0;                          // emu_gemm_tune: A/B switches of singl
 
 // full_tiles whole-K workgroups followed by (tiles - full_tiles) * ksplit slice workgroups, one launch (+ the reduce)
 template <int EPI, bool CONV, class T>
-void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int ksplit = 1, bool ilv = false) {
+void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int ksplit = 1) {
     const int tiles = ((a.M + T::BMv - 1) / T::BMv) * ((a.N + T::BNv - 1) / T::BNv);
     GemmArgs b = a;
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     const int tail = tiles - b.full_tiles;
-    // ILV (LDS-DMA issued behind the MFMAs of each k-step): forced by a lower-case configuration letter, or for every launch of
-    // the lock-step tiles by emu_gemm_tune bit 1 (in-situ A/B)
-    constexpr bool CAN_ILV = EPI == EPI_NONE || EPI == EPI_RESID || EPI == EPI_GEGLU;
-    const bool use_ilv = CAN_ILV && (ilv || (g_tune & 2));
     const int fx = gemm_fx(b);
-    const dim3 grid(b.full_tiles + tail * ksplit), block(T::THREADS);
     if (fx) {                                           // launch_gemm has checked gemm_fx_ok(epi, fx)
         if constexpr (!CONV) {
             gemm_fx_dispatch<EPI>(fx, [&](auto m) {
                 constexpr int FXM = decltype(m)::value;
-                if (use_ilv) hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM, true>), grid, block, 0, s, b);
-                else hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), grid, block, 0, s, b);
+                hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
                 if (tail > 0)
                     hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv, FXM>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
             });
-        }
-        return;
-    }
-    if (use_ilv) {
-        if constexpr (CAN_ILV) {
-            hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, 0, true>), grid, block, 0, s, b);
-            if (tail > 0)
-                hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
         }
         return;
     }
@@ -456,6 +545,10 @@ template <int EPI, bool CONV>
 int launch_v2(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
+    if (a.cross_k) {                                   // the cross-attention epilogue lives on the 128 x 64 tile
+        if constexpr (EPI == EPI_NONE && !CONV) { launch_cfg<EPI, CONV, CfgK>(a, s); EMU_CHECK_LAUNCH(); return 0; }
+        return -22;
+    }
     int cfg = g_force_cfg;
     const bool k64 = (a.K & 63) == 0;
     if (cfg == 'S' && !k64) cfg = 0;
@@ -509,8 +602,6 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
         else cfg = 'K';
     }
-    const bool ilv = cfg >= 'a' && cfg <= 'z';         // lower-case letter: the interleaved-DMA variant of the same tile
-    if (ilv) cfg -= 'a' - 'A';
     switch (cfg) {
         case 'Q': return launch_gemm256(a, s, -1, 1);  // 256x256 ping-pong, never K-sliced (A/B)
         case 'P': {                                   // 256x256 ping-pong with the planned K-slices, whatever the shape
@@ -520,13 +611,13 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         case 'S': {
             const int tc = tiles_of(a, 256, 128);
             const int ksplit = tc < 256 ? pick_ksplit<EPI>(a, tc, 256 * 128, g_force_cfg ? 8 : 24) : 0;
-            if (ksplit) launch_cfg<EPI, CONV, CfgC>(a, s, 0, ksplit, ilv);
-            else launch_cfg<EPI, CONV, CfgC>(a, s, -1, 1, ilv);
+            if (ksplit) launch_cfg<EPI, CONV, CfgC>(a, s, 0, ksplit);
+            else launch_cfg<EPI, CONV, CfgC>(a, s);
             break;
         }
-        case 'C': launch_cfg<EPI, CONV, CfgC>(a, s, -1, 1, ilv); break;
-        case 'K': launch_cfg<EPI, CONV, CfgK>(a, s, -1, 1, ilv); break;
-        default:  launch_cfg<EPI, CONV, CfgB>(a, s, -1, 1, ilv); break;
+        case 'C': launch_cfg<EPI, CONV, CfgC>(a, s); break;
+        case 'K': launch_cfg<EPI, CONV, CfgK>(a, s); break;
+        default:  launch_cfg<EPI, CONV, CfgB>(a, s); break;
     }
     EMU_CHECK_LAUNCH();
     return 0;
@@ -559,6 +650,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
     if (a.vt_out && (a.epi != EPI_NONE || a.conv.mode != CONV_NONE || (a.vt_col0 & 63) || ((a.N - a.vt_col0) & 63) || a.vt_col0 < 0 ||
                      a.vt_col0 >= a.N || a.vt_s < 1 || a.M % a.vt_s || a.vt_spad < a.vt_s || (a.ldc & 3))) return -22;
+    if (a.cross_k && (!a.cross_vt || a.epi != EPI_NONE || a.conv.mode != CONV_NONE || a.bias || (a.N & 63) || (a.ldc & 3) || a.cross_n < 1 ||
+                      a.cross_n > 64 || a.cross_npad < 64 || a.cross_rows < 64 || (a.cross_rows & 63) || a.M % a.cross_rows ||
+                      (a.cross_ldk & 3) || (a.cross_npad & 3) || a.row_stats_out || a.vt_out)) return -22;
     if (a.conv.mode != CONV_NONE) {
         const ConvGeom& g = a.conv;
         if ((g.Cin & 63) || a.K != 9 * g.Cin || a.M % (g.Hout * g.Wout)) return -22;

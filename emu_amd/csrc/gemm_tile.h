@@ -45,6 +45,7 @@ __device__ __forceinline__ bool conv_tap(const ConvGeom& g, int py, int px, int 
 constexpr int FX_LN = 1;            // GemmArgs::ln_*: LayerNorm of A folded into this GEMM
 constexpr int FX_STATS = 2;         // GemmArgs::row_stats_out: emit per-row partial sums of C
 constexpr int FX_VT = 4;            // GemmArgs::vt_out: V heads stored key-contiguous
+constexpr int FX_CROSS = 8;         // GemmArgs::cross_*: cross-attention over <= 64 cached keys in the epilogue (128 x 64 tile)
 
 struct RowFx {
     float mean = 0.f, rstd = 1.f;
@@ -276,9 +277,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 // the feature mask of a launch (host side: picks the FX instantiation), and the (epilogue, mask) pairs that are instantiated:
 // what the UNet transformer blocks launch -- proj_in / to_q producers and consumers, the qkv projection (+ V^T), the residual
 // out-projections and ff-out as producers, the GEGLU projection as a consumer
-inline int gemm_fx(const GemmArgs& a) { return (a.ln_c ? FX_LN : 0) | (a.row_stats_out ? FX_STATS : 0) | (a.vt_out ? FX_VT : 0); }
+inline int gemm_fx(const GemmArgs& a) {
+    return (a.ln_c ? FX_LN : 0) | (a.row_stats_out ? FX_STATS : 0) | (a.vt_out ? FX_VT : 0) | (a.cross_k ? FX_CROSS : 0);
+}
 constexpr bool gemm_fx_ok(int epi, int fx) {
-    return fx == 0 || (epi == EPI_NONE && (fx == FX_LN || fx == FX_STATS || fx == FX_VT || fx == (FX_LN | FX_VT))) ||
+    return fx == 0 || (epi == EPI_NONE && (fx == FX_LN || fx == FX_STATS || fx == FX_VT || fx == (FX_LN | FX_VT) || fx == FX_CROSS ||
+                                           fx == (FX_LN | FX_CROSS))) ||
            (epi == EPI_RESID && fx == FX_STATS) || (epi == EPI_GEGLU && fx == FX_LN);
 }
 // calls f(std::integral_constant<int, FX>) for the instantiated mask of this epilogue; false when the pair does not exist
@@ -290,6 +294,8 @@ inline bool gemm_fx_dispatch(int fx, F&& f) {
             case FX_STATS: f(std::integral_constant<int, FX_STATS>{}); return true;
             case FX_VT: f(std::integral_constant<int, FX_VT>{}); return true;
             case FX_LN | FX_VT: f(std::integral_constant<int, FX_LN | FX_VT>{}); return true;
+            case FX_CROSS: f(std::integral_constant<int, FX_CROSS>{}); return true;
+            case FX_LN | FX_CROSS: f(std::integral_constant<int, FX_LN | FX_CROSS>{}); return true;
         }
     } else if constexpr (EPI == EPI_RESID) {
         if (fx == FX_STATS) { f(std::integral_constant<int, FX_STATS>{}); return true; }

@@ -72,6 +72,17 @@ struct GemmArgs {
     // m = b * vt_s + s  (= [B, H, 64, S_pad] with H * 64 = N - vt_col0).  EPI_NONE only.
     bf16_t* vt_out = nullptr;
     int vt_col0 = 0, vt_s = 0, vt_spad = 0;
+    // ---- cross-attention epilogue (UNet attn2 over <= 64 fixed context tokens): this GEMM is the to_q projection of head-dim-64
+    // heads (N = heads * 64); instead of writing q, every wave runs the whole attention of its (32 queries, 1 head) tile
+    // against the cached K rows / V^T of the prompt -- S = K q^T, softmax over the keys, O = V^T P -- and C receives the
+    // attention output (what the flash kernel would have written), so neither q nor a second launch exists.  128 x 64 tile only.
+    //   cross_k  [B * cross_n, cross_ldk] K rows of every batch element (head h at columns h * 64 ..)
+    //   cross_vt [B, N / 64, 64, cross_npad] V^T, key-contiguous (zero beyond cross_n)
+    //   rows m of batch element b = m / cross_rows; scores scaled by cross_scale
+    const bf16_t* cross_k = nullptr;
+    const bf16_t* cross_vt = nullptr;
+    int cross_ldk = 0, cross_n = 0, cross_npad = 0, cross_rows = 0;
+    float cross_scale = 0.f;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // fp8 x fp8 -> bf16 on the block-scaled MFMA (256x256 ping-pong tile only): K % 128 == 0, a.a_scale / a.w_scale set

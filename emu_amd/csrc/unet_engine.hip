@@ -60,7 +60,8 @@ struct emu_unet {
     size_t splitk_floats = 0;
     std::map<std::string, const bf16_t*> w;
     bool finalized = false;
-    int fusion = 0;                     // bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv epilogue
+    int fusion = 0;                     // bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv epilogue,
+                                        // bit 2: cross-attention inside the attn2 to_q epilogue
     int fusion_avail = 0;               // what the registered tensors allow (set by emu_unet_finalize)
     // resolved structure
     const bf16_t *conv_in_w, *conv_in_b, *te1w, *te1b, *te2w, *te2b, *ae1w, *ae1b, *ae2w, *ae2b, *tpw, *tpb;
@@ -204,6 +205,10 @@ struct Fx {
     const float* stats_in = nullptr;
     bf16_t* vt = nullptr;               // qkv projection: V heads (columns >= vt_col0) stored key-contiguous
     int vt_col0 = 0, vt_s = 0, vt_spad = 0;
+    const bf16_t* cross_k = nullptr;    // attn2 to_q projection: cross-attention over the cached prompt K / V^T in the epilogue
+    const bf16_t* cross_vt = nullptr;
+    int cross_ldk = 0, cross_n = 0, cross_npad = 0, cross_rows = 0;
+    float cross_scale = 0.f;
 };
 
 int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, const bf16_t* res, bf16_t* C, int M, int N, int K,
@@ -222,6 +227,8 @@ int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, con
             g.ln_c = fx->ln->c; g.ln_d = fx->ln->d; g.ln_stats = fx->stats_in; g.ln_slots = K / 128; g.ln_eps = 1e-5f;
         }
         g.vt_out = fx->vt; g.vt_col0 = fx->vt_col0; g.vt_s = fx->vt_s; g.vt_spad = fx->vt_spad;
+        g.cross_k = fx->cross_k; g.cross_vt = fx->cross_vt; g.cross_ldk = fx->cross_ldk; g.cross_n = fx->cross_n;
+        g.cross_npad = fx->cross_npad; g.cross_rows = fx->cross_rows; g.cross_scale = fx->cross_scale;
     }
     return launch_gemm(g, s);
 }
@@ -262,6 +269,7 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     // projection writes V^T itself.  M <= 8 (toy latents) stays on the unfused GEMV path.
     const bool fln = (u->fusion & 1) && M > 8 && (C & 127) == 0;     // statistics slots are 128 columns wide
     const bool fvt = (u->fusion & 2) && M > 8 && HW == hwpad;
+    const bool fca = (u->fusion & 4) && M > 8 && HW == hwpad && n <= 64;     // rows of one tile within one batch element
     float* st = w.lnstats;
     UTRY(launch_groupnorm(x, t.gng, t.gnb, w.gn, w.gnws, Bn, HW, C, u->cfg.groups, 1e-6f, 0, s));
     { Fx fx; fx.stats_out = fln ? st : nullptr;
@@ -288,13 +296,20 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
         // cross attention on the cached context K / Vt
         lnx = b;
         if (!fln) { UTRY(launch_layernorm(b, tb.ln2g, tb.ln2b, nullptr, w.ln, M, C, 1e-5f, s)); lnx = w.ln; }
-        { Fx fx; fx.ln = &tb.q2_ln; fx.stats_in = st;
-          UTRY(gemm(u, lnx, tb.q2, nullptr, nullptr, w.q2, M, C, C, C, 0, C, EPI_NONE, s, fln ? &fx : nullptr)); }
         { const bf16_t* kv = u->ctx_cache + tb.ctx_off;
           const bf16_t* vt = kv + (size_t)Bn * n * 2 * C;
-          FlashArgs f{w.q2, (long)HW * C, (long)D, (long)C, kv, (long)n * 2 * C, (long)D, (long)2 * C, vt,
-                      w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, n, npad, D, 0, scale};
-          UTRY(launch_flash_attn(f, s)); }
+          Fx fx;
+          if (fln) { fx.ln = &tb.q2_ln; fx.stats_in = st; }
+          if (fca) {                                     // to_q + the whole 64-key attention in one launch: writes w.att directly
+              fx.cross_k = kv; fx.cross_vt = vt; fx.cross_ldk = 2 * C; fx.cross_n = n; fx.cross_npad = npad; fx.cross_rows = HW;
+              fx.cross_scale = scale;
+              UTRY(gemm(u, lnx, tb.q2, nullptr, nullptr, w.att, M, C, C, C, 0, C, EPI_NONE, s, &fx));
+          } else {
+              UTRY(gemm(u, lnx, tb.q2, nullptr, nullptr, w.q2, M, C, C, C, 0, C, EPI_NONE, s, fln ? &fx : nullptr));
+              FlashArgs f{w.q2, (long)HW * C, (long)D, (long)C, kv, (long)n * 2 * C, (long)D, (long)2 * C, vt,
+                          w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, n, npad, D, 0, scale};
+              UTRY(launch_flash_attn(f, s));
+          } }
         { Fx fx; fx.stats_out = st;
           UTRY(gemm(u, w.att, tb.o2w, tb.o2b, b, a, M, C, C, C, C, C, EPI_RESID, s, fln ? &fx : nullptr)); }
         // GEGLU feed-forward
@@ -353,7 +368,7 @@ int emu_unet_finalize(emu_unet* u) {
     if (!u) return -22;
     const emu_unet_cfg& c = u->cfg;
     bool ok = true;
-    u->fusion_avail = 3;                               // resolve_transformer clears bit 0 when a packed tensor is missing
+    u->fusion_avail = 7;                               // resolve_transformer clears bit 0 when a packed tensor is missing
     int toff = 0;
     auto mk_res = [&](const std::string& name, int cin, int cout) {
         Resnet r{}; r.name = name; r.cin = cin; r.cout = cout; r.temb_off = toff; toff += cout;

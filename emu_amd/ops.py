@@ -60,11 +60,13 @@ def linear(x, w, bias=None, res=None, norm_w=None, eps: float = 0.0, epi: int = 
     return out
 
 
-def linear_fused(x, w, bias=None, res=None, epi: int = EPI_NONE, out=None, stats_out=None, ln=None, vt=None):
+def linear_fused(x, w, bias=None, res=None, epi: int = EPI_NONE, out=None, stats_out=None, ln=None, vt=None, cross=None):
     """emu_linear_fused_bf16: ``linear`` (M > 8) with the fused epilogues of the UNet transformer blocks.
     ``stats_out`` fp32 [N/128, M, 2]: per-row partial (sum, sum of squares) of the output per 128-column slot.
     ``ln`` = (c fp32 [N], d fp32 [N], stats fp32 [K/128, M, 2], eps): x is the un-normalised activation, w = W * gamma.
-    ``vt`` = (vt_out bf16 [B, N - col0, S_pad], col0, S): columns >= col0 are stored key-contiguous instead of row-major."""
+    ``vt`` = (vt_out bf16 [B, N - col0, S_pad], col0, S): columns >= col0 are stored key-contiguous instead of row-major.
+    ``cross`` = (k_rows bf16 [B * n, ldk], vt bf16 [B, N / 64, 64, n_pad], n, rows_per_batch, scale): x @ w^T is attn2.to_q and the
+    output is the cross-attention over the n <= 64 cached keys (see emu_linear_fx)."""
     import ctypes as C
     from ._lib import LinearFxC
     _req(x, "x"); _req(w, "w")
@@ -85,6 +87,11 @@ def linear_fused(x, w, bias=None, res=None, epi: int = EPI_NONE, out=None, stats
         vt_out, col0, S = vt
         _req(vt_out, "vt_out")
         fx.vt_out, fx.vt_col0, fx.vt_s, fx.vt_spad = vt_out.data_ptr(), int(col0), int(S), vt_out.shape[-1]
+    if cross is not None:
+        ck, cvt, n_ctx, rows, scale = cross
+        _req(ck, "cross_k"); _req(cvt, "cross_vt")
+        fx.cross_k, fx.cross_vt, fx.cross_ldk, fx.cross_n = ck.data_ptr(), cvt.data_ptr(), ck.stride(0), int(n_ctx)
+        fx.cross_npad, fx.cross_rows, fx.cross_scale = cvt.shape[-1], int(rows), float(scale)
     check(lib().emu_linear_fused_bf16(_p(x), _p(w), _p(bias), _p(res), _p(out), M, N, K, x.stride(0), w.stride(0),
                                       res.stride(0) if res is not None else 0, out.stride(0), int(epi), C.byref(fx), stream(x)),
           "emu_linear_fused_bf16")

@@ -198,7 +198,7 @@ class UNetEngine:
 
     def set_fusion(self, mask: int) -> int:
         """Launch fusions of the transformer blocks (bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv
-        epilogue); 0 = the unfused launch sequence.  Invalidates a captured hipGraph.  Returns the mask in effect."""
+        epilogue, bit 2: cross-attention inside the attn2 to_q epilogue); 0 = the unfused launch sequence.  Invalidates a captured hipGraph.  Returns the mask in effect."""
         self._graph = None
         r = lib().emu_unet_set_fusion(self.handle, int(mask))
         if r < 0:

@@ -111,6 +111,11 @@ int emu_linear_fp8w_bf16(const void* A, const void* W8, const float* wscale, con
  *   vt_out/vt_col0/vt_s/vt_spad  output columns n >= vt_col0 (the V heads of a fused qkv projection) are stored
  *                  key-contiguous, vt_out[(b * (N - vt_col0) + n - vt_col0) * vt_spad + s] for row m = b * vt_s + s,
  *                  instead of row-major (what the attention kernel's P.V MFMA reads; replaces a transpose launch)
+ *   cross_k/cross_vt/...  this GEMM is attn2.to_q (head dim 64, N = heads * 64, no bias) and its epilogue runs the whole
+ *                  cross-attention over the <= 64 cached context tokens: C receives softmax(q K^T * cross_scale) V per head
+ *                  (what the attention kernel would have written from q), q itself is never stored.  cross_k [B * cross_n,
+ *                  cross_ldk] K rows (head h at columns h * 64), cross_vt [B, heads, 64, cross_npad] V^T (zero beyond cross_n),
+ *                  batch element of row m = m / cross_rows (cross_rows % 64 == 0).  Combines with ln_* only.
  * All pointers optional (NULL = feature off). */
 typedef struct {
     float* row_stats_out;
@@ -121,6 +126,10 @@ typedef struct {
     float ln_eps;
     void* vt_out;
     int vt_col0, vt_s, vt_spad;
+    const void* cross_k;
+    const void* cross_vt;
+    int cross_ldk, cross_n, cross_npad, cross_rows;
+    float cross_scale;
 } emu_linear_fx;
 int emu_linear_fused_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                           int lda, int ldw, int ldres, int ldc, int epi, const emu_linear_fx* fx, emu_stream_t s);
@@ -279,8 +288,9 @@ int emu_unet_set_weight(emu_unet* u, const char* name, const void* ptr);
 int emu_unet_finalize(emu_unet* u);                       /* -2 + emu_last_error: first missing tensor        */
 /* Launch fusions of the transformer blocks (default: every one whose packed tensors are registered).  Bit 0: LayerNorm folded
  * into the consumer GEMM (needs "<block>attn1.qkv.wln/.c/.d", "attn2.q.wln/.c/.d", "ff.geglu.wln/.c/.d": W * gamma, its fp32
- * row sums, W @ beta + bias); bit 1: V^T written by the qkv projection's epilogue (no transpose launch).  0 = the unfused
- * launch sequence (A/B timing, parity of fused vs unfused).  Returns the mask in effect. */
+ * row sums, W @ beta + bias); bit 1: V^T written by the qkv projection's epilogue (no transpose launch); bit 2: the cross-attention
+ * over the (<= 64) prompt tokens runs inside the attn2.to_q projection's epilogue (no q tensor, no attention launch).  0 = the
+ * unfused launch sequence (A/B timing, parity of fused vs unfused).  Returns the mask in effect. */
 int emu_unet_set_fusion(emu_unet* u, int mask);
 int emu_unet_temb_total(const emu_unet* u);               /* rows of temb_proj_all (sum of resnet out channels) */
 size_t emu_unet_workspace_bytes(const emu_unet* u, int H, int W);

@@ -147,3 +147,39 @@ def test_producer_consumer_chain_equals_unfused_sequence(force, M, C):
     y = F.linear(F.layer_norm(h.float(), (C,), gamma.float(), beta.float(), eps), wg.float(), bg.float())
     y = y[:, 0::2] * F.gelu(y[:, 1::2])
     assert rel(fused, y) < max(6e-3, 1.5 * rel(unfused, y)), (rel(fused, y), rel(unfused, y))
+
+
+@pytest.mark.parametrize("B,S,C,n", [(2, 1024, 1280, 64), (2, 4096, 640, 64), (2, 64, 256, 64), (2, 256, 128, 40), (1, 128, 64, 7)])
+@pytest.mark.parametrize("with_ln", [False, True])
+def test_cross_attention_in_the_to_q_epilogue(force, B, S, C, n, with_ln):
+    """attn2 of a BasicTransformerBlock over the fixed prompt tokens: to_q GEMM + attention over n <= 64 cached keys + softmax + PV
+    in ONE launch (emu_linear_fx::cross_*), against the two-launch sequence (GEMM, flash attention kernel) and against fp32
+    torch; optionally with the LayerNorm ahead of to_q folded in as well.  n < 64 exercises the key mask / clamped K rows."""
+    from emu_amd import ops
+    H, D, M, eps, scale = C // 64, 64, B * S, 1e-5, 0.125
+    x = rnd(M, C, seed=30, scale=1.2, shift=0.4)
+    wq = rnd(C, C, seed=31, scale=C ** -0.5)
+    kv = rnd(B * n, 2 * C, seed=32)                                    # K | V rows of the prompt, as emu_unet_set_context packs them
+    vt = ops.transpose_v(kv[:, C:], B, H, n, D, n * 2 * C, D, 2 * C)   # [B, H, 64, n_pad], zero beyond n
+    gamma, beta = rnd(C, seed=33, scale=0.2, shift=1.0), rnd(C, seed=34, scale=0.2)
+    xin = ops.layernorm(x, gamma, beta, eps) if with_ln else x
+    force("0")
+    q = ops.linear(xin, wq)
+    o = ops.flash_attn(q.view(B, S, H, D), kv[:, :C].view(B, n, H, D), kv[:, C:].view(B, n, H, D), False, scale).reshape(M, C)
+    if with_ln:
+        wln, c, d = fold(wq, gamma, beta, None)
+        got = ops.linear_fused(x, wln, ln=(c, d, slot_stats(x), eps), cross=(kv, vt, n, S, scale)) if C % 128 == 0 else None
+        if got is None:
+            pytest.skip("statistics slots are 128 columns wide")
+    else:
+        got = ops.linear_fused(xin, wq, cross=(kv, vt, n, S, scale))
+    torch.cuda.synchronize()
+    qf = F.linear((F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), eps) if with_ln else x.float()), wq.float())
+    qf = qf.to(BF16).float().view(B, S, H, D).transpose(1, 2)
+    kf, vf = kv[:, :C].float().view(B, n, H, D).transpose(1, 2), kv[:, C:].float().view(B, n, H, D).transpose(1, 2)
+    y = (torch.softmax(qf @ kf.transpose(-1, -2) * scale, dim=-1) @ vf).transpose(1, 2).reshape(M, C)
+    assert bool(torch.isfinite(got.float()).all())
+    e_f, e_u = rel(got, y), rel(o, y)
+    assert e_f < max(6e-3, 1.5 * e_u), (e_f, e_u)
+    if not with_ln:
+        assert rel(got, o) < 4e-3, rel(got, o)                          # same rounding points, another summation order

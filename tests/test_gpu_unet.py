@@ -173,9 +173,9 @@ def test_denoise_loop_cfg_euler_and_graph(tiny_unet):
 
 
 def test_fused_transformer_launches_equal_the_unfused_sequence(tiny_unet):
-    """emu_unet_set_fusion: LayerNorm folded into the consumer GEMMs + V^T from the qkv epilogue (the default) against the
-    unfused launch sequence (mask 0) on the same weights and inputs -- both within the stated tolerance of the restatement,
-    and close to each other; every fusion bit on its own as well."""
+    """emu_unet_set_fusion: LayerNorm folded into the consumer GEMMs + V^T from the qkv epilogue + cross-attention inside the to_q
+    epilogue (the default) against the unfused launch sequence (mask 0) on the same weights and inputs -- all within the stated
+    tolerance of the restatement, and close to each other; every fusion bit on its own as well."""
     from oracle import unet_ref as U
     eng, Wr, ocfg = tiny_unet
     H = Wd = 16
@@ -190,16 +190,18 @@ def test_fused_transformer_launches_equal_the_unfused_sequence(tiny_unet):
     want = U.unet_forward(inp, sch.timesteps[0], prompt.float(), prompt.float().mean(1).to(BF16).float(), time_ids, Wr, ocfg)
     outs = {}
     try:
-        assert eng.set_fusion(3) == 3, "the packed LayerNorm-fold tensors are registered by load_state_dict"
-        for mask in (3, 0, 1, 2):
+        assert eng.set_fusion(7) == 7, "the packed LayerNorm-fold tensors are registered by load_state_dict"
+        for mask in (7, 0, 1, 2, 3, 4):
             assert eng.set_fusion(mask) == mask
             outs[mask] = eng.forward(x, 0)
             assert rel_err(outs[mask], want) < 3e-2, (mask, rel_err(outs[mask], want))
     finally:
-        eng.set_fusion(3)
+        eng.set_fusion(7)
     assert torch.equal(outs[2].cpu(), outs[0].cpu())                 # the V^T epilogue changes no arithmetic at all
     assert rel_err(outs[3], outs[0]) < 1.5e-2, rel_err(outs[3], outs[0])
     assert torch.equal(outs[3].cpu(), outs[1].cpu())
+    assert rel_err(outs[4], outs[0]) < 1e-2, rel_err(outs[4], outs[0])      # cross-attention in the to_q epilogue: same rounding points
+    assert rel_err(outs[7], outs[0]) < 1.5e-2, rel_err(outs[7], outs[0])
 
 
 @pytest.fixture(scope="module")
