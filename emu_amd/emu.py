@@ -189,7 +189,8 @@ class EmuModel:
                      video: Optional[torch.Tensor] = None, max_new_tokens: int = 10, min_len: int = 1,
                      stop_on_eos: bool = True, num_beams: int = 1, length_penalty: float = -1.0, do_sample: bool = False,
                      temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0,
-                     penalty_alpha: Optional[float] = None) -> torch.Tensor:
+                     penalty_alpha: Optional[float] = None, no_repeat_ngram_size: int = 0,
+                     num_return_sequences: int = 1) -> torch.Tensor:
         """``generate`` at the token-id level: returns the NEW ids [B, n] (what HF returns for inputs_embeds).  Mode
         selection as transformers does it: contrastive search (penalty_alpha > 0, top_k > 1, one beam, no sampling), beam
         search / beam sampling (num_beams > 1), sampling or penalised greedy, plain greedy (device-side loop, hipGraph)."""
@@ -197,8 +198,11 @@ class EmuModel:
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
             x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
+        ngram, nret = int(no_repeat_ngram_size or 0), int(num_return_sequences)
         if (penalty_alpha is not None and penalty_alpha > 0 and top_k is not None and top_k > 1 and num_beams == 1
                 and not do_sample):
+            if ngram or nret != 1:
+                raise NotImplementedError("contrastive search with no_repeat_ngram_size / several returned sequences is not built")
             return self.decoder.lm.contrastive_generate(x.view(B, S, -1), attention_mask, max_new_tokens, float(penalty_alpha),
                                                         int(top_k), min_len, repetition_penalty, eos_id=EOS_TOKEN_ID,
                                                         pad_id=PAD_TOKEN_ID)
@@ -206,11 +210,12 @@ class EmuModel:
             return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
                                                         length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,
                                                         do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
-                                                        repetition_penalty=repetition_penalty)
-        if do_sample or repetition_penalty != 1.0:
+                                                        repetition_penalty=repetition_penalty, no_repeat_ngram_size=ngram,
+                                                        num_return_sequences=nret)
+        if do_sample or repetition_penalty != 1.0 or ngram or nret != 1:
             return self.decoder.lm.sample_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len, do_sample,
                                                    temperature, top_k, top_p, repetition_penalty, eos_id=EOS_TOKEN_ID,
-                                                   pad_id=PAD_TOKEN_ID)
+                                                   pad_id=PAD_TOKEN_ID, no_repeat_ngram_size=ngram, num_return_sequences=nret)
         return self.decoder.lm.greedy_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len,
                                                eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID, use_graph=self.use_graph,
                                                stop_on_eos=stop_on_eos)
@@ -228,6 +233,8 @@ class EmuModel:
         if "min_length" in kwargs:
             min_len = max(int(min_len), int(kwargs.pop("min_length")))
         kwargs.pop("use_cache", None)                   # always cached
+        ngram = int(kwargs.pop("no_repeat_ngram_size", 0) or 0)
+        nret = int(kwargs.pop("num_return_sequences", 1) or 1)
         if kwargs:
             raise TypeError(f"EmuModel.generate: unsupported generation options {sorted(kwargs)} "
                             "(the HIP engine implements greedy / beam / sampling / contrastive search with the arguments of the signature)")
@@ -238,7 +245,7 @@ class EmuModel:
         ids = self.generate_ids(inputs.input_ids, inputs.attention_mask, image, video, max_new_tokens, min_len,
                                 num_beams=num_beams, length_penalty=length_penalty, do_sample=do_sample,
                                 temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
-                                penalty_alpha=penalty_alpha)
+                                penalty_alpha=penalty_alpha, no_repeat_ngram_size=ngram, num_return_sequences=nret)
         return tok.batch_decode(ids.cpu(), skip_special_tokens=skip_special_tokens)
 
     # ------------------------------------------------------------------ generate_image (emu.py:92-153)

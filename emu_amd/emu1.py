@@ -266,7 +266,7 @@ class Emu:
     def generate_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, image: Optional[torch.Tensor] = None,
                      num_beams: int = 5, max_new_tokens: int = 50, min_length: int = 1, length_penalty: float = 0.0,
                      do_sample: bool = False, temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0,
-                     penalty_alpha=None):
+                     penalty_alpha=None, no_repeat_ngram_size=None, num_return_sequences: int = 1):
         B, S = input_ids.shape
         x = self.lm.embed_tokens(input_ids).view(B * S, -1)
         if image is not None:
@@ -278,25 +278,28 @@ class Emu:
             ops.scatter_rows(e, rows.contiguous(), x)
         x = x.view(B, S, -1)
         # mode selection as transformers does it (modeling_emu.py:162-179 forwards every argument to lm.generate)
+        ngram, nret = int(no_repeat_ngram_size or 0), int(num_return_sequences)
         if penalty_alpha is not None and penalty_alpha > 0 and top_k is not None and top_k > 1 and num_beams == 1 and not do_sample:
+            if ngram or nret != 1:
+                raise NotImplementedError("contrastive search with no_repeat_ngram_size / several returned sequences is not built")
             return self.lm.contrastive_generate(x, attention_mask, max_new_tokens, float(penalty_alpha), int(top_k), min_length,
                                                 repetition_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID)
         if num_beams > 1:
             return self.lm.beam_search_generate(x, attention_mask, num_beams, max_new_tokens, min_length, length_penalty,
                                                 eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID, do_sample=do_sample,
                                                 temperature=temperature, top_k=top_k, top_p=top_p,
-                                                repetition_penalty=repetition_penalty)
-        if do_sample or repetition_penalty != 1.0:
+                                                repetition_penalty=repetition_penalty, no_repeat_ngram_size=ngram,
+                                                num_return_sequences=nret)
+        if do_sample or repetition_penalty != 1.0 or ngram or nret != 1:
             return self.lm.sample_generate(x, attention_mask, max_new_tokens, min_length, do_sample, temperature, top_k, top_p,
-                                           repetition_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID)
+                                           repetition_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,
+                                           no_repeat_ngram_size=ngram, num_return_sequences=nret)
         return self.lm.greedy_generate(x, attention_mask, max_new_tokens, min_length, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID)
 
     @torch.no_grad()
     def generate(self, samples, do_sample=False, num_beams=5, max_new_tokens=50, min_length=1, top_p=0.9,
                  repetition_penalty=1.0, length_penalty=0.0, num_captions=1, temperature=1, penalty_alpha=None, top_k=None,
                  no_repeat_ngram_size=None, **kwargs) -> List[str]:
-        if no_repeat_ngram_size or num_captions != 1:
-            raise NotImplementedError("Emu1 generate: no_repeat_ngram_size / num_captions > 1 are not built")
         if kwargs:
             raise TypeError(f"Emu.generate: unsupported generation options {sorted(kwargs)}")
         if self.tokenizer is None:
@@ -307,5 +310,6 @@ class Emu:
         tok.padding_side = "right"
         ids = self.generate_ids(enc.input_ids, enc.attention_mask, samples.get("image"), num_beams, max_new_tokens,
                                 min_length, length_penalty, do_sample=do_sample, temperature=temperature, top_k=top_k,
-                                top_p=top_p, repetition_penalty=repetition_penalty, penalty_alpha=penalty_alpha)
+                                top_p=top_p, repetition_penalty=repetition_penalty, penalty_alpha=penalty_alpha,
+                                no_repeat_ngram_size=no_repeat_ngram_size, num_return_sequences=num_captions)
         return tok.batch_decode(ids.cpu(), skip_special_tokens=True)

@@ -383,11 +383,17 @@ class LlamaEngine:
     def sample_generate(self, embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, min_len: int = 1,
                         do_sample: bool = True, temperature: Optional[float] = None, top_k: Optional[int] = None,
                         top_p: Optional[float] = None, repetition_penalty: float = 1.0, eos_id: int = 2,
-                        pad_id: int = 32000) -> torch.Tensor:
+                        pad_id: int = 32000, no_repeat_ngram_size: int = 0, num_return_sequences: int = 1) -> torch.Tensor:
         """``lm.generate(inputs_embeds=..., num_beams=1)`` with logits processing: repetition penalty, min_length, then
         (when sampling) temperature / top-k / top-p warpers and a multinomial draw from torch's global CUDA generator
         (transformers' processor order).  The decoder runs on the HIP engine; the tiny per-step logits post-processing is
-        host-driven, so this path is not graph-replayed."""
+        host-driven, so this path is not graph-replayed.  ``num_return_sequences`` = n samples every prompt n times (rows
+        prompt-major, as the library expands its inputs); without sampling the library refuses n > 1 and so does this."""
+        if num_return_sequences > 1:
+            if not do_sample:
+                raise ValueError("Greedy methods without beam search do not support `num_return_sequences` different than 1")
+            embeds = embeds.repeat_interleave(num_return_sequences, dim=0)
+            attention_mask = attention_mask.repeat_interleave(num_return_sequences, dim=0)
         B, S, H = embeds.shape
         dev = self.device
         s_max = self.kv_capacity(S + max_new_tokens)
@@ -399,7 +405,7 @@ class LlamaEngine:
         n = 0
         for step in range(max_new_tokens):
             scores = process_logits(self.logits(row).float(), out[:, :step], step < min_len, eos_id, do_sample, temperature,
-                                    top_k, top_p, repetition_penalty)
+                                    top_k, top_p, repetition_penalty, no_repeat_ngram_size=int(no_repeat_ngram_size or 0))
             if do_sample:
                 nxt = torch.multinomial(torch.softmax(scores, dim=-1), num_samples=1).squeeze(1)
             else:
@@ -508,7 +514,8 @@ class LlamaEngine:
                              pad_id: int = 32000, do_sample: bool = False, temperature: Optional[float] = None,
                              top_k: Optional[int] = None, top_p: Optional[float] = None,
                              repetition_penalty: float = 1.0, hf_semantics: str = "4.31",
-                             trace: Optional[dict] = None) -> torch.Tensor:
+                             trace: Optional[dict] = None, no_repeat_ngram_size: int = 0,
+                             num_return_sequences: int = 1) -> torch.Tensor:
         """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False, early_stopping=False)`` -- the reference's
         DEFAULT decoding mode (num_beams=5, length_penalty=-1, Emu2/emu/emu.py:163-172,213-229).  Restates
         transformers' vectorised beam search: per step keep the 2N best continuations over beams x vocab, the N best
@@ -531,10 +538,17 @@ class LlamaEngine:
         kept in draw order.  With temperature 1 and no top-k / top-p the two differ only in the sort.  The deterministic
         modes (do_sample=False) are the same in both.
 
+        ``no_repeat_ngram_size`` adds the library's NoRepeatNGramLogitsProcessor to the pipeline; ``num_return_sequences`` = n
+        returns the n best results of every prompt ([B * n, len], prompt-major: what Emu1's ``num_captions`` asks for,
+        Emu1/models/modeling_emu.py:110,173).
+
         ``trace`` (a dict, diagnostics for the tests): receives ``margin`` = the smallest gap seen between the N-th and the
         (N+1)-th running candidate at a pruning step and between the two best final results."""
         if hf_semantics not in ("4.31", "5.x"):
             raise ValueError("hf_semantics must be '4.31' or '5.x'")
+        if not 1 <= num_return_sequences <= num_beams:
+            raise ValueError("`num_return_sequences` has to be smaller or equal to `num_beams`")       # the library's own check
+        ngram = int(no_repeat_ngram_size or 0)
         B, S, H = embeds.shape
         nb, V, dev = num_beams, self.vocab, self.device
         s_max = self.kv_capacity(S + max_new_tokens)
@@ -572,10 +586,10 @@ class LlamaEngine:
         old = do_sample and hf_semantics == "4.31"
         while True:
             log_probs = torch.log_softmax(lp_rows, dim=-1)
-            if do_sample or repetition_penalty != 1.0:
+            if do_sample or repetition_penalty != 1.0 or ngram:
                 log_probs = process_logits(log_probs.reshape(B * nb, V), running_seq[:, :, :cur].reshape(B * nb, cur), cur < min_len,
                                            eos_id, do_sample and not old, temperature, top_k, top_p, repetition_penalty,
-                                           min_keep=2).view(B, nb, V)
+                                           min_keep=2, no_repeat_ngram_size=ngram).view(B, nb, V)
             elif cur < min_len:
                 log_probs = log_probs.clone()
                 log_probs[..., eos_id] = -float("inf")
@@ -640,16 +654,19 @@ class LlamaEngine:
             self.forward(hid, B * nb, 1, pos, slot, kstart_b, ctx=ctx + 1)
             pos = pos + 1
             lp_rows = self.logits(hid).float().view(B, nb, V)
-        out_len = int(seq_len[:, 0].max().item())
+        nret = int(num_return_sequences)
+        out_len = int(seq_len[:, :nret].max().item())
         if trace is not None:
             trace["margin"] = min(margin, float((beam_scores[:, 0] - beam_scores[:, 1]).min()))
         self.ctx.check_p2p()
-        return sequences[:, 0, :out_len]
+        if nret == 1:
+            return sequences[:, 0, :out_len]
+        return sequences[:, :nret, :out_len].reshape(B * nret, out_len)
 
 
 def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: bool, eos_id: int, do_sample: bool,
                    temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
-                   repetition_penalty: float = 1.0, min_keep: int = 1) -> torch.Tensor:
+                   repetition_penalty: float = 1.0, min_keep: int = 1, no_repeat_ngram_size: int = 0) -> torch.Tensor:
     """transformers' logits pipeline for ``generate(inputs_embeds=...)`` in its order: RepetitionPenaltyLogitsProcessor over
     the ids generated so far (with inputs_embeds the prompt contributes no ids), MinLengthLogitsProcessor (EOS -> -inf),
     then -- only when sampling -- TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper.  ``scores`` [B, V] fp32,
@@ -659,11 +676,31 @@ def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: 
         g = torch.gather(scores, 1, generated)
         g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
         scores = scores.scatter(1, generated, g)
+    if no_repeat_ngram_size and no_repeat_ngram_size > 0:
+        scores = ban_repeated_ngrams(scores, generated, int(no_repeat_ngram_size))
     if suppress_eos:
         scores = scores.clone()
         scores[:, eos_id] = -float("inf")
     if do_sample:
         scores = warp_logits(scores, temperature, top_k, top_p, min_keep)
+    return scores
+
+
+def ban_repeated_ngrams(scores: torch.Tensor, generated: torch.Tensor, n: int) -> torch.Tensor:
+    """transformers' NoRepeatNGramLogitsProcessor (after the repetition penalty, ahead of MinLength in the library's processor
+    list): a token that would complete an n-gram already present in the row's generated ids gets -inf.  ``generated`` [B, cur]
+    (with inputs_embeds the prompt contributes no ids).  Host loop: rows x cur is a few hundred at most."""
+    B, cur = generated.shape
+    if cur + 1 < n:
+        return scores
+    scores = scores.clone()
+    gen = generated.tolist()
+    for b in range(B):
+        row = gen[b]
+        prefix = tuple(row[cur - (n - 1):]) if n > 1 else ()
+        for i in range(cur - n + 1):
+            if tuple(row[i:i + n - 1]) == prefix:
+                scores[b, row[i + n - 1]] = -float("inf")
     return scores
 
 

@@ -211,6 +211,12 @@ def generate_fixture(t, ref_json, vkw, W_vis, image):
                 txt = emu.generate({"image": image[:1], "prompt": prompt}, num_beams=nb, max_new_tokens=6)
             outs[name] = captured["ids"].numpy()
             print(name, outs[name].tolist(), txt)
+        # num_captions (= num_return_sequences) and no_repeat_ngram_size (modeling_emu.py:110,115,173,176), round 3
+        with torch.no_grad():
+            txt = emu.generate({"image": image[:1], "prompt": prompt}, num_beams=5, max_new_tokens=8, num_captions=2,
+                               no_repeat_ngram_size=2)
+        outs["beam_cap2_ngram2"] = captured["ids"].numpy()
+        print("beam_cap2_ngram2", outs["beam_cap2_ngram2"].tolist(), txt)
     finally:
         tok.batch_decode = orig
     tok.padding_side = "left"
@@ -219,7 +225,8 @@ def generate_fixture(t, ref_json, vkw, W_vis, image):
     meta.update(cfg_vocab=np.array(vocab), cfg_lhidden=np.array(lh), cfg_lffn=np.array(lf), cfg_lheads=np.array(lheads),
                 cfg_llayers=np.array(ll))
     np.savez(os.path.join(OUT, "emu1_generate_tiny.npz"), image=image[:1].numpy(), ids=enc.input_ids.numpy(),
-             mask=enc.attention_mask.numpy(), greedy=outs["greedy"], beam=outs["beam"], **meta)
+             mask=enc.attention_mask.numpy(), greedy=outs["greedy"], beam=outs["beam"], beam_cap2_ngram2=outs["beam_cap2_ngram2"],
+             **meta)
     shutil.rmtree(tmp, ignore_errors=True)
 
 

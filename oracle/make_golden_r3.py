@@ -136,6 +136,14 @@ def main():
     ref = capture_ids(m, tok, text=text, num_beams=3, repetition_penalty=1.5, max_new_tokens=8)
     assert ref.tolist() == got.tolist(), (ref.tolist(), got.tolist())
     out.update(pen_ids=enc.input_ids.numpy(), pen_mask=enc.attention_mask.numpy(), pen_new=ref.numpy(), pen_margin=np.array(mg))
+    # the same prompts with no_repeat_ngram_size = 2 and num_return_sequences = 2 (EmuModel.generate forwards **kwargs to
+    # transformers' generate, emu.py:175,228): 4 rows, prompt-major
+    ref2 = capture_ids(m, tok, text=text, num_beams=3, max_new_tokens=8, no_repeat_ngram_size=2, num_return_sequences=2)
+    got2 = L.LlamaEngine.beam_search_generate(new_eng(), R.embed_tokens(enc.input_ids, W), enc.attention_mask, 3, 8,
+                                              no_repeat_ngram_size=2, num_return_sequences=2)
+    assert ref2.tolist() == got2.tolist(), (ref2.tolist(), got2.tolist())
+    out.update(ngram_new=ref2.numpy())
+    print("ngram2 / 2 sequences", ref2.tolist())
     # 2b. the default decoding mode: 5 beams, 10 tokens, length_penalty -1, one image
     best = None
     e = R.encode_image(imgs[:1], W, cfg)

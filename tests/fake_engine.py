@@ -14,8 +14,9 @@ class _NoComm:                                       # the product checks its co
 
 
 class FakeEngine:
-    def __init__(self, lcfg: LlamaCfg, vocab: int, W, rcfg: R.LlamaCfg):
-        self.cfg, self.vocab, self.W, self.rcfg = lcfg, vocab, W, rcfg
+    def __init__(self, lcfg: LlamaCfg, vocab: int, W, rcfg: R.LlamaCfg, dtype=torch.float32):
+        """``dtype`` = the arithmetic of the stand-in: fp32 (default) or bf16 with bf16 weights (how the reference runs Emu1)."""
+        self.cfg, self.vocab, self.W, self.rcfg, self.dtype = lcfg, vocab, W, rcfg, dtype
         self.device = torch.device("cpu")
         self.embed = W["decoder.lm.model.embed_tokens.weight"]
         self.kcache = self.vcache = None
@@ -27,8 +28,8 @@ class FakeEngine:
 
     def alloc_kv(self, batch, s_max):
         L, H, D = self.rcfg.layers, self.rcfg.heads, self.rcfg.head_dim
-        self.kcache = torch.zeros(L, batch, H, s_max, D)
-        self.vcache = torch.zeros(L, batch, H, s_max, D)
+        self.kcache = torch.zeros(L, batch, H, s_max, D, dtype=self.dtype)
+        self.vcache = torch.zeros(L, batch, H, s_max, D, dtype=self.dtype)
         self.kv_batch, self.s_max = batch, s_max
 
     def _run(self, x, pos, n_past, kstart):
@@ -52,19 +53,19 @@ class FakeEngine:
         self.alloc_kv(B, s_max or self.cfg.max_position_embeddings)
         pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1) if hf_generate_positions else torch.arange(S)[None].expand(B, -1)
         kstart = (S - am.sum(1)).to(torch.int32)
-        h = self._run(embeds.float(), pos, 0, kstart)
+        h = self._run(embeds.to(self.dtype), pos, 0, kstart)
         nxt = am.sum(1) if hf_generate_positions else torch.full((B,), S)
         return h, kstart, nxt.to(torch.int32)
 
     def forward(self, hidden, B, T, pos, slot, kstart, ctx, ctx_dev=None):
         assert T == 1
-        h = self._run(hidden.float().view(B, 1, -1), pos, int(slot[0]), kstart)
+        h = self._run(hidden.to(self.dtype).view(B, 1, -1), pos, int(slot[0]), kstart)
         hidden.copy_(h.view(B, -1))
         return hidden
 
     def final_norm_rows(self, hidden):
-        return R.rms_norm(hidden.float(), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
+        return R.rms_norm(hidden.to(self.dtype), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
 
     def logits(self, rows, out=None):
-        h = R.rms_norm(rows.float(), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
+        h = R.rms_norm(rows.to(self.dtype), self.W["decoder.lm.model.norm.weight"], self.rcfg.rms_eps)
         return torch.nn.functional.linear(h, self.W["decoder.lm.lm_head.weight"])

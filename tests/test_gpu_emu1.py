@@ -107,6 +107,14 @@ def test_emu1_generate_follows_real_reference(golden_dir):
             lp = torch.log_softmax(torch.nn.functional.linear(h[:, ids.shape[1] - 1:], Wb["decoder.lm.lm_head.weight"]).float(), -1)
             return float(lp[0, torch.arange(seq.shape[1]), seq[0]].sum())
         assert seq_lp(beam) > seq_lp(torch.from_numpy(z["beam"])) - 0.15
+    # num_captions = 2 with a bigram ban (modeling_emu.py:110,115): two distinct captions, the best one the real reference's
+    cap = m.generate_ids(ids, mask, img.cuda(), num_beams=5, max_new_tokens=8, length_penalty=0.0, no_repeat_ngram_size=2,
+                         num_return_sequences=2).cpu()
+    assert cap.shape == (2, 8) and cap[0].tolist() != cap[1].tolist()
+    assert cap[0].tolist() == z["beam_cap2_ngram2"][0].tolist()
+    for row in cap.tolist():
+        big = list(zip(row, row[1:]))
+        assert len(big) == len(set(big)), row
 
 
 def test_emu1_generate_greedy_and_beam(tiny_emu1):

@@ -174,6 +174,14 @@ def test_generate_beam_sampling_and_penalised_beams(tiny_model, golden_dir):
     zm = tiny.load(golden_dir, "generate_margin_tiny.npz")
     pen = m.generate_ids(_t(zm["pen_ids"]), _t(zm["pen_mask"]), None, max_new_tokens=8, num_beams=3, repetition_penalty=1.5).cpu()
     assert pen.tolist() == zm["pen_new"].tolist()
+    # no_repeat_ngram_size + num_return_sequences (forwarded **kwargs of the reference's generate): 4 rows, prompt-major; the best
+    # sequence of every prompt is the real reference's, no row repeats a bigram
+    ng = m.generate_ids(_t(zm["pen_ids"]), _t(zm["pen_mask"]), None, max_new_tokens=8, num_beams=3, no_repeat_ngram_size=2,
+                        num_return_sequences=2).cpu()
+    assert ng.shape == (4, 8) and ng[0::2].tolist() == zm["ngram_new"][0::2].tolist()
+    for row in ng.tolist():
+        big = list(zip(row, row[1:]))
+        assert len(big) == len(set(big)), row
 
 
 def test_generate_contrastive_search(tiny_model, golden_dir):

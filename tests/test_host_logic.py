@@ -420,3 +420,88 @@ def test_logits_processing_matches_transformers_processors():
     # greedy: warpers are not applied
     s0 = torch.randn(2, 50, generator=g)
     assert torch.equal(process_logits(s0.clone(), torch.zeros(2, 0, dtype=torch.long), False, eos, False, 0.5, 3, 0.5, 1.0), s0)
+
+
+def test_no_repeat_ngram_matches_transformers_processor():
+    """ban_repeated_ngrams (process_logits' no_repeat_ngram_size) against transformers' NoRepeatNGramLogitsProcessor, element for
+    element, on id rows with planted repeats; and its place in the pipeline: after the repetition penalty, ahead of MinLength."""
+    from transformers.generation.logits_process import (MinLengthLogitsProcessor, NoRepeatNGramLogitsProcessor,
+                                                        RepetitionPenaltyLogitsProcessor)
+    from emu_amd.llama import ban_repeated_ngrams, process_logits
+    g = torch.Generator().manual_seed(8)
+    V = 40
+    for n in (1, 2, 3, 4):
+        for cur in (0, 1, 2, 3, 7, 15):
+            gen = torch.randint(3, 9, (4, cur), generator=g)             # a tiny alphabet: repeats are everywhere
+            scores = torch.randn(4, V, generator=g)
+            want = NoRepeatNGramLogitsProcessor(n)(gen, scores.clone())
+            got = ban_repeated_ngrams(scores.clone(), gen, n)
+            assert torch.equal(torch.isinf(got), torch.isinf(want)), (n, cur)
+            assert torch.equal(got[~torch.isinf(want)], want[~torch.isinf(want)])
+    gen = torch.randint(3, 9, (3, 6), generator=g)
+    scores = torch.randn(3, V, generator=g)
+    want = MinLengthLogitsProcessor(9, 2)(gen, NoRepeatNGramLogitsProcessor(2)(gen, RepetitionPenaltyLogitsProcessor(1.4)(gen, scores.clone())))
+    got = process_logits(scores.clone(), gen, True, 2, False, repetition_penalty=1.4, no_repeat_ngram_size=2)
+    assert torch.equal(torch.isinf(got), torch.isinf(want)) and torch.equal(got[~torch.isinf(want)], want[~torch.isinf(want)])
+
+
+def test_product_ngram_ban_and_several_returned_sequences_match_reference(golden_dir, monkeypatch):
+    """no_repeat_ngram_size = 2 with num_return_sequences = 2 through the PRODUCT's beam search on the CPU stand-in engine: ids of
+    the real reference (Emu2: EmuModel.generate forwards **kwargs, emu.py:175,228; fixture generate_margin_tiny.npz), 4 rows
+    prompt-major; the library's argument checks are mirrored."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_margin_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    x, mask = R.embed_tokens(t(z["pen_ids"]), W), t(z["pen_mask"])
+    out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 3, 8, no_repeat_ngram_size=2,
+                                             num_return_sequences=2)
+    assert out.tolist() == z["ngram_new"].tolist() and out.shape[0] == 4
+    for row in out.tolist():                                             # no bigram twice
+        big = list(zip(row, row[1:]))
+        assert len(big) == len(set(big)), row
+    with pytest.raises(ValueError):
+        L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 3, 8, num_return_sequences=4)
+    with pytest.raises(ValueError):
+        L.LlamaEngine.sample_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 4, do_sample=False, num_return_sequences=2)
+
+
+def test_emu1_num_captions_and_ngram_ban_match_real_reference(golden_dir, monkeypatch):
+    """Emu1's ``num_captions`` / ``no_repeat_ngram_size`` (Emu1/models/modeling_emu.py:110,115,173,176): the product's beam search
+    on the CPU stand-in engine, fed the oracle's visual embeddings, against the two captions of the REAL Emu1 class
+    (tests/golden/emu1_generate_tiny.npz: 5 beams, 8 tokens, bigram ban, length_penalty 0, whole model in bf16 under autocast).
+    The BEST caption must be the reference's.  The runner-up is decided by a pruning margin of 0.003 nat on this prompt (measured
+    with ``trace``), which the reference's autocast arithmetic and a plain bf16 / fp32 evaluation resolve differently, so for it
+    the library's guarantees are checked instead: distinct from the best, same length, no bigram twice, and the exact-id pin of
+    this mode is the margin-screened Emu2 fixture above."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from oracle import emu1_ref as E
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "emu1_generate_tiny.npz")
+    v, t5, l, vocab, W, cfg = tiny.emu1_generate_from(z)
+    Wb = R.cast_weights(W, torch.bfloat16)
+    ids, mask, img = (torch.from_numpy(np.asarray(z[k])) for k in ("ids", "mask", "image"))
+    x = R.embed_tokens(ids, Wb)
+    e = E.encode_image(img.to(torch.bfloat16), Wb, cfg)
+    x = R.scatter_image_embeds(x, ids, e.reshape(-1, e.shape[-1]))
+    monkeypatch.setattr(ops, "embed_gather", lambda i_, table, out=None: out.copy_(table[i_.long()]))
+    eng = FakeEngine(l, vocab, Wb, cfg.llama, dtype=torch.bfloat16)      # bf16 arithmetic, as the reference runs the model
+    tr = {}
+    out = L.LlamaEngine.beam_search_generate(eng, x, mask, 5, 8, length_penalty=0.0, no_repeat_ngram_size=2, num_return_sequences=2,
+                                             trace=tr)
+    want = z["beam_cap2_ngram2"].tolist()
+    assert out.shape == (2, 8) and out[0].tolist() == want[0]
+    if tr["margin"] >= 0.05:
+        assert out[1].tolist() == want[1]
+    assert out[1].tolist() != out[0].tolist()
+    for row in out.tolist() + want:
+        big = list(zip(row, row[1:]))
+        assert len(big) == len(set(big)), row
