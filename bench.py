@@ -49,9 +49,29 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-legs", action="store_true", help="skip the extra BASELINE-config legs (S=1544 prefill, generate_image, "
                                                           "VAE decode, any-to-image)")
+    p.add_argument("--pmc-prefill", type=int, default=0, metavar="N", help="profiling aid for rocprofv3 --pmc passes: load the decoder only, "
+                   "run exactly N prefills of the S=770 prompt shape and print the algorithmic bytes of their GEMMs")
     p.add_argument("--pmc-mode", type=int, default=0, metavar="N", help="profiling aid for rocprofv3 --pmc passes: after the "
                    "prefill run exactly N eager decode steps and print the algorithmic bytes of every GEMV launch of the process")
     return p.parse_args()
+
+
+def gemm_source_hash():
+    """sha256 over the sources of the MFMA GEMM kernels: the prefill leg's PMC traffic ratio is only quoted for exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm256.hip", "gemm_tile.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "emu_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def prefill_gemm_bytes(lcfg, S):
+    """Algorithmic bytes of the GEMMs of one S-token prefill: every weight once, every GEMM's activation operands once
+    (input rows, output rows, the residual of o_proj / down_proj)."""
+    H, F, L = lcfg.hidden_size, lcfg.intermediate_size, lcfg.num_hidden_layers
+    w = 4 * H * H + 3 * H * F
+    act = S * ((H + 3 * H) + (H + 2 * H) + (H + F) + (F + 2 * H))       # qkv | o (+res) | gate/up (SwiGLU output F) | down (+res)
+    return 2 * L * (w + act)
 
 
 def gemv_source_hash():
@@ -364,6 +384,20 @@ def main():
     import ctypes as C
 
     ctx = EmuHipContext(dev, rank, world)
+    if a.pmc_prefill:
+        from emu_amd.llama import LlamaEngine
+        lcfg = LlamaCfg(num_hidden_layers=a.layers)
+        lm = LlamaEngine(lcfg, VOCAB_EMU2_CHAT, ctx)
+        lm.load_weights(synth.iter_synth(synth.llama_param_shapes(lcfg, VOCAB_EMU2_CHAT), seed=0, device=dev, dtype=torch.bfloat16))
+        S = a.prompt_tokens + 258
+        x = (torch.randn(1, S, lcfg.hidden_size, device=dev) * 0.02).to(torch.bfloat16)
+        with torch.no_grad():
+            for _ in range(a.pmc_prefill):
+                lm.prefill(x, torch.ones(1, S, dtype=torch.long), lm.kv_capacity(S + 8))
+        torch.cuda.synchronize()
+        print(json.dumps({"pmc_prefill_calls": a.pmc_prefill, "S": S, "gemm_algorithmic_bytes_per_prefill": prefill_gemm_bytes(lcfg, S)}),
+              flush=True)
+        return
     if a.only_denoise:
         d = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None, a.unet_fusion)
         if rank == 0:
@@ -617,6 +651,17 @@ def main():
     except Exception as e:
         traffic_src = f"no PMC pass available ({type(e).__name__})"
 
+    prefill_traffic, prefill_traffic_src = None, "no PMC pass over the GEMM sources committed"
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_prefill_gemm_pmc_traffic.json")))
+        if pm.get("source_sha256") == gemm_source_hash():
+            prefill_traffic = float(pm["traffic_over_algorithmic"]) * prefill_gemm_bytes(lcfg, S)
+            prefill_traffic_src = ("profiles/r03_prefill_gemm_pmc_traffic.json (same kernel sources, sha256 checked): traffic / algorithmic GEMM bytes = "
+                                   f"{float(pm['traffic_over_algorithmic']):.3f}")
+        else:
+            prefill_traffic_src = "profiles/r03_prefill_gemm_pmc_traffic.json is STALE (other kernel sources): traffic not reported"
+    except Exception:
+        pass
     if rank == 0:
         prefill_flops = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
                                                    + 2 * S * S * lcfg.hidden_size)
@@ -642,7 +687,8 @@ def main():
                       "prefill_roofline": {"bound": "mfma", "achieved": prefill_flops / world / (min(prefill_ms, prefill_ms2) * 1e-3) / 1e12,
                                            "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                                            "frac": prefill_flops / world / (min(prefill_ms, prefill_ms2) * 1e-3) / MFMA_BF16_PEAK,
-                                           "flops": prefill_flops / world, "traffic": None},
+                                           "flops": prefill_flops / world, "traffic": prefill_traffic,
+                                           "traffic_source": prefill_traffic_src, "algorithmic_gemm_bytes": prefill_gemm_bytes(lcfg, S)},
                       "vit_roofline": {"bound": "mfma", "achieved": VIT_FLOPS_PER_IMAGE / (min(vit_ms, vit_ms2) * 1e-3) / 1e12,
                                        "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                                        "frac": VIT_FLOPS_PER_IMAGE / (min(vit_ms, vit_ms2) * 1e-3) / MFMA_BF16_PEAK,
