@@ -72,19 +72,29 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     // Workgroups [0, full_tiles) own whole tiles (XCD-aware bijective remap so the 8 L2s each see a compact set of
     // tiles); the rest are K-slices of the tail tiles (wave-quantisation fix: a 2.13-round problem would otherwise pay
     // for 3 rounds).  full_tiles == number of tiles and ksplit == 1 for an unsplit launch.
+    // The slice workgroups take the same remap over a slice-major order (slice ks of every tail tile, then ks + 1), which
+    // keeps the row tiles that read one slice of a weight column on one XCD.
     const int b = blockIdx.x;
+    const int tiles_m = (a.M + T::BMv - 1) / T::BMv;
+    auto xcd_order = [](int i, int n) {                              // i-th block of n -> its place in the logical order
+        const int xcd = i & 7, q8 = n >> 3, r8 = n & 7;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (i >> 3);
+    };
     int wg, ks = 0, nsl = 1;
     if (b < a.full_tiles) {
-        const int nwg = a.full_tiles;
-        const int xcd = b & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+        wg = xcd_order(b, a.full_tiles);
     } else {
-        const int j = b - a.full_tiles;
-        wg = a.full_tiles + j / a.ksplit;
-        ks = j - (wg - a.full_tiles) * a.ksplit;
         nsl = a.ksplit;
+        const int rest = tiles_m * ((a.N + T::BNv - 1) / T::BNv) - a.full_tiles;
+        const int l = xcd_order(b - a.full_tiles, rest * nsl);
+        ks = l / rest;
+        wg = a.full_tiles + (l - ks * rest);
+        if (a.slice_rr) {
+            const int j = b - a.full_tiles;
+            wg = a.full_tiles + j / nsl;
+            ks = j - (wg - a.full_tiles) * nsl;
+        }
     }
-    const int tiles_m = (a.M + T::BMv - 1) / T::BMv;
     const int n0 = (wg / tiles_m) * T::BNv, m0 = (wg % tiles_m) * T::BMv;
 
     // per-lane source of every LDS-DMA instruction: LDS row r = (i*NW + wave)*8 + lane/8, slot p = lane%8 receives global
@@ -545,6 +555,7 @@ template <int EPI, bool CONV>
 int launch_v2(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
+    a.slice_rr = (g_tune >> 1) & 1;
     if (a.cross_k) {                                   // the cross-attention epilogue lives on the 128 x 64 tile
         if constexpr (EPI == EPI_NONE && !CONV) { launch_cfg<EPI, CONV, CfgK>(a, s); EMU_CHECK_LAUNCH(); return 0; }
         return -22;

@@ -81,22 +81,34 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // workgroups [0, full_tiles): whole-K tiles, XCD-aware bijective remap; the rest: K-slices of the remaining tiles
+    // workgroups [0, full_tiles): whole-K tiles; the rest: K-slices of the remaining tiles.  Both ranges go through the
+    // XCD-aware bijective remap (block b runs on XCD b % 8; every XCD gets a contiguous run of the logical order), and the
+    // logical order keeps the tiles_m row tiles of one weight column -- of one K-slice of it -- adjacent, so that the
+    // workgroups reading the same weight bytes share one L2.  (Before round 3 the K-slices of a tile were dealt round-robin:
+    // the row tiles of a slice sat on different XCDs and FETCH_SIZE showed the S=770 o / down weights fetched ~2.6x.)
     const int b = blockIdx.x;
-    int wg, ks = 0, nsl = 1;
-    if (b < a.full_tiles) {
-        const int nwg = a.full_tiles;
-        const int xcd = b & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-    } else {
-        const int j = b - a.full_tiles;
-        wg = a.full_tiles + j / a.ksplit;
-        ks = j - (wg - a.full_tiles) * a.ksplit;
-        nsl = a.ksplit;
-    }
     int ext_rows;
     constexpr uint32_t ESZ = F8 ? 1u : 2u;                          // bytes per element
     const int tiles_m = pp_tiles_m(a.M, !CONV && !F8, ext_rows);
+    auto xcd_order = [](int i, int n) {                              // i-th block of n -> its place in the logical order
+        const int xcd = i & 7, q8 = n >> 3, r8 = n & 7;
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (i >> 3);
+    };
+    int wg, ks = 0, nsl = 1;
+    if (b < a.full_tiles) {
+        wg = xcd_order(b, a.full_tiles);
+    } else {
+        nsl = a.ksplit;
+        const int rest = tiles_m * ((a.N + 255) >> 8) - a.full_tiles;
+        const int l = xcd_order(b - a.full_tiles, rest * nsl);       // slice-major: slice ks of every remaining tile, then ks + 1
+        ks = l / rest;
+        wg = a.full_tiles + (l - ks * rest);
+        if (a.slice_rr) {
+            const int j = b - a.full_tiles;
+            wg = a.full_tiles + j / nsl;
+            ks = j - (wg - a.full_tiles) * nsl;
+        }
+    }
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
     // this workgroup also owns rows m0 + 256 .. M - 1 (never with the fused epilogues: gemm256_ok refuses that combination)

@@ -54,6 +54,8 @@ struct GemmArgs {
     int full_tiles = 0;     // set by launch_gemm: tiles [0, full_tiles) run whole-K (workgroups [0, full_tiles)); every
                             // later tile t is cut into ksplit slices (workgroup full_tiles + (t - full_tiles) * ksplit + ks)
                             // whose fp32 tiles land compactly at partial[((t - full_tiles) * ksplit + ks) * BM * BN]
+    int slice_rr = 0;       // A/B only (emu_gemm_tune bit 1): deal the slice workgroups tile by tile round-robin over the XCDs
+                            // (the order before round 3) instead of the XCD-aware slice-major order
     // ---- fused LayerNorm (UNet transformer blocks: removes the LayerNorm launch between two GEMMs)
     // Producer side: besides C, emit per-row partial (sum, sum of squares) of the bf16-rounded outputs, one pair per
     // 128-column slot: row_stats_out[(slot * M + m) * 2 + {0, 1}], slot = n / 128 (N % 128 == 0; EPI_NONE / EPI_RESID).

@@ -67,7 +67,9 @@ void emu_set_splitk_scratch(void* ptr, size_t bytes);
  * bench's true shapes with it (tests/test_gpu_ops.py); production code never calls it. */
 void emu_gemm_force_config(int cfg);
 /* Bench hook: A/B switches of single dispatch decisions (0 = the shipped heuristic).  Bit 0: GLU GEMMs that the heuristic
- * splits into whole rounds of the 256x256 tile + a remainder GEMM run as ONE launch of 128x128 tiles. */
+ * splits into whole rounds of the 256x256 tile + a remainder GEMM run as ONE launch of 128x128 tiles.  Bit 1: the K-slice
+ * workgroups of a split GEMM are dealt tile by tile round-robin over the XCDs (the order before round 3) instead of the
+ * XCD-aware slice-major order. */
 void emu_gemm_tune(int mask);
 
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while

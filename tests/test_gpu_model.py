@@ -19,6 +19,15 @@ def rel_err(got, want):
     return float((got - want).norm() / want.norm().clamp_min(1e-12))
 
 
+def _seq_logprob(W, cfg, prompt, new):
+    """Sum of the oracle's fp32 log-probabilities of ``new`` continuing the (unpadded) ``prompt``."""
+    from oracle import emu2_ref as R
+    ids = torch.cat([prompt.long(), new.long()])[None]
+    h = R.llama_model(R.embed_tokens(ids, W), torch.ones_like(ids), W, cfg.llama)
+    lp = torch.log_softmax(torch.nn.functional.linear(h[0, prompt.numel() - 1:-1], W["decoder.lm.lm_head.weight"]).float(), -1)
+    return float(lp.gather(1, new.long()[:, None]).sum())
+
+
 @pytest.fixture(scope="module")
 def tiny_model(golden_dir):
     """emu_amd.EmuModel (HIP) + oracle weights (fp32 tensors holding the same bf16 values)."""
@@ -178,7 +187,15 @@ def test_generate_beam_sampling_and_penalised_beams(tiny_model, golden_dir):
     # sequence of every prompt is the real reference's, no row repeats a bigram
     ng = m.generate_ids(_t(zm["pen_ids"]), _t(zm["pen_mask"]), None, max_new_tokens=8, num_beams=3, no_repeat_ngram_size=2,
                         num_return_sequences=2).cpu()
-    assert ng.shape == (4, 8) and ng[0::2].tolist() == zm["ngram_new"][0::2].tolist()
+    assert ng.shape == (4, 8)
+    # this search was not margin-screened: where the bf16 engine picks another best sequence than the reference, the two must be a
+    # near-tie in the ORACLE's fp32 arithmetic (sum of log-probabilities of the 8 tokens; no token is banned on either path).
+    # Measured: prompt 0's reference best and runner-up differ by 0.078 nat over 8 tokens and the bf16 engine swaps them
+    for b in range(2):
+        prompt = _t(zm["pen_ids"])[b][_t(zm["pen_mask"])[b].bool()]
+        got, want = ng[2 * b], _t(zm["ngram_new"])[2 * b]
+        if got.tolist() != want.tolist():
+            assert abs(_seq_logprob(W, cfg, prompt, got) - _seq_logprob(W, cfg, prompt, want)) < 0.15, (b, got.tolist(), want.tolist())
     for row in ng.tolist():
         big = list(zip(row, row[1:]))
         assert len(big) == len(set(big)), row

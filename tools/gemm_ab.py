@@ -6,7 +6,8 @@ determinism (race screen), and HIP-event timing on random data.
     python tools/gemm_ab.py [--cfgs 0,B,C,S,P,P1] [--iters 20] [--filter prefill] [--no-check]
 
 A configuration is a letter of emu_gemm_force_config ("0" = heuristic) optionally followed by the number of a schedule
-variant / timing ablation of the 256x256 tile (gemm256.hip; variants >= 2 are timing-only, their results are not checked).
+variant / timing ablation of the 256x256 tile (gemm256.hip; variants >= 2 are timing-only, their results are not checked),
+and by "t<N>" = run under emu_gemm_tune(N) (e.g. "0t2": the heuristic with the pre-round-3 K-slice order).
 """
 import argparse
 import os
@@ -98,7 +99,9 @@ def main():
         gemms = [("custom",) + tuple(int(v) for v in sh.split(",")) for sh in a.shapes.split(";")]
         convs = []
     names = a.cfgs.split(",")
-    cfgs = [0 if c == "0" else (ord(c[0]) | (int(c[1:] or 0) << 8)) for c in names]
+    tunes = [int(c.split("t")[1]) if "t" in c else 0 for c in names]          # "0t2" = heuristic under emu_gemm_tune(2)
+    names_c = [c.split("t")[0] for c in names]
+    cfgs = [0 if c == "0" else (ord(c[0]) | (int(c[1:] or 0) << 8)) for c in names_c]
     print(f"{'case':40s} " + " ".join(f"{('auto' if c == '0' else c):>14s}" for c in names))
     bad = 0
     for name, M, N, K, epi in gemms:
@@ -109,8 +112,9 @@ def main():
         res = r(M, N) if epi == 1 else None
         want = None if a.no_check else ref_linear(x, w, bias, res, epi)
         cells, outs = [], {}
-        for c in cfgs:
+        for c, tn in zip(cfgs, tunes):
             L.emu_gemm_force_config(c)
+            L.emu_gemm_tune(tn)
             fn = lambda: ops.linear(x, w, bias=bias, res=res, epi=epi)
             t = timeit(fn, a.iters if M * N * K > 1e9 else 3)
             tag = ""
@@ -145,8 +149,9 @@ def main():
                 xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
             want = bfr(F.conv2d(xi, w.float().permute(0, 3, 1, 2), stride=2 if mode == 2 else 1, padding=1)).permute(0, 2, 3, 1)
         cells = []
-        for c in cfgs:
+        for c, tn in zip(cfgs, tunes):
             L.emu_gemm_force_config(c)
+            L.emu_gemm_tune(tn)
             fn = lambda: ops.conv3x3_nhwc(x, w, mode=mode)
             t = timeit(fn, a.iters)
             tag = ""
@@ -161,6 +166,7 @@ def main():
             cells.append(f"{2.0 * B * Ho * Ho * Cout * 9 * Cin / t / 1e12:7.0f}TF{tag:>5s}")
         print(f"{name + f' {H}^2 {Cin}->{Cout} m{mode}':40s} " + " ".join(f"{c:>14s}" for c in cells), flush=True)
     L.emu_gemm_force_config(0)
+    L.emu_gemm_tune(0)
     print("FAILURES:", bad)
     return 1 if bad else 0
 
