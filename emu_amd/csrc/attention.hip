@@ -403,7 +403,106 @@ int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, i
 namespace {
 constexpr int DF_CHUNK = 128;                          // keys per workgroup (32 per wave)
 
+// One 128-key split of SHARED slots (beam search: the prompt's keys, stored in row b0 only) against the queries of all
+// nb beams of the group: the K / V rows are loaded once and stay in registers, the beams' rotated queries meet in LDS, and
+// every beam's split state is formed with the arithmetic (and summation order) of the one-row path below, so a shared
+// cache gives the same bits as nb replicated ones.  No append here: the new token's slot is never a shared one.
 template <int D>
+__device__ __forceinline__ void decode_shared_split(const DecodeFusedArgs& a, int nsplit, float (*sm)[D + 2], int split, int h,
+                                                    int b0, int kstart, int ctx) {
+    constexpr int LPK = D / 8, KPI = 64 / LPK, ITER = (DF_CHUNK / 4) / KPI, NP = 4 * KPI;
+    __shared__ float qs[DECODE_SHARE_MAX][D];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = lane / LPK, dl = lane % LPK, d0 = dl * 8;
+    const int nb = a.share_nb, k0 = split * DF_CHUNK;
+    const size_t hb = ((size_t)b0 * a.H + h) * a.S_max;
+    const bf16_t* kc = a.kcache + hb * D;
+    const bf16_t* vc = a.vcache + hb * D;
+    constexpr int half = D / 2;
+    // rotated query of beam tid / LPK, slice tid % LPK (loads first, like everything else here)
+    const bool qlane = tid < nb * LPK;
+    const int qb = qlane ? tid / LPK : 0, qd0 = (tid % LPK) * 8;
+    const int qdp = (qd0 + half) % D, qdc = qd0 % half;
+    const bf16_t* qh = a.qkv + (size_t)(b0 + qb) * 3 * a.H * D + (size_t)h * D;
+    const int qpos = a.pos[b0 + qb];
+    const u32x4 cv = ld16(a.cos + (size_t)qpos * D + qdc), sv = ld16(a.sin + (size_t)qpos * D + qdc);
+    const u32x4 q1v = ld16(qh + qd0), q2v = ld16(qh + qdp);
+    u32x4 kr[ITER], vr[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;           // < share_len <= S_max
+        kr[it] = ld16(kc + (size_t)key * D + d0);
+        vr[it] = ld16(vc + (size_t)key * D + d0);
+    }
+    if (qlane) {
+        float c[8], sn[8], x1[8], x2[8];
+        unpack8(cv, c); unpack8(sv, sn); unpack8(q1v, x1); unpack8(q2v, x2);
+        const float sgn = qd0 < half ? -1.f : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qs[qb][qd0 + j] = bfround(bfround(x1[j] * c[j]) + bfround(sgn * x2[j] * sn[j]));
+    }
+    __syncthreads();
+    for (int jb = 0; jb < nb; ++jb) {
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = qs[jb][d0 + j];
+        float sd[ITER];
+        float m = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
+            const bool valid = key < ctx && key >= kstart;
+            float kf[8];
+            unpack8(kr[it], kf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[j] = valid ? kf[j] : 0.f;
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t = fmaf(kf[j], q[j], t);
+            t = LPK == 16 ? row16_sum(t) : row8_sum(t);
+            sd[it] = valid ? t * a.scale : -INFINITY;
+            m = fmaxf(m, sd[it]);
+        }
+        float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            float vf[8];
+            unpack8(vr[it], vf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vf[j] = sd[it] == -INFINITY ? 0.f : vf[j];
+            const float p = sd[it] == -INFINITY ? 0.f : __expf(sd[it] - m);
+            l += p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+        }
+        {
+            float* dst = sm[wave * KPI + g];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[d0 + j] = acc[j];
+            if (dl == 0) { dst[D] = m; dst[D + 1] = l; }
+        }
+        __syncthreads();
+        if (tid < D) {
+            float num = 0.f, den = 0.f, mt = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NP; ++w) mt = fmaxf(mt, sm[w][D]);
+#pragma unroll
+            for (int w = 0; w < NP; ++w) {
+                const float f = (sm[w][D] == -INFINITY) ? 0.f : __expf(sm[w][D] - mt);
+                num = fmaf(f, sm[w][tid], num);
+                den = fmaf(f, sm[w][D + 1], den);
+            }
+            float* wout = a.ws + (((size_t)(b0 + jb) * a.H + h) * nsplit + split) * (D + 2);
+            wout[tid] = num;
+            if (tid == 0) { wout[D] = mt; wout[D + 1] = den; }
+        }
+        __syncthreads();                               // sm is reused by the next beam
+    }
+}
+
+// SHARE: the launch has beam groups (a.share_nb > 1); a separate instantiation so that the one-row-per-sequence launches
+// (greedy decode, the headline path) keep their registers and occupancy.
+template <int D, bool SHARE>
 __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs a, int nsplit) {
     constexpr int LPK = D / 8;                         // lanes per key row (16 bytes each): 16 (D=128) or 8 (D=64)
     constexpr int KPI = 64 / LPK;                      // keys per wave iteration
@@ -417,6 +516,15 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     const int k0 = split * DF_CHUNK;
     if (k0 >= ctx) return;                             // split beyond the live context: no work, not counted
     const int kstart = a.kstart ? a.kstart[b] : 0;
+    // beams of one prompt: slots [0, share_len) live in the group's first row b0 only
+    const int b0 = SHARE ? b - b % a.share_nb : b;
+    const int nshare = SHARE ? a.share_len : 0;
+    if constexpr (SHARE) {
+        if (k0 + DF_CHUNK <= nshare) {                 // a split of shared slots: the first row's workgroup serves the group
+            if (b == b0) decode_shared_split<D>(a, nsplit, sm, split, h, b0, kstart, ctx);
+            return;
+        }
+    }
     const int pos = a.pos[b];
     const bf16_t* row = a.qkv + (size_t)b * 3 * a.H * D;
     const bf16_t* qh = row + (size_t)h * D;
@@ -428,6 +536,7 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     const size_t hb = ((size_t)b * a.H + h) * a.S_max;
     const bf16_t* kc = a.kcache + hb * D;
     const bf16_t* vc = a.vcache + hb * D;
+    const long to_b0 = -(long)(b - b0) * a.H * a.S_max * D;        // from this row's cache to the group's first row
 
     // ---- every load of the block is issued before anything is consumed: RoPE inputs first (the in-order vmcnt lets
     // the rotation start while the K/V rows are still in flight), then this wave's 32 keys (LPK lanes cover one row)
@@ -440,8 +549,9 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     for (int it = 0; it < ITER; ++it) {
         const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
         const int kc_i = key < a.S_max ? key : a.S_max - 1;
-        kr[it] = ld16(kc + (size_t)kc_i * D + d0);
-        vr[it] = ld16(vc + (size_t)kc_i * D + d0);
+        const long off = (long)kc_i * D + d0 + (SHARE && key < nshare ? to_b0 : 0);   // the straddling split's shared keys
+        kr[it] = ld16(kc + off);
+        vr[it] = ld16(vc + off);
     }
     // ---- RoPE of q and of the new key (this lane's 8-wide slice), transformers' rounding points
     float c[8], sn[8], q[8], nk[8], nv[8];
@@ -550,12 +660,16 @@ size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max) {
 
 int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s) {
     if (a.ctx_max < 1 || a.ctx_max > a.S_max) return -22;
+    if (a.share_nb > 1 && (a.share_nb > DECODE_SHARE_MAX || a.B % a.share_nb || a.share_len < 0 || a.share_len > a.S_max)) return -22;
     const int ns = (a.ctx_max + DF_CHUNK - 1) / DF_CHUNK;
+    const bool share = a.share_nb > 1;
     if (a.D == 128) {
-        hipLaunchKernelGGL(decode_fused_kernel<128>, dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        if (share) hipLaunchKernelGGL((decode_fused_kernel<128, true>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        else hipLaunchKernelGGL((decode_fused_kernel<128, false>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
         hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else if (a.D == 64) {
-        hipLaunchKernelGGL(decode_fused_kernel<64>, dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        if (share) hipLaunchKernelGGL((decode_fused_kernel<64, true>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        else hipLaunchKernelGGL((decode_fused_kernel<64, false>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
         hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else return -22;
     EMU_CHECK_LAUNCH();

@@ -303,6 +303,7 @@ struct emu_llama {
     const bf16_t *final_norm = nullptr, *lm_head = nullptr, *embed = nullptr, *cos = nullptr, *sin = nullptr;
     bf16_t *kcache = nullptr, *vcache = nullptr;
     int kv_batch = 0, s_max = 0;
+    int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
 };
 
 namespace {
@@ -407,6 +408,15 @@ int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head
 int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max) {
     if (!m || batch < 1 || s_max < 1) return -22;
     m->kcache = B(kcache); m->vcache = B(vcache); m->kv_batch = batch; m->s_max = s_max;
+    m->kv_share_nb = m->kv_share_len = 0;
+    return 0;
+}
+int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots) {
+    if (!m) return -22;
+    if (beams <= 1) { m->kv_share_nb = m->kv_share_len = 0; return 0; }
+    if (beams > DECODE_SHARE_MAX || !m->kcache || m->kv_batch % beams || shared_slots < 0 || shared_slots > m->s_max)
+        return fail(m->ctx, -22, "emu_llama_set_kv_share: 2..8 beams dividing the cache batch, shared slots within the capacity");
+    m->kv_share_nb = beams; m->kv_share_len = shared_slots;
     return 0;
 }
 size_t emu_llama_workspace_bytes(const emu_llama* m, int Bn, int T) {
@@ -457,9 +467,10 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         if (T == 1) {
             // RoPE + KV append + attention in one launch; context = slot + 1 is read on the device (graph replay)
             DecodeFusedArgs a{w.qkv, m->cos, m->sin, pos, slot, kc, vc, w.attn, (long)HD, (long)D, kstart, w.dec,
-                              Bn, Hl, D, m->s_max, ctx, scale};
+                              Bn, Hl, D, m->s_max, ctx, scale, m->kv_share_nb, m->kv_share_len};
             TRY(cx, launch_decode_fused(a, s));
         } else {
+            if (m->kv_share_nb > 1) return fail(cx, -22, "emu_llama_forward: shared-prefix KV rows serve single-token steps only");
             { RopeKvArgs r{w.qkv, m->cos, m->sin, pos, slot, kc, vc, Bn, T, Hl, D, m->s_max};
               TRY(cx, launch_rope_kv(r, s)); }
             TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, w.vt, Bn, Hl, ctx, D, spad};

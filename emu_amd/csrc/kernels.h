@@ -184,7 +184,13 @@ struct DecodeFusedArgs {
     float* ws;                                 // decode_fused_ws_floats(B, H, D, ctx_max)
     int B, H, D, S_max, ctx_max;               // ctx_max sizes the launch (>= max slot + 1)
     float scale;
+    // Beam search: rows come in groups of share_nb beams of one prompt whose first share_len cache slots (the prompt) are
+    // identical.  They are stored ONCE, in the group's first row, and a 128-key split that lies inside them is read once
+    // and scored against the queries of all the group's beams by one workgroup.  Rows of a group must agree in slot,
+    // pos and kstart.  share_nb <= 1: every row owns all of its slots.
+    int share_nb = 0, share_len = 0;
 };
+constexpr int DECODE_SHARE_MAX = 8;            // beams per group the shared-prefix path takes
 size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max);
 int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s);
 

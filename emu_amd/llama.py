@@ -252,6 +252,7 @@ class LlamaEngine:
 
     def alloc_kv(self, batch: int, s_max: int) -> None:
         if batch == self.kv_batch and s_max == self.s_max and self.kcache is not None:
+            self.set_kv_share(0, 0)
             return
         L, Hl, D = self.cfg.num_hidden_layers, self.plan.heads_local, self.cfg.head_dim
         self.kcache = torch.zeros(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
@@ -260,6 +261,34 @@ class LlamaEngine:
         check(lib().emu_llama_set_kv(self.handle, self.kcache.data_ptr(), self.vcache.data_ptr(), batch, s_max),
               "emu_llama_set_kv")
         self._ws = None
+
+    KV_SHARE_MAX = 8                                   # DECODE_SHARE_MAX of the decode attention kernel
+
+    def set_kv_share(self, rows_per_prompt: int, shared_slots: int) -> None:
+        """Groups of ``rows_per_prompt`` consecutive cache rows keep their first ``shared_slots`` slots (the prompt) in the
+        group's first row only (include/emu_hip.h: emu_llama_set_kv_share); (0, 0) = every row owns its slots."""
+        if rows_per_prompt <= 1 and not getattr(self, "_kv_share", False):
+            return
+        check(lib().emu_llama_set_kv_share(self.handle, int(rows_per_prompt), int(shared_slots)), "emu_llama_set_kv_share")
+        self._kv_share = rows_per_prompt > 1
+
+    def fan_out_kv(self, B: int, n: int, S: int, s_max: int) -> None:
+        """After a prefill of B prompts: a cache of B * n rows (n beams / candidates per prompt) that continue the prompts.
+        transformers copies the prompt's keys and values to every beam (``_expand_inputs_for_generation``); here, for
+        n <= 8, they stay in ONE row per prompt and the decode attention reads them from there (``set_kv_share``): no n-fold
+        copy (6 GB at S = 770, 5 beams, 60 layers) and the prompt's keys cross the memory system once per step, not n times."""
+        k_old, v_old = self.kcache, self.vcache
+        self.kcache = self.vcache = None
+        self.alloc_kv(B * n, s_max)
+        if 2 <= n <= self.KV_SHARE_MAX:
+            first = torch.arange(B, device=self.device) * n
+            self.kcache[:, first, :, :S] = k_old[:, :, :, :S]
+            self.vcache[:, first, :, :S] = v_old[:, :, :, :S]
+            self.set_kv_share(n, S)
+        else:
+            rep = torch.arange(B, device=self.device).repeat_interleave(n)
+            self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
+            self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         need = lib().emu_llama_workspace_bytes(self.handle, B, T)
@@ -450,13 +479,7 @@ class LlamaEngine:
         ctx_h = self.final_norm_rows(hidden.reshape(B * S, H).contiguous()).view(B, S, H).float()
         ctx_ok = torch.arange(S, device=dev)[None, :] >= kstart[:, None].to(dev)
         logit = self.logits(hidden[:, -1, :]).float()
-        k_old, v_old = self.kcache, self.vcache
-        self.kcache = self.vcache = None
-        self.alloc_kv(B * k, s_max)
-        rep = torch.arange(B, device=dev).repeat_interleave(k)
-        self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
-        self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
-        del k_old, v_old
+        self.fan_out_kv(B, k, S, s_max)
         kstart_k = kstart.repeat_interleave(k).contiguous()
         pos = next_pos.repeat_interleave(k).contiguous()
         out = torch.full((B, max_new_tokens), pad_id, dtype=torch.int64, device=dev)
@@ -504,6 +527,7 @@ class LlamaEngine:
             ctx_ok = torch.cat((ctx_ok, torch.ones(B, 1, dtype=torch.bool, device=dev)), dim=1)
             logit = cand_logits[ar, sel]
             pos = pos + 1
+        self.set_kv_share(0, 0)
         self.ctx.check_p2p()
         return out[:, :n]
 
@@ -521,8 +545,9 @@ class LlamaEngine:
         transformers' vectorised beam search: per step keep the 2N best continuations over beams x vocab, the N best
         non-finished ones keep running, finished ones (EOS, or the length limit) compete for the N result slots with
         score / len**length_penalty, and the loop ends when no running beam can beat the worst kept result.
-        One prefill for the B prompts; the KV cache is then replicated per beam and re-ordered by beam index each
-        step (rows are gathered on the device).  Returns the best sequence per prompt [B, <= max_new_tokens].
+        One prefill for the B prompts; every beam then gets a cache row, of which only the GENERATED slots are its own
+        (the prompt's stay in one row per prompt, ``fan_out_kv``) and are re-ordered by beam index each step (gathered on
+        the device).  Returns the best sequence per prompt [B, <= max_new_tokens].
 
         ``do_sample=True`` is the library's *beam-search multinomial sampling*: the per-beam log-probabilities go through
         the logits pipeline (repetition penalty, min length, temperature / top-k / top-p with min_tokens_to_keep = 2)
@@ -554,14 +579,8 @@ class LlamaEngine:
         s_max = self.kv_capacity(S + max_new_tokens)
         hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
         logits = self.logits(hidden[:, -1, :]).float()                                  # [B, V]
-        # replicate the prompt's KV rows for every beam: row b*nb + j <- row b
-        k_old, v_old = self.kcache, self.vcache
-        self.kcache = self.vcache = None
-        self.alloc_kv(B * nb, s_max)
-        rep = torch.arange(B, device=dev).repeat_interleave(nb)
-        self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
-        self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
-        del k_old, v_old
+        # rows b*nb .. b*nb + nb - 1 are the beams of prompt b; its keys / values stay in the first of them (fan_out_kv)
+        self.fan_out_kv(B, nb, S, s_max)
         kstart_b = kstart.repeat_interleave(nb).contiguous()
         pos = next_pos.repeat_interleave(nb).contiguous()
 
@@ -643,8 +662,8 @@ class LlamaEngine:
             # advance the model: reorder the cache rows by beam, feed the chosen tokens
             flat = (beam_idx + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
             ctx = S + cur - 1
-            # beams of one prompt share the prompt's KV rows (replicated above and identical), so only the generated
-            # slots [S, ctx) move with the beam permutation -- a few KB per layer instead of the whole live cache
+            # beams of one prompt share the prompt's KV slots, so only the generated slots [S, ctx) move with the beam
+            # permutation -- a few KB per layer instead of the whole live cache
             if ctx > S:
                 self.kcache[:, :, :, S:ctx] = self.kcache[:, flat, :, S:ctx]
                 self.vcache[:, :, :, S:ctx] = self.vcache[:, flat, :, S:ctx]
@@ -654,6 +673,7 @@ class LlamaEngine:
             self.forward(hid, B * nb, 1, pos, slot, kstart_b, ctx=ctx + 1)
             pos = pos + 1
             lp_rows = self.logits(hid).float().view(B, nb, V)
+        self.set_kv_share(0, 0)
         nret = int(num_return_sequences)
         out_len = int(seq_len[:, :nret].max().item())
         if trace is not None:

@@ -215,6 +215,13 @@ int emu_llama_use_fp8(emu_llama* m, int enable);
 int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed,
                        const void* rope_cos, const void* rope_sin);
 int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max);
+/* Beam search (the reference's default decoding mode: lm.generate(num_beams=5), Emu2/emu/emu.py:163-172,213-229; transformers
+ * replicates the prompt's cache per beam with expand_inputs / _reorder_cache).  Here cache rows come in groups of `beams`
+ * consecutive rows of one prompt whose first `shared_slots` slots (the prompt) are stored ONCE, in the group's first row:
+ * single-token steps read them from there, one workgroup scoring a 128-key split against all the group's queries, and
+ * only slots >= shared_slots are per-row.  Rows of a group must agree in pos / slot / kstart.  beams <= 1 switches it off
+ * (emu_llama_set_kv does too).  -22 for beams > 8, a batch the group size does not divide, or slots beyond the capacity. */
+int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
 /* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
  * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).

@@ -25,12 +25,28 @@ class FakeEngine:
 
     KV_BUCKETS = LlamaEngine.KV_BUCKETS
     kv_capacity = LlamaEngine.kv_capacity            # the product's own bucket logic
+    KV_SHARE_MAX = LlamaEngine.KV_SHARE_MAX
+    fan_out_kv = LlamaEngine.fan_out_kv              # ... and its own cache fan-out for beams / candidates
+
+    def set_kv_share(self, rows_per_prompt, shared_slots):
+        """Like the device engine: groups of rows keep slots [0, shared_slots) in the group's first row only."""
+        self.share = (int(rows_per_prompt), int(shared_slots)) if rows_per_prompt > 1 else (0, 0)
+
+    def _rows(self, cache_l, B, n_past):
+        """Layer cache rows [B, H, n_past, D] as the attention sees them (shared slots come from the group's first row)."""
+        out = cache_l[:B, :, :n_past].clone()
+        n, sh = getattr(self, "share", (0, 0))
+        if n > 1:
+            first = (torch.arange(B) // n) * n
+            out[:, :, :min(sh, n_past)] = cache_l[first, :, :min(sh, n_past)]
+        return out
 
     def alloc_kv(self, batch, s_max):
         L, H, D = self.rcfg.layers, self.rcfg.heads, self.rcfg.head_dim
         self.kcache = torch.zeros(L, batch, H, s_max, D, dtype=self.dtype)
         self.vcache = torch.zeros(L, batch, H, s_max, D, dtype=self.dtype)
         self.kv_batch, self.s_max = batch, s_max
+        self.share = (0, 0)
 
     def _run(self, x, pos, n_past, kstart):
         """x [B,T,H]; writes k/v of the T new slots at [n_past, n_past+T)."""
@@ -38,8 +54,8 @@ class FakeEngine:
         cache = R.KVCache(self.rcfg.layers)
         if n_past > 0:
             for i in range(self.rcfg.layers):
-                cache.k[i] = self.kcache[i, :B, :, :n_past].clone()
-                cache.v[i] = self.vcache[i, :B, :, :n_past].clone()
+                cache.k[i] = self._rows(self.kcache[i], B, n_past)
+                cache.v[i] = self._rows(self.vcache[i], B, n_past)
         mask = (torch.arange(n_past + T)[None, :] >= kstart[:, None]).long()
         h = R.llama_model(x, mask, self.W, self.rcfg, position_ids=pos.long().view(B, T), cache=cache, final_norm=False)
         for i in range(self.rcfg.layers):

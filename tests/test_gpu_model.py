@@ -390,6 +390,46 @@ def test_decode_attention_paths(heads, D, s_max, S, pad):
     assert rel_err(step, want) < 2e-2, rel_err(step, want)
 
 
+@pytest.mark.parametrize("heads,D,S,pad,nb", [(4, 128, 300, 7, 5), (4, 128, 256, 0, 3), (2, 64, 131, 3, 8), (4, 128, 100, 0, 2)])
+def test_beam_rows_share_the_prompt_cache_bit_exact(heads, D, S, pad, nb, monkeypatch):
+    """Beam search / contrastive search keep the prompt's keys and values in ONE cache row per prompt (emu_llama_set_kv_share):
+    splits inside the prompt are scored for all beams of a group by one workgroup, the split straddling the prompt's end takes
+    its shared keys from the group's first row.  Two single-token steps (the second one reads a generated slot per beam) must
+    give the bits of the replicated cache: prompts of 1..3 splits, ending inside / on a split edge, left padding, both head dims,
+    2..8 beams, batch of two prompts."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import LlamaCfg
+    from emu_amd.llama import EmuHipContext, LlamaEngine
+    l = LlamaCfg(hidden_size=heads * D, intermediate_size=256, num_attention_heads=heads, num_hidden_layers=2)
+    W = synth.synth_state_dict(synth.llama_param_shapes(l, 64), seed=S)
+    eng = LlamaEngine(l, 64, EmuHipContext(torch.device("cuda", 0)))
+    eng.load_weights(W.items())
+    g = torch.Generator().manual_seed(S + nb)
+    x = torch.randn(2, S, l.hidden_size, generator=g).to(BF16).cuda()
+    steps = [torch.randn(2 * nb, l.hidden_size, generator=g).to(BF16).cuda() for _ in range(2)]
+    mask = torch.ones(2, S, dtype=torch.long)
+    if pad:
+        mask[1, :pad] = 0
+    outs = {}
+    for mode in ("shared", "replicated"):
+        monkeypatch.setattr(LlamaEngine, "KV_SHARE_MAX", 8 if mode == "shared" else 0)
+        s_max = eng.kv_capacity(S + 4)
+        _, kstart, pos = eng.prefill(x, mask, s_max=s_max)
+        eng.fan_out_kv(2, nb, S, s_max)
+        assert bool(getattr(eng, "_kv_share", False)) == (mode == "shared")
+        if mode == "shared":                                          # nothing but the group's first row holds the prompt
+            assert float(eng.kcache[:, 1:nb, :, :S].abs().max()) == 0.0 and float(eng.kcache[:, 0, :, int(kstart[0]):S].abs().max()) > 0.0
+        ks, p = kstart.repeat_interleave(nb).contiguous(), pos.repeat_interleave(nb).contiguous()
+        got = []
+        for i, e in enumerate(steps):
+            got.append(eng.decode_embeds(e.clone(), p + i, S + i, ks).clone())
+        outs[mode] = got
+        eng.set_kv_share(0, 0)
+    for a_, b_ in zip(outs["shared"], outs["replicated"]):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(outs["shared"][0][0], outs["shared"][0][1])           # beams do differ
+
+
 def test_rccl_single_rank_path_eager_and_graph(golden_dir):
     """The tensor-parallel code path (ncclAllReduce on the launch stream after o_proj / down_proj, also inside hipGraph
     capture) with a 1-rank RCCL communicator: must reproduce the reference's greedy ids exactly."""
