@@ -403,18 +403,19 @@ int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, i
 namespace {
 constexpr int DF_CHUNK = 128;                          // keys per workgroup (32 per wave)
 
-// One 128-key split of SHARED slots (beam search: the prompt's keys, stored in row b0 only) against the queries of all
-// nb beams of the group: the K / V rows are loaded once and stay in registers, the beams' rotated queries meet in LDS, and
-// every beam's split state is formed with the arithmetic (and summation order) of the one-row path below, so a shared
-// cache gives the same bits as nb replicated ones.  No append here: the new token's slot is never a shared one.
-template <int D>
-__device__ __forceinline__ void decode_shared_split(const DecodeFusedArgs& a, int nsplit, float (*sm)[D + 2], int split, int h,
-                                                    int b0, int kstart, int ctx) {
+// One 128-key split of SHARED slots (beam search: the prompt's keys, stored in the group's first row b0 only) against the
+// queries of all the group's beams (<= NB): the K / V rows are loaded once and stay in registers, every beam's split state is
+// formed with the arithmetic and the summation order of the one-row path below (so a shared cache gives the bits of
+// replicated ones), the beams' states meet in LDS behind ONE barrier.  No append here: the new token's slot is never shared.
+template <int D, int NB>
+__device__ __forceinline__ void decode_shared_split(const DecodeFusedArgs& a, int nsplit, int split, int h, int b0) {
     constexpr int LPK = D / 8, KPI = 64 / LPK, ITER = (DF_CHUNK / 4) / KPI, NP = 4 * KPI;
-    __shared__ float qs[DECODE_SHARE_MAX][D];
+    __shared__ float st[NB][NP][D + 2];
+    __shared__ float qs[NB][D];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane / LPK, dl = lane % LPK, d0 = dl * 8;
     const int nb = a.share_nb, k0 = split * DF_CHUNK;
+    const int ctx = a.slot[b0] + 1, kstart = a.kstart ? a.kstart[b0] : 0;
     const size_t hb = ((size_t)b0 * a.H + h) * a.S_max;
     const bf16_t* kc = a.kcache + hb * D;
     const bf16_t* vc = a.vcache + hb * D;
@@ -442,74 +443,106 @@ __device__ __forceinline__ void decode_shared_split(const DecodeFusedArgs& a, in
         for (int j = 0; j < 8; ++j) qs[qb][qd0 + j] = bfround(bfround(x1[j] * c[j]) + bfround(sgn * x2[j] * sn[j]));
     }
     __syncthreads();
-    for (int jb = 0; jb < nb; ++jb) {
-        float q[8];
+    float q[NB][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) q[j] = qs[jb][d0 + j];
-        float sd[ITER];
-        float m = -INFINITY;
+    for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
-            const bool valid = key < ctx && key >= kstart;
-            float kf[8];
-            unpack8(kr[it], kf);
+        for (int j = 0; j < 8; ++j) q[jb][j] = jb < nb ? qs[jb][d0 + j] : 0.f;
+    float sd[NB][ITER], m[NB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kf[j] = valid ? kf[j] : 0.f;
+    for (int jb = 0; jb < NB; ++jb) m[jb] = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
+        const bool valid = key < ctx && key >= kstart;
+        float kf[8];
+        unpack8(kr[it], kf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = valid ? kf[j] : 0.f;
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
             float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t = fmaf(kf[j], q[j], t);
+            for (int j = 0; j < 8; ++j) t = fmaf(kf[j], q[jb][j], t);
             t = LPK == 16 ? row16_sum(t) : row8_sum(t);
-            sd[it] = valid ? t * a.scale : -INFINITY;
-            m = fmaxf(m, sd[it]);
+            sd[jb][it] = valid ? t * a.scale : -INFINITY;
+            m[jb] = fmaxf(m[jb], sd[jb][it]);
         }
-        float l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float l[NB], acc[NB][8];
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            float vf[8];
-            unpack8(vr[it], vf);
+    for (int jb = 0; jb < NB; ++jb) {
+        l[jb] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vf[j] = sd[it] == -INFINITY ? 0.f : vf[j];
-            const float p = sd[it] == -INFINITY ? 0.f : __expf(sd[it] - m);
-            l += p;
+        for (int j = 0; j < 8; ++j) acc[jb][j] = 0.f;
+    }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+    for (int it = 0; it < ITER; ++it) {
+        float vf[8];
+        unpack8(vr[it], vf);
+        const bool dead = sd[0][it] == -INFINITY;                             // validity is the same for every beam
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vf[j] = dead ? 0.f : vf[j];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            const float p = dead ? 0.f : __expf(sd[jb][it] - m[jb]);
+            l[jb] += p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[jb][j] = fmaf(p, vf[j], acc[jb][j]);
         }
-        {
-            float* dst = sm[wave * KPI + g];
+    }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dst[d0 + j] = acc[j];
-            if (dl == 0) { dst[D] = m; dst[D + 1] = l; }
+    for (int jb = 0; jb < NB; ++jb) {
+        float* dst = st[jb][wave * KPI + g];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[d0 + j] = acc[jb][j];
+        if (dl == 0) { dst[D] = m[jb]; dst[D + 1] = l[jb]; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nb * D; idx += 256) {
+        const int jb = idx / D, d = idx - jb * D;
+        float num = 0.f, den = 0.f, mt = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NP; ++w) mt = fmaxf(mt, st[jb][w][D]);
+#pragma unroll
+        for (int w = 0; w < NP; ++w) {
+            const float f = (st[jb][w][D] == -INFINITY) ? 0.f : __expf(st[jb][w][D] - mt);
+            num = fmaf(f, st[jb][w][d], num);
+            den = fmaf(f, st[jb][w][D + 1], den);
         }
-        __syncthreads();
-        if (tid < D) {
-            float num = 0.f, den = 0.f, mt = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < NP; ++w) mt = fmaxf(mt, sm[w][D]);
-#pragma unroll
-            for (int w = 0; w < NP; ++w) {
-                const float f = (sm[w][D] == -INFINITY) ? 0.f : __expf(sm[w][D] - mt);
-                num = fmaf(f, sm[w][tid], num);
-                den = fmaf(f, sm[w][D + 1], den);
-            }
-            float* wout = a.ws + (((size_t)(b0 + jb) * a.H + h) * nsplit + split) * (D + 2);
-            wout[tid] = num;
-            if (tid == 0) { wout[D] = mt; wout[D + 1] = den; }
-        }
-        __syncthreads();                               // sm is reused by the next beam
+        float* wout = a.ws + (((size_t)(b0 + jb) * a.H + h) * nsplit + split) * (D + 2);
+        wout[d] = num;
+        if (d == 0) { wout[D] = mt; wout[D + 1] = den; }
     }
 }
 
-// SHARE: the launch has beam groups (a.share_nb > 1); a separate instantiation so that the one-row-per-sequence launches
-// (greedy decode, the headline path) keep their registers and occupancy.
-template <int D, bool SHARE>
+// NB > 0: the rows are beam groups (a.share_nb in 2..NB) whose shared slots (the prompt) are stored in the group's first row
+// only (DecodeFusedArgs).  The launch is one-dimensional: first one workgroup per (shared split, head, GROUP), then one per
+// (other split, head, row) as in the one-row form, whose split that straddles the end of the prompt takes its shared keys
+// from the group's first row.  A separate instantiation, so the one-row launches (greedy decode: the headline path) keep
+// their registers and occupancy.
+template <int D, int NB>
 __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs a, int nsplit) {
+    constexpr bool SHARE = NB > 0;
     constexpr int LPK = D / 8;                         // lanes per key row (16 bytes each): 16 (D=128) or 8 (D=64)
     constexpr int KPI = 64 / LPK;                      // keys per wave iteration
     constexpr int ITER = (DF_CHUNK / 4) / KPI;
     constexpr int NP = 4 * KPI;                        // partial states per block: (wave, key group)
     __shared__ float sm[NP][D + 2];
-    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    if constexpr (SHARE) {
+        const int nsh = a.share_len / DF_CHUNK, ngrp = a.B / a.share_nb;       // whole splits of shared slots
+        int L = blockIdx.x;
+        if (L < nsh * a.H * ngrp) {
+            decode_shared_split<D, NB>(a, nsplit, L % nsh, (L / nsh) % a.H, (L / (nsh * a.H)) * a.share_nb);
+            return;
+        }
+        L -= nsh * a.H * ngrp;
+        const int nrest = nsplit - nsh;
+        split = nsh + L % nrest;
+        h = (L / nrest) % a.H;
+        b = L / (nrest * a.H);
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane / LPK, dl = lane % LPK, d0 = dl * 8;
     const int slot = a.slot[b], ctx = slot + 1;
@@ -519,12 +552,6 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     // beams of one prompt: slots [0, share_len) live in the group's first row b0 only
     const int b0 = SHARE ? b - b % a.share_nb : b;
     const int nshare = SHARE ? a.share_len : 0;
-    if constexpr (SHARE) {
-        if (k0 + DF_CHUNK <= nshare) {                 // a split of shared slots: the first row's workgroup serves the group
-            if (b == b0) decode_shared_split<D>(a, nsplit, sm, split, h, b0, kstart, ctx);
-            return;
-        }
-    }
     const int pos = a.pos[b];
     const bf16_t* row = a.qkv + (size_t)b * 3 * a.H * D;
     const bf16_t* qh = row + (size_t)h * D;
@@ -549,7 +576,7 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     for (int it = 0; it < ITER; ++it) {
         const int key = k0 + wave * (DF_CHUNK / 4) + it * KPI + g;
         const int kc_i = key < a.S_max ? key : a.S_max - 1;
-        const long off = (long)kc_i * D + d0 + (SHARE && key < nshare ? to_b0 : 0);   // the straddling split's shared keys
+        const long off = (long)kc_i * D + d0 + (SHARE && key < nshare ? to_b0 : 0);   // shared slots: the group's first row
         kr[it] = ld16(kc + off);
         vr[it] = ld16(vc + off);
     }
@@ -660,16 +687,35 @@ size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max) {
 
 int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s) {
     if (a.ctx_max < 1 || a.ctx_max > a.S_max) return -22;
-    if (a.share_nb > 1 && (a.share_nb > DECODE_SHARE_MAX || a.B % a.share_nb || a.share_len < 0 || a.share_len > a.S_max)) return -22;
+    // shared slots are prompt slots: the new token's slot (< ctx_max) is never one of them
+    if (a.share_nb > 1 && (a.share_nb > DECODE_SHARE_MAX || a.B % a.share_nb || a.share_len < 0 || a.share_len >= a.ctx_max)) return -22;
     const int ns = (a.ctx_max + DF_CHUNK - 1) / DF_CHUNK;
-    const bool share = a.share_nb > 1;
+    if (a.share_nb > 1) {
+        const int nsh = a.share_len / DF_CHUNK;         // < ns: share_len < ctx_max (checked above)
+        const dim3 grid(nsh * a.H * (a.B / a.share_nb) + (ns - nsh) * a.H * a.B);
+#define EMU_SHARE_CASE(DD, NBT) hipLaunchKernelGGL((decode_fused_kernel<DD, NBT>), grid, dim3(256), 0, s, a, ns)
+        if (a.D == 128) {
+            if (a.share_nb <= 2) EMU_SHARE_CASE(128, 2);
+            else if (a.share_nb <= 4) EMU_SHARE_CASE(128, 4);
+            else if (a.share_nb <= 5) EMU_SHARE_CASE(128, 5);
+            else EMU_SHARE_CASE(128, 8);
+        } else if (a.D == 64) {
+            if (a.share_nb <= 2) EMU_SHARE_CASE(64, 2);
+            else if (a.share_nb <= 4) EMU_SHARE_CASE(64, 4);
+            else if (a.share_nb <= 5) EMU_SHARE_CASE(64, 5);
+            else EMU_SHARE_CASE(64, 8);
+        } else return -22;
+#undef EMU_SHARE_CASE
+        if (a.D == 128) hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        else hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        EMU_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.D == 128) {
-        if (share) hipLaunchKernelGGL((decode_fused_kernel<128, true>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        else hipLaunchKernelGGL((decode_fused_kernel<128, false>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        hipLaunchKernelGGL((decode_fused_kernel<128, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
         hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else if (a.D == 64) {
-        if (share) hipLaunchKernelGGL((decode_fused_kernel<64, true>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        else hipLaunchKernelGGL((decode_fused_kernel<64, false>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
+        hipLaunchKernelGGL((decode_fused_kernel<64, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
         hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else return -22;
     EMU_CHECK_LAUNCH();

@@ -48,6 +48,7 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
     // rows too when the MFMA kernel covers the shape -- a 128-row GEMM tile would be > 87 % padding there
     const bool skinny = M > 8 && M <= 16 && !norm_w && (K & 31) == 0 && (ldw & 7) == 0 && (lda & 7) == 0 &&
                         (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SWIGLU || epi == EPI_SILU || epi == EPI_GELU);
+    // A/B aid (emu_gemm_tune bit 2): 2..32 rows without a fused norm go through the thin MFMA tile instead
     if (M <= 8 || skinny) {
         GemvArgs g{A, W, norm_w, bias, res, C, M, N, K, lda, ldw, ldres, ldc, eps, epi, 0, wscale};
         if (!g_prof.on) return launch_gemv(g, s);

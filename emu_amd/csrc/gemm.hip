@@ -639,6 +639,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
 void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; }
 void emu_gemm_tune_set(int mask) { g_tune = mask; }
+int emu_gemm_tune_get() { return g_tune; }
 
 int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;

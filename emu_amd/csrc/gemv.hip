@@ -1002,6 +1002,11 @@ int launch_gemv(const GemvArgs& a, hipStream_t s) {
     // 9..16 rows: the 16x16x32 MFMA stream.  Up to 8 rows the v_dot2c block kernel is faster (M = 2: 6.4 vs 4.1 TB/s,
     // M = 5: 4.5 vs 3.9, M = 8: 3.7 vs 3.5; tools/kbench.py --filter rows): its row-contiguous 1 KiB loads use HBM better
     // than the MFMA fragment's 64 bytes per row.
+    // 4..16 rows with whole 256-wide k stages: LDS-DMA stages + MFMA (gemv_thin.hip).  Measured on the LLaMA-33B shapes
+    // (tools/thin_ab.py, profiles/r03_thin_stream_ab.log): 5 rows 42.7 / 17.9 / 74.6 / 42.6 us (qkv / o / gate-up / down) against
+    // 46.4 / 21.7 / 77.4 / 47.6 on the v_dot2c kernel below, 8 rows 43.7 vs 60.7, 16 rows 49.2 vs 92.0 (register-fed MFMA); at 2-3
+    // rows the v_dot2c kernel is level or ahead (qkv 40.6 vs 41.0).  emu_gemm_tune bit 2 switches it off (A/B).
+    if (a.M >= 4 && !(emu_gemm_tune_get() & 4) && gemv_thin_ok(a)) return launch_gemv_thin(a, s);
     if (a.M > 8 && !a.wscale && !a.norm_w && (a.K & 31) == 0 && (a.ldw & 7) == 0 &&
         (a.ldx & 7) == 0)
         return launch_gemv_mfma(a, s);

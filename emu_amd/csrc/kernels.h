@@ -22,6 +22,9 @@ struct GemvArgs {
     const float* wscale;    // non-null: W holds OCP fp8 e4m3 bytes [N, ldw] with one fp32 scale per row (K % 16 == 0)
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
+// 2..16 rows through LDS-DMA stages and v_mfma_f32_16x16x32_bf16 (gemv_thin.hip); needs K % 256 == 0, no fused norm, bf16 weights
+bool gemv_thin_ok(const GemvArgs& a);
+int launch_gemv_thin(const GemvArgs& a, hipStream_t s);
 
 // Implicit-GEMM 3x3 convolution over an NHWC activation: A is [B, Hin, Win, Cin], the GEMM row m is the output
 // pixel (b, yo, xo), K = 9*Cin ordered (ky, kx, ci) -- weights repacked to [Cout, 3, 3, Cin].  Cin % 64 == 0.
@@ -103,6 +106,7 @@ void emu_gemm_set_splitk_scratch(float* ptr, size_t floats);
 void emu_gemm_force_config_set(int cfg);
 // A/B switches of single dispatch decisions (bit 0: GLU GEMMs the hybrid would split run as one launch of 128 x 128 tiles)
 void emu_gemm_tune_set(int mask);
+int emu_gemm_tune_get();
 
 // ---- row-wise / elementwise (elementwise.hip)
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);
@@ -185,9 +189,9 @@ struct DecodeFusedArgs {
     int B, H, D, S_max, ctx_max;               // ctx_max sizes the launch (>= max slot + 1)
     float scale;
     // Beam search: rows come in groups of share_nb beams of one prompt whose first share_len cache slots (the prompt) are
-    // identical.  They are stored ONCE, in the group's first row, and a 128-key split that lies inside them is read once
-    // and scored against the queries of all the group's beams by one workgroup.  Rows of a group must agree in slot,
-    // pos and kstart.  share_nb <= 1: every row owns all of its slots.
+    // identical.  They are stored ONCE, in the group's first row, and read from there by every beam of the group (the
+    // workgroups reading the same keys are dispatched onto one XCD so its L2 serves all but the first).  share_nb <= 1:
+    // every row owns all of its slots.
     int share_nb = 0, share_len = 0;
 };
 constexpr int DECODE_SHARE_MAX = 8;            // beams per group the shared-prefix path takes

@@ -69,7 +69,8 @@ void emu_gemm_force_config(int cfg);
 /* Bench hook: A/B switches of single dispatch decisions (0 = the shipped heuristic).  Bit 0: GLU GEMMs that the heuristic
  * splits into whole rounds of the 256x256 tile + a remainder GEMM run as ONE launch of 128x128 tiles.  Bit 1: the K-slice
  * workgroups of a split GEMM are dealt tile by tile round-robin over the XCDs (the order before round 3) instead of the
- * XCD-aware slice-major order. */
+ * XCD-aware slice-major order.  Bit 2: 4..16-row linears skip the LDS-DMA + MFMA stream (gemv_thin.hip) and run on the
+ * v_dot2c / register-fed MFMA kernels as before round 3; bits 8-11: variant of that stream (tools/thin_ab.py). */
 void emu_gemm_tune(int mask);
 
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while
@@ -218,8 +219,8 @@ int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_
 /* Beam search (the reference's default decoding mode: lm.generate(num_beams=5), Emu2/emu/emu.py:163-172,213-229; transformers
  * replicates the prompt's cache per beam with expand_inputs / _reorder_cache).  Here cache rows come in groups of `beams`
  * consecutive rows of one prompt whose first `shared_slots` slots (the prompt) are stored ONCE, in the group's first row:
- * single-token steps read them from there, one workgroup scoring a 128-key split against all the group's queries, and
- * only slots >= shared_slots are per-row.  Rows of a group must agree in pos / slot / kstart.  beams <= 1 switches it off
+ * single-token steps read them from there (the beams' workgroups for one 128-key split run on one XCD, whose L2 then
+ * serves all but the first), and only slots >= shared_slots are per-row.  beams <= 1 switches it off
  * (emu_llama_set_kv does too).  -22 for beams > 8, a batch the group size does not divide, or slots beyond the capacity. */
 int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);

@@ -83,6 +83,54 @@ def test_skinny_mfma_stream(M, N, K, epi):
     close(got, ref_linear(x, w, bias, res, epi=epi), what=f"skinny M{M} N{N} K{K} epi{epi}")
 
 
+@pytest.mark.parametrize("M", [4, 5, 7, 8, 9, 12, 16])
+@pytest.mark.parametrize("N,K", [(50, 256), (1002, 512), (264, 768), (37, 1024), (16, 256)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_thin_stream_rows_4_to_16(M, N, K, epi):
+    """4..16 activation rows with K % 256 == 0 (5 beams: the reference's default decoding mode) stream the weights through LDS-DMA
+    stages into v_mfma_f32_16x16x32_bf16 (gemv_thin.hip): one to four k stages (shorter than the ring is deep), ragged N (partial
+    16-row workgroups, fewer rows than one workgroup, odd store alignment), both activation-row paddings (8 / 16), every
+    epilogue, bias; the same call with the stream switched off (emu_gemm_tune bit 2) must agree to accumulation-order noise."""
+    ops = _ops()
+    from emu_amd._lib import lib
+    N += int(epi == 2 and N % 2)                                   # gate / up pairs
+    x, w = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=0.05)
+    bias = rnd(N, seed=63) if epi in (0, 2, 3) else None
+    res = rnd(M, N, seed=64) if epi == 1 else None
+    args = dict(bias=None if bias is None else bias.cuda(), res=None if res is None else res.cuda(), epi=epi)
+    got = ops.linear(x.cuda(), w.cuda(), **args)
+    assert torch.equal(got, ops.linear(x.cuda(), w.cuda(), **args))
+    close(got, ref_linear(x, w, bias, res, epi=epi), what=f"thin M{M} N{N} K{K} epi{epi}")
+    lib().emu_gemm_tune(4)
+    try:
+        old = ops.linear(x.cuda(), w.cuda(), **args)
+    finally:
+        lib().emu_gemm_tune(0)
+    assert float((got.float() - old.float()).abs().max()) <= 2 ** -6 * float(old.float().abs().max().clamp_min(1e-3))
+
+
+def test_thin_stream_identity_asymmetric_and_strides():
+    """x = the first 16 rows of I (K = 512: two k stages) against an asymmetric, exactly representable W: out[m, n] must equal
+    W[n, m] exactly -- catches any row / column / k-slot swap between the DMA swizzle, the ds_read of the fragments and the
+    16x16x32 operand maps.  Strided x rows, strided weight rows and strided out rows; nothing is written beyond N."""
+    ops = _ops()
+    K, N, M = 512, 83, 16
+    x = torch.eye(K)[:M].to(BF16)
+    w = ((torch.arange(N * K).reshape(N, K) * 7) % 251 - 125).float().to(BF16)
+    xb = torch.zeros(M, 2 * K, dtype=BF16)
+    xb[:, :K] = x
+    wb = torch.zeros(N, K + 64, dtype=BF16)
+    wb[:, :K] = w
+    out = torch.zeros(M, N + 8, dtype=BF16, device="cuda")
+    ops.linear(xb.cuda()[:, :K], wb.cuda()[:, :K], out=out[:, :N])
+    assert torch.equal(out[:, :N].float().cpu(), w.float()[:, :M].t().contiguous())
+    assert float(out[:, N:].abs().max()) == 0.0
+    # k values far into the row: x = rows 300..304 of I
+    x2 = torch.eye(K)[300:305].to(BF16)
+    got = ops.linear(x2.cuda(), w.cuda())
+    assert torch.equal(got.float().cpu(), w.float()[:, 300:305].t().contiguous())
+
+
 def test_skinny_mfma_identity_asymmetric():
     """x = the first 16 rows of I with an asymmetric, exactly representable W: out[m, n] must equal W[n, m] exactly
     (catches any row/col or k-lane swap in the 16x16x32 fragment maps); strided x and out rows."""

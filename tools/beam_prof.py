@@ -52,5 +52,26 @@ with torch.no_grad():
                 p = p + 1
                 lm.logits(hid)
         t_bare, _ = timed(bare)
+        # the model part of the real call, by events around forward + logits (the rest of a step is beam bookkeeping)
+        ev = []
+        fwd, lg = lm.forward, lm.logits
+
+        def fwd_t(*a_, **k_):
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            r = fwd(*a_, **k_)
+            ev.append([e0, None])
+            return r
+
+        def lg_t(*a_, **k_):
+            r = lg(*a_, **k_)
+            if ev and ev[-1][1] is None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                ev[-1][1] = e1
+            return r
+        lm.forward, lm.logits = fwd_t, lg_t
+        t_call2, _ = timed(lambda: lm.beam_search_generate(x, mask, nb, n_new, min_len=n_new))
+        lm.forward, lm.logits = fwd, lg
+        model_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev[1:] if e1 is not None)          # ev[0] is the prefill
+        print(f"rep {rep}: instrumented call {t_call2*1e3:.1f} ms: model part of the {len(ev)-1} steps {model_ms/max(1,len(ev)-1):.2f} ms/step", flush=True)
         print(f"rep {rep}: call {t_call*1e3:.1f} ms, prefill {t_pf*1e3:.1f} ms, {steps} steps: {(t_call-t_pf)/steps*1e3:.2f} ms/step "
               f"of which bare 5-row model step {t_bare/steps*1e3:.2f} ms", flush=True)

@@ -40,9 +40,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--filter", default="")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--tune", type=int, default=0, help="emu_gemm_tune mask for the whole run (A/B aid)")
     a = ap.parse_args()
     cases = []
     from emu_amd._lib import lib as _lib
+    _lib().emu_gemm_tune(a.tune)
     _sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")      # split-K scratch, as the engines carry
     if not os.environ.get("EMU_KBENCH_NO_SCRATCH"):
         _lib().emu_set_splitk_scratch(_sk.data_ptr(), _sk.numel() * 4)
@@ -109,6 +111,7 @@ def main():
     gemv("qkv beams5", 5, 19968, 6656, 0, False)
     gemv("gateup beams5", 5, 35840, 6656, 2, False)
     gemv("down beams5", 5, 6656, 17920, 1, False)
+    gemv("o beams5", 5, 6656, 6656, 1, False)
     gemv("tp8 qkv", 1, 2688, 6656, 0, True)
     gemv("tp8 o", 1, 6656, 896, 1)
     gemv("tp8 gateup", 1, 4480, 6656, 2, True)
