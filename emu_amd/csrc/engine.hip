@@ -494,7 +494,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         } else {
             TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
             if (f8p) TRY(cx, linear_q8(w, w.xn, H, m->layers8[l].wgu, m->layers8[l].sgu, nullptr, w.act, M, 2 * Fl, H, 0, Fl, EPI_SWIGLU, s));
-            else TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s));
+            else TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s, nullptr, w.splitk, w.splitk_floats));
         }
         if (f8) TRY(cx, linear(w.act, B(L8.wdown), nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, L8.sdown));
         else if (f8p) TRY(cx, linear_q8(w, w.act, Fl, m->layers8[l].wdown, m->layers8[l].sdown, w.hB, hA, M, H, Fl, H, H, epi_res, s));

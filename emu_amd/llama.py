@@ -33,12 +33,16 @@ def rope_tables(head_dim: int, max_pos: int, theta: float, device) -> Tuple[torc
 
 
 class EmuHipContext:
-    """One per (process, device): owns the emu_ctx handle and, for tp_size > 1, the RCCL communicator."""
+    """One per (process, device): owns the emu_ctx handle and, for tp_size > 1, the RCCL communicator.  One process drives
+    one GPU: creating the context makes its device the process's current device (explicitly, here and nowhere else --
+    ``ops.stream`` refuses operands of another device instead of switching to it)."""
 
     def __init__(self, device: torch.device, tp_rank: int = 0, tp_size: int = 1):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("emu_amd needs a GPU device (no CPU path)")
+        if self.device.index is not None and self.device.index != torch.cuda.current_device():
+            torch.cuda.set_device(self.device)
         self.tp_rank, self.tp_size = tp_rank, tp_size
         self.p2p = False
         h = C.c_void_p()
@@ -106,7 +110,12 @@ class EmuHipContext:
     def check_p2p(self) -> None:
         """Raise if a device-side wait of the P2P all-reduce ever timed out (the sums since then are invalid)."""
         if self.p2p and lib().emu_tp_p2p_giveups() != 0:
-            raise RuntimeError("peer-to-peer all-reduce timed out waiting for a peer rank; results are invalid")
+            # the path cannot recover (its per-piece sequence counters have diverged across the ranks): leave it for good, so
+            # that whatever this process runs next goes through RCCL (where a communicator exists) instead of summing stale slots
+            self.p2p = False
+            lib().emu_tp_p2p_enable(self.handle, 0)
+            raise RuntimeError("peer-to-peer all-reduce timed out waiting for a peer rank; the results of this generation are invalid "
+                               "(the peer-to-peer path is now switched off for this process)")
 
     def allreduce(self, t: torch.Tensor) -> torch.Tensor:
         check(lib().emu_allreduce_bf16(self.handle, t.data_ptr(), t.numel(), ops.stream(self.device)), "emu_allreduce_bf16", self.handle)

@@ -18,14 +18,16 @@ BF16 = torch.bfloat16
 def stream(ref=None) -> int:
     """HIP stream handle for one library call: torch's current stream of the device that holds ``ref`` (a tensor or a
     torch.device; None = the current device).  The library launches on that stream without touching the HIP device
-    state, so when ``ref`` lives on another GPU than the calling thread's current device, the current device is
-    switched to it first (one process drives one GPU in this design; this keeps a stray ``device='cuda:1'`` correct
-    instead of enqueueing device-1 work on a device-0 stream)."""
+    state, and a launch on a stream of another GPU than the calling thread's current one is invalid -- so a ``ref`` on
+    another device is refused here (no hidden ``set_device``: one process drives one GPU in this design, and
+    ``EmuHipContext`` is the one place that makes its device current)."""
     if ref is None:
         return torch.cuda.current_stream().cuda_stream
     dev = ref.device if isinstance(ref, torch.Tensor) else torch.device(ref)
     if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
-        torch.cuda.set_device(dev)
+        raise ValueError(f"emu_amd: operand on {dev} but the current device is cuda:{torch.cuda.current_device()}; one process "
+                         "drives one GPU -- create the EmuHipContext for that device (it makes it current) or call "
+                         "torch.cuda.set_device first")
     return torch.cuda.current_stream(dev).cuda_stream
 
 

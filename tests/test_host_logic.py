@@ -505,3 +505,15 @@ def test_emu1_num_captions_and_ngram_ban_match_real_reference(golden_dir, monkey
     for row in out.tolist() + want:
         big = list(zip(row, row[1:]))
         assert len(big) == len(set(big)), row
+
+
+def test_stream_handle_refuses_another_device_without_switching(monkeypatch):
+    """``ops.stream`` is a getter: an operand on another GPU than the current one is refused loudly, the current device is never
+    switched behind the caller's back (one process drives one GPU; EmuHipContext is the place that selects it)."""
+    from emu_amd import ops
+    switched = []
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: switched.append(d))
+    with pytest.raises(ValueError, match="current device"):
+        ops.stream(torch.device("cuda", 1))
+    assert switched == []
