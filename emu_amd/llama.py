@@ -666,7 +666,9 @@ class LlamaEngine:
             best_run = running_scores[:, :1] / float(cur ** length_penalty)
             worst_fin = torch.where(finished, beam_scores.min(dim=1, keepdim=True)[0], torch.full_like(beam_scores, NEG))
             heuristic_open = heuristic_open & (best_run > worst_fin).any(dim=-1, keepdim=True)
-            if not bool(heuristic_open.any()) or bool(hits.all()):
+            # (every candidate is a hit exactly when the length limit is reached: a beam contributes EOS at most once, so the 2N
+            # candidates are never all EOS -- known on the host, one device read per step instead of two)
+            if cur >= max_len or not bool(heuristic_open.any()):
                 break
             # advance the model: reorder the cache rows by beam, feed the chosen tokens
             flat = (beam_idx + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
