@@ -358,20 +358,20 @@ def test_true_width_single_layer_decode_and_prefill():
 def test_true_width_five_beam_step_against_oracle_and_single_rows():
     """The reference's default decoding mode at the decoder's true width: one LLaMA-33B-shaped layer, a 300-token prompt, 5 beams
     that share the prompt's cache row and feed five different tokens -- the step runs the 5-row LDS-DMA + MFMA weight streams
-    (qkv / o / gate-up / down at the bench's shapes) and the shared-split decode attention.  Every beam's hidden row must match
+    (qkv / o / gate-up / down at the bench's shapes) and the shared-split decode attention, over two layers.  Every beam's hidden row must match
     the CPU oracle's cached step of that row, and the same row run ALONE through the one-row kernels (v_dot2c GEMV, per-row
     cache) to accumulation-order noise."""
     from emu_amd import synth
     from emu_amd.conf.emu_conf import LlamaCfg
     from emu_amd.llama import EmuHipContext, LlamaEngine
     from oracle import emu2_ref as R
-    l = LlamaCfg(num_hidden_layers=1)
+    l = LlamaCfg(num_hidden_layers=2)
     vocab, nb, S = 1024, 5, 300
     W = synth.synth_state_dict(synth.llama_param_shapes(l, vocab), seed=3)
     eng = LlamaEngine(l, vocab, EmuHipContext(torch.device("cuda", 0)))
     eng.load_weights(W.items())
     Wr = R.bf16_round(W)
-    cfg = R.LlamaCfg(layers=1, vocab=vocab)
+    cfg = R.LlamaCfg(layers=2, vocab=vocab)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(1, S, l.hidden_size, generator=g).to(BF16)
     new = torch.randn(nb, l.hidden_size, generator=g).to(BF16)
@@ -380,18 +380,21 @@ def test_true_width_five_beam_step_against_oracle_and_single_rows():
     _, kstart, pos = eng.prefill(x.cuda(), mask, s_max=s_max)
     eng.fan_out_kv(1, nb, S, s_max)
     assert eng._kv_share
-    got = eng.decode_embeds(new.cuda(), pos.repeat_interleave(nb).contiguous(), S, kstart.repeat_interleave(nb).contiguous()).clone()
+    pos5, ks5 = pos.repeat_interleave(nb).contiguous(), kstart.repeat_interleave(nb).contiguous()
+    got = eng.decode_embeds(new.cuda(), pos5, S, ks5).clone()
+    assert torch.equal(got, eng.decode_embeds(new.cuda(), pos5, S, ks5))         # deterministic
     eng.set_kv_share(0, 0)
-    cache = R.KVCache(1)
+    cache = R.KVCache(2)
     R.llama_model(x.float(), mask, Wr, cfg, cache=cache, final_norm=False)
-    k0, v0 = cache.k[0].clone(), cache.v[0].clone()
+    kv0 = [(cache.k[i].clone(), cache.v[i].clone()) for i in range(2)]
     for j in range(nb):
-        cache.k[0], cache.v[0] = k0.clone(), v0.clone()
+        for i in range(2):
+            cache.k[i], cache.v[i] = kv0[i][0].clone(), kv0[i][1].clone()
         want = R.llama_model(new[j].float().view(1, 1, -1), torch.ones(1, S + 1, dtype=torch.long), Wr, cfg, cache=cache, final_norm=False)
         assert rel_err(got[j], want[0, 0]) < 2e-2, (j, rel_err(got[j], want[0, 0]))
         _, ks1, p1 = eng.prefill(x.cuda(), mask, s_max=s_max)                     # the row alone: one-row kernels, own cache
         alone = eng.decode_embeds(new[j:j + 1].cuda(), p1, S, ks1)
-        assert rel_err(got[j], alone[0]) < 4e-3, (j, rel_err(got[j], alone[0]))
+        assert rel_err(got[j], alone[0]) < 1.2e-2, (j, rel_err(got[j], alone[0]))     # two layers of bf16 rounding in another order
 
 
 @pytest.mark.parametrize("heads,D", [(4, 64), (3, 128), (9, 128)])
