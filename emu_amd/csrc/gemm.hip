@@ -120,6 +120,21 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
             const int rr = gm - pb[i] * hw;
             py[i] = rr / a.conv.Wout;
             px[i] = rr - py[i] * a.conv.Wout;
+            if (a.conv.cpt_magic) {
+                // fast gather (ConvGeom): gA = the centre source pixel's channel 0 (+ this lane's chunk), py = the 9-bit tap mask
+                // (nearest x2 upsampling: the centre is (py / 2, px / 2) and the parities of py, px ride in bits 9, 10)
+                const bool up = a.conv.mode == CONV_3X3_UP2;
+                const int cy = up ? py[i] >> 1 : (a.conv.mode == CONV_3X3_S2 ? 2 * py[i] : py[i]);
+                const int cx = up ? px[i] >> 1 : (a.conv.mode == CONV_3X3_S2 ? 2 * px[i] : px[i]);
+                int mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    int yi, xi;
+                    mask |= (int)conv_tap(a.conv, py[i], px[i], t / 3, t % 3, yi, xi) << t;
+                }
+                gA[i] = a.A + ((size_t)(pb[i] * a.conv.Hin + cy) * a.conv.Win + cx) * a.conv.Cin + ck;
+                py[i] = mask | ((py[i] & 1) << 9) | ((px[i] & 1) << 10);
+            }
         }
     }
     // split-K: this workgroup owns K-tiles [kt0, kt0 + nk) of slice ks
@@ -135,14 +150,33 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
 #pragma unroll
             for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
             // a 64-wide k tile lies inside one filter tap because Cin % 64 == 0
-            const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            if (a.conv.cpt_magic) {
+                const int ktile = kt0 + kt;
+                const int tap = (ktile * a.conv.cpt_magic) >> 16, ci0 = (ktile - tap * a.conv.cpt) << 6;
+                const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                if (a.conv.mode != CONV_3X3_UP2) {
+                    const long delta = (long)((ky - 1) * a.conv.Win + (kx - 1)) * a.conv.Cin + ci0;  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < T::NLA; ++i) {
-                int yi, xi;
-                const bool ok = conv_tap(a.conv, py[i], px[i], ky, kx, yi, xi);
-                const size_t off = (((size_t)pb[i] * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin + ci0 + ck;
-                glds16(ok ? a.A + off : zero, base + T::W_BYTES + i * NW * 1024);
+                    for (int i = 0; i < T::NLA; ++i)
+                        glds16(((py[i] >> tap) & 1) ? gA[i] + delta : zero, base + T::W_BYTES + i * NW * 1024);
+                } else {                               // upsampled: the source step of a tap depends on the pixel's parity
+#pragma unroll
+                    for (int i = 0; i < T::NLA; ++i) {
+                        const int dy = (((py[i] >> 9) & 1) + ky - 1) >> 1, dx = (((py[i] >> 10) & 1) + kx - 1) >> 1;
+                        const long delta = (long)(dy * a.conv.Win + dx) * a.conv.Cin + ci0;
+                        glds16(((py[i] >> tap) & 1) ? gA[i] + delta : zero, base + T::W_BYTES + i * NW * 1024);
+                    }
+                }
+            } else {
+                const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int i = 0; i < T::NLA; ++i) {
+                    int yi, xi;
+                    const bool ok = conv_tap(a.conv, py[i], px[i], ky, kx, yi, xi);
+                    const size_t off = (((size_t)pb[i] * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin + ci0 + ck;
+                    glds16(ok ? a.A + off : zero, base + T::W_BYTES + i * NW * 1024);
+                }
             }
         } else if (k0 + BK <= a.K) {
 #pragma unroll
@@ -671,9 +705,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         if (g.mode == CONV_3X3 && (g.Hout != g.Hin || g.Wout != g.Win)) return -22;
         if (g.mode == CONV_3X3_S2 && (g.Hout != (g.Hin + 1) / 2 || g.Wout != (g.Win + 1) / 2)) return -22;
         if (g.mode == CONV_3X3_UP2 && (g.Hout != 2 * g.Hin || g.Wout != 2 * g.Win)) return -22;
+        GemmArgs b = a;
+        const int cpt = g.Cin / 64;
+        const long src_pixels = (long)(a.M / (g.Hout * g.Wout)) * g.Hin * g.Win;
+        if (cpt <= 64 && src_pixels < (g.mode == CONV_3X3_UP2 ? 1L << 21 : 1L << 23) && src_pixels * g.Cin * 2 < (1L << 31) && !(g_tune & 32)) {
+            b.conv.cpt = cpt;
+            b.conv.cpt_magic = (65536 + cpt - 1) / cpt;
+        }
         switch (a.epi) {
-            case EPI_NONE:  return launch_v2<EPI_NONE, true>(a, s);
-            case EPI_RESID: return launch_v2<EPI_RESID, true>(a, s);
+            case EPI_NONE:  return launch_v2<EPI_NONE, true>(b, s);
+            case EPI_RESID: return launch_v2<EPI_RESID, true>(b, s);
             default: return -22;
         }
     }

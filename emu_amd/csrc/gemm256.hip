@@ -137,6 +137,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 const int pb = gm / hw, rr = gm - pb * hw;
                 const int py = rr / a.conv.Wout, px = rr - py * a.conv.Wout;
                 qpix[s][i] = (uint32_t)((pb << 22) | (py << 11) | px);
+                if (a.conv.cpt_magic) {
+                    // fast gather (ConvGeom): 9-bit tap mask << 23 | index of the centre source pixel (< 2^23; nearest x2
+                    // upsampling: centre (py / 2, px / 2) < 2^21, the parities of py, px in bits 22, 21)
+                    const bool up = a.conv.mode == CONV_3X3_UP2;
+                    const int cy = up ? py >> 1 : (a.conv.mode == CONV_3X3_S2 ? 2 * py : py);
+                    const int cx = up ? px >> 1 : (a.conv.mode == CONV_3X3_S2 ? 2 * px : px);
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        int yi, xi;
+                        mask |= (uint32_t)conv_tap(a.conv, py, px, t / 3, t % 3, yi, xi) << t;
+                    }
+                    qpix[s][i] = (mask << 23) | (uint32_t)((pb * a.conv.Hin + cy) * a.conv.Win + cx) |
+                                 (up ? (uint32_t)(((py & 1) << 22) | ((px & 1) << 21)) : 0u);
+                }
             }
     }
     const uint32_t w_bytes = (uint32_t)a.N * (uint32_t)a.ldw * ESZ;
@@ -164,14 +179,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 dma(rA, vQ, ((kt0 + tau) << 7) + (i * 128 + S * 32) * a.lda * (int)ESZ, base + i * 8192);
             } else {
                 // implicit-GEMM gather: a 64-wide k tile lies inside one filter tap (Cin % 64 == 0)
-                const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
-                const int ky = tap / 3, kx = tap - ky * 3;
                 const uint32_t o = qpix[S][i];
-                const int pb = o >> 22, py = (o >> 11) & 2047, px = o & 2047;
-                int yi, xi;
-                const bool ok = conv_tap(a.conv, py, px, ky, kx, yi, xi);
-                const uint32_t off = (uint32_t)((((pb * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin) * 2) + sck;
-                dma(rA, ok ? off : OOB, ci0 * 2, base + i * 8192);
+                if (a.conv.cpt_magic) {
+                    const int ktile = kt0 + tau;
+                    const int tap = (ktile * a.conv.cpt_magic) >> 16, ci0 = (ktile - tap * a.conv.cpt) << 6;
+                    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                    uint32_t src;
+                    if (a.conv.mode != CONV_3X3_UP2) {
+                        src = (o & 0x7fffffu) + (uint32_t)((ky - 1) * a.conv.Win + (kx - 1));          // wave-uniform step
+                    } else {                           // upsampled: the source step of a tap depends on the pixel's parity
+                        const int dy = (int)(((o >> 22) & 1u) + ky - 1) >> 1, dx = (int)(((o >> 21) & 1u) + kx - 1) >> 1;
+                        src = (o & 0x1fffffu) + (uint32_t)(dy * a.conv.Win + dx);
+                    }
+                    const uint32_t off = __umul24(src, (uint32_t)a.conv.Cin * 2u) + sck;
+                    dma(rA, ((o >> (23 + tap)) & 1u) ? off : OOB, ci0 * 2, base + i * 8192);
+                } else {
+                    const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const int pb = o >> 22, py = (o >> 11) & 2047, px = o & 2047;
+                    int yi, xi;
+                    const bool ok = conv_tap(a.conv, py, px, ky, kx, yi, xi);
+                    const uint32_t off = (uint32_t)((((pb * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin) * 2) + sck;
+                    dma(rA, ok ? off : OOB, ci0 * 2, base + i * 8192);
+                }
             }
         }
     };

@@ -29,7 +29,13 @@ int launch_gemv_thin(const GemvArgs& a, hipStream_t s);
 // Implicit-GEMM 3x3 convolution over an NHWC activation: A is [B, Hin, Win, Cin], the GEMM row m is the output
 // pixel (b, yo, xo), K = 9*Cin ordered (ky, kx, ci) -- weights repacked to [Cout, 3, 3, Cin].  Cin % 64 == 0.
 enum EmuConvMode { CONV_NONE = 0, CONV_3X3 = 1, CONV_3X3_S2 = 2, CONV_3X3_UP2 = 3 };
-struct ConvGeom { int mode, Hin, Win, Hout, Wout, Cin; };
+struct ConvGeom {
+    int mode, Hin, Win, Hout, Wout, Cin;
+    // set by launch_gemm (0 = off): the gather's fast form for the stride-1 / stride-2 modes.  A k tile (64 channels) lies inside one
+    // filter tap; tap = k_tile / cpt is taken as (k_tile * cpt_magic) >> 16 (exact for the < 9 * cpt tiles of a conv), and a tap's
+    // source is the output pixel's centre source + (ky - 1) * Win + (kx - 1) pixels, valid where a 9-bit mask computed once per row says
+    int cpt = 0, cpt_magic = 0;
+};
 
 struct GemmArgs {
     const bf16_t* A;        // [M, lda]  activations (K contiguous)   (conv: NHWC input)
