@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--denoise-steps", type=int, default=50)
     p.add_argument("--only-denoise", action="store_true", help="profiling aid: run just the UNet leg (prints its object)")
     p.add_argument("--unet-fusion", type=int, default=-1, help="A/B aid: emu_unet_set_fusion mask for the denoise leg (default: all)")
+    p.add_argument("--gemm-tune", type=int, default=0, help="A/B aid: emu_gemm_tune mask for the whole run (0 = the shipped dispatch; "
+                   "anything else marks the line invalid)")
     p.add_argument("--no-beam", action="store_true", help="skip the extra 5-beam leg (the reference's default decoding mode)")
     p.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weight decode leg (never the headline value)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -384,6 +386,8 @@ def main():
     import ctypes as C
 
     ctx = EmuHipContext(dev, rank, world)
+    if a.gemm_tune:
+        lib().emu_gemm_tune(a.gemm_tune)
     if a.pmc_prefill:
         from emu_amd.llama import LlamaEngine
         lcfg = LlamaCfg(num_hidden_layers=a.layers)
@@ -676,7 +680,7 @@ def main():
                        "decoder_layers": lcfg.num_hidden_layers, "vit_layers": vcfg.layers,
                        "parallelism": f"tp{world}" + (" (ranks sharing one GPU: validation only)" if shared else ""), "allreduce": ("p2p one-shot (<=256 KiB) + rccl" if ctx.p2p else "rccl") if world > 1 else None,
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "valid": bool(a.layers == 60 and a.vit_layers == 64 and not shared)},
+                       "valid": bool(a.layers == 60 and a.vit_layers == 64 and not shared and not a.gemm_tune)},
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel (weight-streaming GEMV, all epilogues)",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

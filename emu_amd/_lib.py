@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libemu_hip.so")
+# EMU_HIP_LIB: A/B hook for tools/ (same-box comparison of two builds); production loads the in-tree library
+LIB_PATH = os.environ.get("EMU_HIP_LIB") or os.path.join(HERE, "csrc", "libemu_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "emu_hip.h")
 
 

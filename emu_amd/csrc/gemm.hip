@@ -708,7 +708,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
         GemmArgs b = a;
         const int cpt = g.Cin / 64;
         const long src_pixels = (long)(a.M / (g.Hout * g.Wout)) * g.Hin * g.Win;
-        if (cpt <= 64 && src_pixels < (g.mode == CONV_3X3_UP2 ? 1L << 21 : 1L << 23) && src_pixels * g.Cin * 2 < (1L << 31) && !(g_tune & 32)) {
+        if (cpt <= 64 && src_pixels < (g.mode == CONV_3X3_UP2 ? 1L << 21 : 1L << 23) && src_pixels * g.Cin * 2 < (1L << 31)) {
             b.conv.cpt = cpt;
             b.conv.cpt_magic = (65536 + cpt - 1) / cpt;
         }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const uint32_t sck = (uint32_t)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);       // bytes
     const uint32_t vP = (uint32_t)(n0 + srow) * (uint32_t)a.ldw * ESZ + sck;
     const uint32_t vQ = (uint32_t)(m0 + (srow >> 5) * 64 + (srow & 31)) * (uint32_t)a.lda * ESZ + sck;     // plain GEMM
-    uint32_t qpix[2][2];                             // CONV: output pixel (b << 22 | y << 11 | x) of every Q piece's row
+    uint32_t qpix[2][2];                             // CONV: tap mask and centre source pixel of every Q piece's row (ConvGeom)
     if constexpr (CONV) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -136,8 +136,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 const int hw = a.conv.Hout * a.conv.Wout;
                 const int pb = gm / hw, rr = gm - pb * hw;
                 const int py = rr / a.conv.Wout, px = rr - py * a.conv.Wout;
-                qpix[s][i] = (uint32_t)((pb << 22) | (py << 11) | px);
-                if (a.conv.cpt_magic) {
+                {
                     // fast gather (ConvGeom): 9-bit tap mask << 23 | index of the centre source pixel (< 2^23; nearest x2
                     // upsampling: centre (py / 2, px / 2) < 2^21, the parities of py, px in bits 22, 21)
                     const bool up = a.conv.mode == CONV_3X3_UP2;
@@ -169,7 +168,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     auto stage = [&](auto uc, auto bc, int tau) {
         constexpr int U = decltype(uc)::value, BF = decltype(bc)::value;
         constexpr int S = (U == U_P1 || U == U_Q1) ? 1 : 0;
-        const int k0 = (kt0 + tau) << 6;
         char* base = smem + BF * BUFB + U * UNIT + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             } else {
                 // implicit-GEMM gather: a 64-wide k tile lies inside one filter tap (Cin % 64 == 0)
                 const uint32_t o = qpix[S][i];
-                if (a.conv.cpt_magic) {
+                {                                      // (gemm256_ok: only problems the fast gather covers come here)
                     const int ktile = kt0 + tau;
                     const int tap = (ktile * a.conv.cpt_magic) >> 16, ci0 = (ktile - tap * a.conv.cpt) << 6;
                     const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
@@ -193,14 +191,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                     }
                     const uint32_t off = __umul24(src, (uint32_t)a.conv.Cin * 2u) + sck;
                     dma(rA, ((o >> (23 + tap)) & 1u) ? off : OOB, ci0 * 2, base + i * 8192);
-                } else {
-                    const int tap = k0 / a.conv.Cin, ci0 = k0 - tap * a.conv.Cin;
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const int pb = o >> 22, py = (o >> 11) & 2047, px = o & 2047;
-                    int yi, xi;
-                    const bool ok = conv_tap(a.conv, py, px, ky, kx, yi, xi);
-                    const uint32_t off = (uint32_t)((((pb * a.conv.Hin + yi) * a.conv.Win + xi) * a.conv.Cin) * 2) + sck;
-                    dma(rA, ok ? off : OOB, ci0 * 2, base + i * 8192);
                 }
             }
         }
@@ -528,6 +518,7 @@ int gemm256_tiles(const GemmArgs& a) {
 
 // operand extents the 32-bit descriptor offsets can address, k tiles of 64
 bool gemm256_ok(const GemmArgs& a) {
+    if (a.conv.mode != CONV_NONE && !a.conv.cpt_magic) return false;   // the gather here is the fast form only (ConvGeom)
     if (a.a_scale) {                                   // fp8 operands: k tiles of 128 elements, plain GEMM only
         if ((a.K & 127) || a.conv.mode != CONV_NONE || !a.w_scale) return false;
         return (size_t)a.N * a.ldw < 0x7fffffffull && (size_t)a.M * a.lda < 0x7fffffffull;
