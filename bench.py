@@ -629,7 +629,8 @@ def main():
             beam = {"num_beams": 5, "new_tokens": int(out.shape[1]), "call_ms": dtb * 1e3,
                     "ms_per_beam_step": (dtb - dpf) * 1e3 / steps_b, "tokens_per_s": steps_b / max(1e-9, dtb - dpf),
                     "note": "5 rows per weight stream (LDS-DMA stages + 16x16x32 MFMA, gemv_thin.hip), the prompt's KV kept once per prompt "
-                            "and read by all beams (emu_llama_set_kv_share), host-driven beam bookkeeping; prefill excluded from the per-step time"}
+                            "and read by all beams (emu_llama_set_kv_share), every step's 2N-best selection and scorer bookkeeping in two launches "
+                            "(emu_beam_step_bf16) with one flag read by the host; prefill excluded from the per-step time"}
         except Exception as e:
             beam = {"num_beams": 5, "note": f"beam leg failed: {e}"}
 

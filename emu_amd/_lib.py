@@ -95,6 +95,8 @@ _PROTOS = {
     "emu_llama_set_head": (i32, [vp, vp, vp, vp, vp, vp]),
     "emu_llama_set_kv": (i32, [vp, vp, vp, i32, i32]),
     "emu_llama_set_kv_share": (i32, [vp, i32, i32]),
+    "emu_beam_step_bf16": (i32, [vp, lng, lng, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "emu_beam_step_workspace_bytes": (sz, [i32, i32, i32]),
     "emu_llama_workspace_bytes": (sz, [vp, i32, i32]),
     "emu_llama_forward": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
     "emu_llama_final_norm": (i32, [vp, vp, vp, i32, vp]),

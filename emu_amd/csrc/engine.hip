@@ -504,6 +504,19 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     return 0;
 }
 
+size_t emu_beam_step_workspace_bytes(int Bn, int nb, int V) { return beam_step_ws_floats(Bn, nb, V) * sizeof(float); }
+int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, int Bn, int nb, int L, int cur, int suppress_eos,
+                       int eos_id, float len_div, int32_t* running_seq, int32_t* sequences, float* running_scores, float* beam_scores,
+                       unsigned char* finished, int32_t* seq_len, unsigned char* heuristic_open, int32_t* next_tok, long* beam_flat,
+                       void* workspace, size_t ws_bytes, emu_stream_t s) {
+    if (!logits || !running_seq || !sequences || !running_scores || !beam_scores || !finished || !seq_len || !heuristic_open ||
+        !next_tok || !beam_flat)
+        return -22;
+    BeamStepArgs a{B(logits), ld_prompt, ld_beam, V, Bn, nb, L, cur, suppress_eos, eos_id, len_div, running_seq, sequences,
+                   running_scores, beam_scores, finished, seq_len, heuristic_open, next_tok, beam_flat};
+    return launch_beam_step(a, reinterpret_cast<float*>(workspace), ws_bytes / sizeof(float), S(s));
+}
+
 int emu_llama_final_norm(emu_llama* m, const void* hidden, void* out, int rows, emu_stream_t s) {
     if (!m || !m->final_norm) return -22;
     return launch_rmsnorm(B(hidden), m->final_norm, B(out), rows, m->cfg.hidden, m->cfg.hidden, m->cfg.hidden,

@@ -204,6 +204,22 @@ constexpr int DECODE_SHARE_MAX = 8;            // beams per group the shared-pre
 size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max);
 int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s);
 
+// One beam-search step on the device (beam.hip): see emu_beam_step_bf16 in include/emu_hip.h
+struct BeamStepArgs {
+    const bf16_t* logits;                      // row of (prompt b, beam j) = logits + b * ld_prompt + j * ld_beam
+    long ld_prompt, ld_beam;                   // elements (step 0: ld_beam = 0, every beam continues the prompt)
+    int V, B, nb, L, cur;                      // vocabulary, prompts, beams, max new tokens, tokens generated so far
+    int suppress_eos, eos_id;
+    float len_div;                             // (cur + 1) ** length_penalty
+    int32_t* running_seq; int32_t* sequences;  // [B, nb, L]
+    float* running_scores; float* beam_scores; // [B, nb]
+    unsigned char* finished; int32_t* seq_len; // [B, nb]
+    unsigned char* heuristic_open;             // [B]
+    int32_t* next_tok; long* beam_flat;        // [B * nb] out: token to feed / cache row it continues
+};
+size_t beam_step_ws_floats(int B, int nb, int V);     // scratch of the two-launch step (chunk partials)
+int launch_beam_step(const BeamStepArgs& a, float* ws, size_t ws_floats, hipStream_t s);
+
 // ---- UNet denoise helpers (unet.hip); activations are NHWC: [B, H*W, C] bf16
 // GroupNorm(groups, eps) (+ optional SiLU) over x [B, HW, C]: three launches (partial sums, finalize to per-(b, c)
 // scale/shift, apply).  ws must hold gn_ws_floats(B, C, HW) floats.

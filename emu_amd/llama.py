@@ -587,7 +587,7 @@ class LlamaEngine:
         nb, V, dev = num_beams, self.vocab, self.device
         s_max = self.kv_capacity(S + max_new_tokens)
         hidden, kstart, next_pos = self.prefill(embeds, attention_mask, s_max)
-        logits = self.logits(hidden[:, -1, :]).float()                                  # [B, V]
+        logits = self.logits(hidden[:, -1, :])                                          # [B, V]
         # rows b*nb .. b*nb + nb - 1 are the beams of prompt b; its keys / values stay in the first of them (fan_out_kv)
         self.fan_out_kv(B, nb, S, s_max)
         kstart_b = kstart.repeat_interleave(nb).contiguous()
@@ -595,6 +595,13 @@ class LlamaEngine:
 
         max_len = max_new_tokens
         NEG = -1.0e9
+        # The deterministic mode (the reference's default) runs each step's selection and bookkeeping in ONE kernel
+        # (emu_beam_step_bf16); sampling, penalties, n-gram bans and the diagnostics keep the torch pipeline below.
+        if (not do_sample and repetition_penalty == 1.0 and not ngram and trace is None and nb <= 8 and max_len <= 256
+                and V >= 2 * nb and hasattr(self, "handle") and logits.dtype == BF16):
+            return self._beam_search_device(logits, B, S, nb, max_len, min_len, length_penalty, eos_id, pad_id, kstart_b, pos,
+                                            int(num_return_sequences))
+        logits = logits.float()
         running_seq = torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=dev)
         sequences = running_seq.clone()
         running_scores = torch.zeros(B, nb, device=dev)
@@ -693,6 +700,60 @@ class LlamaEngine:
         if nret == 1:
             return sequences[:, 0, :out_len]
         return sequences[:, :nret, :out_len].reshape(B * nret, out_len)
+
+    def _beam_search_device(self, logits0: torch.Tensor, B: int, S: int, nb: int, max_len: int, min_len: int,
+                            length_penalty: float, eos_id: int, pad_id: int, kstart_b: torch.Tensor, pos: torch.Tensor,
+                            nret: int) -> torch.Tensor:
+        """The loop of ``beam_search_generate`` for the deterministic mode with every step's log-softmax, 2N-best selection and
+        scorer bookkeeping in one launch (``emu_beam_step_bf16``, csrc/beam.hip: the same statements as the torch pipeline, which
+        stays the specification and the fallback).  Per step the host enqueues: the beam-step kernel, the re-order of the
+        generated KV slots, the embedding gather, the decoder step and the logits -- and reads one flag."""
+        dev, V = self.device, self.vocab
+        i32 = dict(dtype=torch.int32, device=dev)
+        running_seq = torch.full((B, nb, max_len), pad_id, **i32)
+        sequences = running_seq.clone()
+        running_scores = torch.zeros(B, nb, device=dev)
+        running_scores[:, 1:] = -1.0e9
+        beam_scores = torch.full((B, nb), -1.0e9, device=dev)
+        finished = torch.zeros(B, nb, dtype=torch.uint8, device=dev)
+        seq_len = torch.zeros(B, nb, **i32)
+        still_open = torch.ones(B, dtype=torch.uint8, device=dev)
+        next_tok = torch.zeros(B * nb, **i32)
+        beam_flat = torch.zeros(B * nb, dtype=torch.int64, device=dev)
+        hid = torch.empty(B * nb, self.cfg.hidden_size, device=dev, dtype=BF16)
+        slot = torch.full((B * nb,), S - 1, **i32)
+        pos = pos.clone()
+        ws = torch.empty(lib().emu_beam_step_workspace_bytes(B, nb, V), dtype=torch.uint8, device=dev)
+        lg, ld_prompt, ld_beam = logits0, logits0.stride(0), 0          # step 0: every beam continues the prompt
+        cur = 0
+        L = lib()
+        while True:
+            len_div = float(torch.tensor(float((cur + 1) ** length_penalty), dtype=torch.float32))
+            check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, cur, int(cur < min_len), eos_id, len_div,
+                                       running_seq.data_ptr(), sequences.data_ptr(), running_scores.data_ptr(),
+                                       beam_scores.data_ptr(), finished.data_ptr(), seq_len.data_ptr(), still_open.data_ptr(),
+                                       next_tok.data_ptr(), beam_flat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       ops.stream(self.device)), "emu_beam_step_bf16", self.ctx.handle)
+            cur += 1
+            if cur >= max_len or not bool(still_open.any()):
+                break
+            ctx = S + cur - 1
+            if ctx > S:                                # only the generated slots move with the beam permutation
+                self.kcache[:, :, :, S:ctx] = self.kcache[:, beam_flat, :, S:ctx]
+                self.vcache[:, :, :, S:ctx] = self.vcache[:, beam_flat, :, S:ctx]
+            ops.embed_gather(next_tok, self.embed, out=hid)
+            slot += 1
+            self.forward(hid, B * nb, 1, pos, slot, kstart_b, ctx=ctx + 1)
+            pos += 1
+            lg = self.logits(hid)
+            ld_prompt, ld_beam = nb * lg.stride(0), lg.stride(0)
+        self.set_kv_share(0, 0)
+        out_len = int(seq_len[:, :nret].max().item())
+        self.ctx.check_p2p()
+        seqs = sequences.long()
+        if nret == 1:
+            return seqs[:, 0, :out_len]
+        return seqs[:, :nret, :out_len].reshape(B * nret, out_len)
 
 
 def process_logits(scores: torch.Tensor, generated: torch.Tensor, suppress_eos: bool, eos_id: int, do_sample: bool,
