@@ -10,8 +10,12 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# EMU_HIP_LIB: A/B hook for tools/ (same-box comparison of two builds); production loads the in-tree library
-LIB_PATH = os.environ.get("EMU_HIP_LIB") or os.path.join(HERE, "csrc", "libemu_hip.so")
+# Production loads the in-tree library.  EMU_HIP_LIB redirects the load to another build for same-box A/B runs of tools/ ONLY:
+# it is honoured when EMU_HIP_TOOLS=1 is set as well (a stale variable in a serving environment must not swap the library),
+# announced on stderr, and the loaded library must report this binding's ABI version either way.
+_OVERRIDE = os.environ.get("EMU_HIP_LIB") if os.environ.get("EMU_HIP_TOOLS") == "1" else None
+LIB_PATH = _OVERRIDE or os.path.join(HERE, "csrc", "libemu_hip.so")
+ABI_VERSION = 2            # emu_version() of the library these prototypes and struct layouts belong to
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "emu_hip.h")
 
 
@@ -95,7 +99,7 @@ _PROTOS = {
     "emu_llama_set_head": (i32, [vp, vp, vp, vp, vp, vp]),
     "emu_llama_set_kv": (i32, [vp, vp, vp, i32, i32]),
     "emu_llama_set_kv_share": (i32, [vp, i32, i32]),
-    "emu_beam_step_bf16": (i32, [vp, lng, lng, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "emu_beam_step_bf16": (i32, [vp, lng, lng, i32, i32, i32, i32, i32, vp, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "emu_beam_step_workspace_bytes": (sz, [i32, i32, i32]),
     "emu_llama_workspace_bytes": (sz, [vp, i32, i32]),
     "emu_llama_forward": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
@@ -142,6 +146,13 @@ def lib() -> C.CDLL:
         except Exception:
             pass
         l = C.CDLL(LIB_PATH)
+        l.emu_version.restype, l.emu_version.argtypes = i32, []
+        if l.emu_version() != ABI_VERSION:
+            raise EmuHipError(f"{LIB_PATH} reports ABI version {l.emu_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                              "(`python -m emu_amd.build --force`)")
+        if _OVERRIDE:
+            import sys
+            print(f"emu_amd: EMU_HIP_LIB override active, loaded {LIB_PATH} (tools A/B mode)", file=sys.stderr)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args

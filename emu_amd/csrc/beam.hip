@@ -12,6 +12,14 @@
 //      the scorer's bookkeeping, statement for statement the host's: the N best non-finished candidates keep running, the
 //      finished ones among the first N candidates (EOS or the length limit) compete with the kept results at
 //      score / (len ** length_penalty), and the early-stopping heuristic compares the best running beam with the worst kept one.
+// Two scorer conventions (BeamStepArgs::hf431): 0 = the vectorised search of transformers 5.x (what is installed here and what the
+// golden fixtures pin): a hypothesis that ends -- by EOS or at the length limit -- is scored over cur + 1 tokens, only the first N
+// candidates may end, the heuristic looks at the best RUNNING beam.  1 = BeamSearchScorer / BeamHypotheses of transformers 4.31 (the
+// release the reference pins, Emu2/requirements.txt:2; restated, not runnable here): an EOS hypothesis is scored over the cur tokens
+// before the EOS (`hyp.shape[-1] ** length_penalty`), the heuristic looks at the best of all 2N candidates, and at the length limit
+// `finalize` adds every running beam at L ** length_penalty unless the prompt is already done.
+// The step index and everything derived from it (EOS suppression below min_len, the length divisors) are read from a device counter
+// when one is given, so a captured hipGraph replays the step for every token.
 // Out: the N tokens to feed next, the beam each of them extends (flat cache row, for the KV re-order), the updated state.
 #include "common.h"
 #include "kernels.h"
@@ -54,6 +62,9 @@ __global__ __launch_bounds__(NT) void beam_chunk_kernel(const BeamStepArgs a, fl
     __shared__ float red_v[NW];
     __shared__ int red_i[NW];
     const int c = blockIdx.x, j = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cur = a.cur_dev ? *a.cur_dev : a.cur;
+    if (cur >= a.L) return;                            // graph replays beyond the length limit are no-ops
+    const bool suppress_eos = cur < a.min_len;
     const bf16_t* r = a.logits + (size_t)b * a.ld_prompt + (size_t)j * a.ld_beam;
     float x[4]; int vi[4];
 #pragma unroll
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(NT) void beam_chunk_kernel(const BeamStepArgs a, fl
     // (the statistics include the EOS logit: the library masks its LOG-PROBABILITY, after the softmax)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        if (a.suppress_eos && vi[e] == a.eos_id) x[e] = -INFINITY;
+        if (suppress_eos && vi[e] == a.eos_id) x[e] = -INFINITY;
     const int T = 2 * a.nb;
     for (int k = 0; k < T; ++k) {
         float bv = -INFINITY; int bi = 0x7fffffff;
@@ -106,7 +117,8 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const BeamStepArgs a, con
     __shared__ int cand[2 * BEAM_MAXN][BEAM_MAXL];     // candidate sequences
     __shared__ int kept[BEAM_MAXN][BEAM_MAXL];         // kept results before this step
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int nb = a.nb, V = a.V, L = a.L, cur = a.cur;
+    const int nb = a.nb, V = a.V, L = a.L, cur = a.cur_dev ? *a.cur_dev : a.cur;
+    if (cur >= L) return;
     int* run_seq = a.running_seq + (size_t)b * nb * L;
     int* res_seq = a.sequences + (size_t)b * nb * L;
     float* run_sc = a.running_scores + (size_t)b * nb;
@@ -163,11 +175,16 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const BeamStepArgs a, con
         bool hits[2 * BEAM_MAXN];
         float run_lp[2 * BEAM_MAXN], fin_lp[2 * BEAM_MAXN];
         const bool open = a.heuristic_open[b] != 0;
+        const bool v431 = a.hf431 != 0, at_limit = cur + 1 >= L;
+        // (cur + 1) ** length_penalty as the host's double-precision power rounded to fp32 (the torch pipeline's divisor)
+        const float len_div = (float)pow((double)(cur + 1), (double)a.length_penalty);
+        const float eos_div = (v431 && cur > 0) ? (float)pow((double)cur, (double)a.length_penalty) : len_div;
         for (int k = 0; k < n2; ++k) {
             const int tok = top_idx[k] % V;
-            hits[k] = tok == a.eos_id || cur + 1 >= L;
+            const bool eos = tok == a.eos_id;
+            hits[k] = eos || (!v431 && at_limit);      // 4.31: at the limit the non-EOS candidates still become running beams
             run_lp[k] = top_lp[k] + (hits[k] ? 1.f : 0.f) * BEAM_NEG;
-            float f = top_lp[k] / a.len_div;
+            float f = top_lp[k] / (eos ? eos_div : len_div);
             f = f + (open ? 0.f : 1.f) * BEAM_NEG;
             const bool just = hits[k] && k < nb;       // only the first N candidates may finish
             f = f + (just ? 0.f : 1.f) * BEAM_NEG;
@@ -198,14 +215,34 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const BeamStepArgs a, con
             new_fin[j] = best < nb ? fin[best] : (unsigned char)(hits[best - nb] && best - nb < nb);
             new_len[j] = best < nb ? res_len[best] : cur + 1;
         }
-        // early-stopping heuristic (early_stopping=False): can the best running beam still beat the worst kept result?
-        const float best_run = new_rs[0] / a.len_div;
-        float worst = INFINITY; bool any_unfinished = false;
-        for (int j = 0; j < nb; ++j) { worst = fminf(worst, new_sc[j]); any_unfinished |= !new_fin[j]; }
+        // early-stopping heuristic (early_stopping=False): can the best running beam (4.31: the best of all 2N candidates, an
+        // EOS one included) still beat the worst kept result?
+        const float best_run = (v431 ? top_lp[0] : new_rs[0]) / len_div;
+        float worst = INFINITY;
+        for (int j = 0; j < nb; ++j) worst = fminf(worst, new_sc[j]);
         bool still = false;
         for (int j = 0; j < nb; ++j) still |= best_run > (new_fin[j] ? worst : BEAM_NEG);
-        (void)any_unfinished;
-        a.heuristic_open[b] = (unsigned char)(open && still);
+        const bool open_now = open && still;
+        a.heuristic_open[b] = (unsigned char)open_now;
+        // 4.31 `finalize` at the length limit: the N running beams (now L tokens long) join the kept results at L ** length_penalty
+        // unless the prompt is done; entries nb + n2 + j of the merge below are running beam j (= candidate nxt[j])
+        if (v431 && at_limit) {
+            float k_sc[BEAM_MAXN]; int k_src[BEAM_MAXN]; int k_len[BEAM_MAXN]; unsigned char k_fin[BEAM_MAXN];
+            for (int j = 0; j < nb; ++j) { k_sc[j] = new_sc[j]; k_src[j] = keep[j]; k_len[j] = new_len[j]; k_fin[j] = new_fin[j]; }
+            bool used2[2 * BEAM_MAXN] = {};
+            for (int j = 0; j < nb; ++j) {
+                int best = -1; float bs = 0.f;
+                for (int e = 0; e < 2 * nb; ++e) {
+                    if (used2[e]) continue;
+                    const float sc = e < nb ? k_sc[e] : new_rs[e - nb] / len_div + (open_now ? 0.f : 1.f) * BEAM_NEG;
+                    if (best < 0 || sc > bs) { best = e; bs = sc; }
+                }
+                used2[best] = true;
+                new_sc[j] = bs;
+                if (best < nb) { keep[j] = k_src[best]; new_fin[j] = k_fin[best]; new_len[j] = k_len[best]; }
+                else { keep[j] = nb + nxt[best - nb]; new_fin[j] = 1; new_len[j] = cur + 1; }
+            }
+        }
     }
     __syncthreads();
     for (int q = tid; q < nb * L; q += NT) {
@@ -230,7 +267,7 @@ size_t beam_step_ws_floats(int B, int nb, int V) { return (size_t)B * nb * ((V +
 
 int launch_beam_step(const BeamStepArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
     if (a.B < 1 || a.nb < 1 || a.nb > BEAM_MAXN || a.L < 1 || a.L > BEAM_MAXL || a.cur < 0 || a.cur >= a.L || a.V < 2 * a.nb ||
-        !(a.len_div > 0.f) || !ws || ws_floats < beam_step_ws_floats(a.B, a.nb, a.V))
+        a.min_len < 0 || !ws || ws_floats < beam_step_ws_floats(a.B, a.nb, a.V))
         return -22;
     const int nchunk = (a.V + CHUNK - 1) / CHUNK;
     hipLaunchKernelGGL(beam_chunk_kernel, dim3(nchunk, a.nb, a.B), dim3(NT), 0, s, a, ws, nchunk);

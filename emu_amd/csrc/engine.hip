@@ -75,7 +75,7 @@ int emu_ctx_fail(emu_ctx* c, int code, const char* what) { return fail(c, code, 
 
 extern "C" {
 
-int emu_version(void) { return 1; }
+int emu_version(void) { return 2; }      // ABI version: emu_amd/_lib.py::ABI_VERSION must match
 
 void emu_set_splitk_scratch(void* ptr, size_t bytes) { emu_gemm_set_splitk_scratch(reinterpret_cast<float*>(ptr), bytes / sizeof(float)); }
 void emu_gemm_force_config(int cfg) { emu_gemm_force_config_set(cfg); }
@@ -505,14 +505,14 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
 }
 
 size_t emu_beam_step_workspace_bytes(int Bn, int nb, int V) { return beam_step_ws_floats(Bn, nb, V) * sizeof(float); }
-int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, int Bn, int nb, int L, int cur, int suppress_eos,
-                       int eos_id, float len_div, int32_t* running_seq, int32_t* sequences, float* running_scores, float* beam_scores,
+int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, int Bn, int nb, int L, int cur, const int32_t* cur_dev,
+                       int min_len, int eos_id, float length_penalty, int hf431, int32_t* running_seq, int32_t* sequences, float* running_scores, float* beam_scores,
                        unsigned char* finished, int32_t* seq_len, unsigned char* heuristic_open, int32_t* next_tok, long* beam_flat,
                        void* workspace, size_t ws_bytes, emu_stream_t s) {
     if (!logits || !running_seq || !sequences || !running_scores || !beam_scores || !finished || !seq_len || !heuristic_open ||
         !next_tok || !beam_flat)
         return -22;
-    BeamStepArgs a{B(logits), ld_prompt, ld_beam, V, Bn, nb, L, cur, suppress_eos, eos_id, len_div, running_seq, sequences,
+    BeamStepArgs a{B(logits), ld_prompt, ld_beam, V, Bn, nb, L, cur, cur_dev, min_len, eos_id, length_penalty, hf431, running_seq, sequences,
                    running_scores, beam_scores, finished, seq_len, heuristic_open, next_tok, beam_flat};
     return launch_beam_step(a, reinterpret_cast<float*>(workspace), ws_bytes / sizeof(float), S(s));
 }

@@ -613,7 +613,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
             if (a.res) rest.res = a.res + head.N;
             if (a.bias2) rest.bias2 = a.bias2 + head.N;
             if (a.ln_c) { rest.ln_c = a.ln_c + head.N; rest.ln_d = a.ln_d + head.N; }
-            if (a.row_stats_out) rest.row_stats_out = a.row_stats_out + (size_t)(head.N >> 6) * a.M * 2;
+            if (a.row_stats_out) rest.row_stats_out = a.row_stats_out + (size_t)(head.N / LN_SLOT_COLS) * a.M * 2;   // slots of 128 columns
             rest.C = a.C + (GLU ? head.N / 2 : head.N);
             int st = launch_gemm256(head, s, -1, 1);
             if (st != 0) return st;
@@ -689,7 +689,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7)) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
     if (a.bias2 && a.rows_per_batch < 1) return -22;
-    // fused LayerNorm / V^T epilogues: whole quads only, statistics slots of 64 columns
+    // fused LayerNorm / V^T epilogues: whole quads only, statistics slots of LN_SLOT_COLS = 128 columns
     if (!gemm_fx_ok(a.epi, gemm_fx(a))) return -22;
     if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
     if (a.row_stats_out && ((a.N & 127) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||

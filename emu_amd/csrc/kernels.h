@@ -209,8 +209,10 @@ struct BeamStepArgs {
     const bf16_t* logits;                      // row of (prompt b, beam j) = logits + b * ld_prompt + j * ld_beam
     long ld_prompt, ld_beam;                   // elements (step 0: ld_beam = 0, every beam continues the prompt)
     int V, B, nb, L, cur;                      // vocabulary, prompts, beams, max new tokens, tokens generated so far
-    int suppress_eos, eos_id;
-    float len_div;                             // (cur + 1) ** length_penalty
+    const int32_t* cur_dev;                    // non-null: the step index is read here instead (hipGraph replay); steps >= L are no-ops
+    int min_len, eos_id;                       // EOS is masked while cur < min_len
+    float length_penalty;
+    int hf431;                                 // scorer conventions: 0 = transformers 5.x, 1 = transformers 4.31 (beam.hip)
     int32_t* running_seq; int32_t* sequences;  // [B, nb, L]
     float* running_scores; float* beam_scores; // [B, nb]
     unsigned char* finished; int32_t* seq_len; // [B, nb]

@@ -89,6 +89,9 @@ class EmuModel:
         self.image_placeholder = DEFAULT_IMG_TOKEN + DEFAULT_IMAGE_TOKEN * self.n_query + DEFAULT_IMG_END_TOKEN
         self.video_placeholder = DEFAULT_IMG_TOKEN + DEFAULT_gIMG_TOKEN * self.v_query + DEFAULT_IMG_END_TOKEN
         self.use_graph = False
+        # beam-search conventions: the transformers release the reference pins (Emu2/requirements.txt:2); "5.x" = the installed
+        # library's vectorised search, the one the golden fixtures can pin (LlamaEngine.beam_search_generate)
+        self.hf_semantics = "4.31"
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def device(self, module=None):
@@ -190,10 +193,12 @@ class EmuModel:
                      stop_on_eos: bool = True, num_beams: int = 1, length_penalty: float = -1.0, do_sample: bool = False,
                      temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0,
                      penalty_alpha: Optional[float] = None, no_repeat_ngram_size: int = 0,
-                     num_return_sequences: int = 1) -> torch.Tensor:
+                     num_return_sequences: int = 1, hf_semantics: Optional[str] = None) -> torch.Tensor:
         """``generate`` at the token-id level: returns the NEW ids [B, n] (what HF returns for inputs_embeds).  Mode
         selection as transformers does it: contrastive search (penalty_alpha > 0, top_k > 1, one beam, no sampling), beam
-        search / beam sampling (num_beams > 1), sampling or penalised greedy, plain greedy (device-side loop, hipGraph)."""
+        search / beam sampling (num_beams > 1), sampling or penalised greedy, plain greedy (device-side loop, hipGraph).
+        ``hf_semantics`` (default: ``self.hf_semantics`` = "4.31", the transformers release the reference pins): beam-search
+        conventions, see ``LlamaEngine.beam_search_generate``; "5.x" = the installed library the golden fixtures come from."""
         B, S = input_ids.shape
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
@@ -211,7 +216,8 @@ class EmuModel:
                                                         length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,
                                                         do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
                                                         repetition_penalty=repetition_penalty, no_repeat_ngram_size=ngram,
-                                                        num_return_sequences=nret)
+                                                        num_return_sequences=nret,
+                                                        hf_semantics=hf_semantics or getattr(self, "hf_semantics", "4.31"))
         if do_sample or repetition_penalty != 1.0 or ngram or nret != 1:
             return self.decoder.lm.sample_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len, do_sample,
                                                    temperature, top_k, top_p, repetition_penalty, eos_id=EOS_TOKEN_ID,

@@ -221,6 +221,8 @@ class Emu:
         self.visual = VitEngine(self.vision_cfg, self.ctx)
         self.cformer = CausalFormer(self.t5_cfg, self.vision_cfg.width, self.llama_cfg.hidden_size, self.ctx)
         self.lm = LlamaEngine(self.llama_cfg, vocab, self.ctx)
+        # Emu1/requirements.txt:2 leaves transformers unpinned: the beam-search conventions of the current library
+        self.hf_semantics = "5.x"
         self.ln_w = self.ln_b = None
         self.n_causal = self.t5_cfg.n_causal
         self.image_placeholder = "[IMG]" + "<image>" * self.n_causal + "[/IMG]"
@@ -266,7 +268,8 @@ class Emu:
     def generate_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, image: Optional[torch.Tensor] = None,
                      num_beams: int = 5, max_new_tokens: int = 50, min_length: int = 1, length_penalty: float = 0.0,
                      do_sample: bool = False, temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0,
-                     penalty_alpha=None, no_repeat_ngram_size=None, num_return_sequences: int = 1):
+                     penalty_alpha=None, no_repeat_ngram_size=None, num_return_sequences: int = 1,
+                     hf_semantics: Optional[str] = None):
         B, S = input_ids.shape
         x = self.lm.embed_tokens(input_ids).view(B * S, -1)
         if image is not None:
@@ -289,7 +292,8 @@ class Emu:
                                                 eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID, do_sample=do_sample,
                                                 temperature=temperature, top_k=top_k, top_p=top_p,
                                                 repetition_penalty=repetition_penalty, no_repeat_ngram_size=ngram,
-                                                num_return_sequences=nret)
+                                                num_return_sequences=nret,
+                                                hf_semantics=hf_semantics or getattr(self, "hf_semantics", "5.x"))
         if do_sample or repetition_penalty != 1.0 or ngram or nret != 1:
             return self.lm.sample_generate(x, attention_mask, max_new_tokens, min_length, do_sample, temperature, top_k, top_p,
                                            repetition_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,

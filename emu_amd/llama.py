@@ -259,13 +259,14 @@ class LlamaEngine:
                 return b
         return cap
 
-    def alloc_kv(self, batch: int, s_max: int) -> None:
+    def alloc_kv(self, batch: int, s_max: int, zero: bool = True) -> None:
         if batch == self.kv_batch and s_max == self.s_max and self.kcache is not None:
             self.set_kv_share(0, 0)
             return
         L, Hl, D = self.cfg.num_hidden_layers, self.plan.heads_local, self.cfg.head_dim
-        self.kcache = torch.zeros(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
-        self.vcache = torch.zeros(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
+        make = torch.zeros if zero else torch.empty
+        self.kcache = make(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
+        self.vcache = make(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
         self.kv_batch, self.s_max = batch, s_max
         check(lib().emu_llama_set_kv(self.handle, self.kcache.data_ptr(), self.vcache.data_ptr(), batch, s_max),
               "emu_llama_set_kv")
@@ -288,16 +289,22 @@ class LlamaEngine:
         copy (6 GB at S = 770, 5 beams, 60 layers) and the prompt's keys cross the memory system once per step, not n times."""
         k_old, v_old = self.kcache, self.vcache
         self.kcache = self.vcache = None
-        self.alloc_kv(B * n, s_max)
+        # no zero fill: every slot a row reads was written first (the prompt's by the copy below -- with set_kv_share only the
+        # group's first row is ever read there -- and a generated slot by the step that appends it)
+        self.alloc_kv(B * n, s_max, zero=False)
         if 2 <= n <= self.KV_SHARE_MAX:
             first = torch.arange(B, device=self.device) * n
             self.kcache[:, first, :, :S] = k_old[:, :, :, :S]
+            del k_old
             self.vcache[:, first, :, :S] = v_old[:, :, :, :S]
+            del v_old
             self.set_kv_share(n, S)
         else:
             rep = torch.arange(B, device=self.device).repeat_interleave(n)
             self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
+            del k_old
             self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
+            del v_old
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         need = lib().emu_llama_workspace_bytes(self.handle, B, T)
@@ -569,8 +576,17 @@ class LlamaEngine:
         beam scores are added, THEN the warpers (temperature / top-k / top-p) act on the accumulated rows, and the 2N
         draws are sorted by score before the beam bookkeeping (so "only the first N candidates may finish" is by rank, not
         by draw order), and all N beams start at score 0 instead of (0, -1e9, ...); "5.x" = processors and warpers on the per-beam log-probabilities, scores added afterwards, draws
-        kept in draw order.  With temperature 1 and no top-k / top-p the two differ only in the sort.  The deterministic
-        modes (do_sample=False) are the same in both.
+        kept in draw order.  With temperature 1 and no top-k / top-p the two differ only in the sort.
+        It also selects the SCORER conventions, in every mode (do_sample or not): "5.x" = the vectorised search of the installed
+        library, which the golden fixtures pin (a hypothesis that ends, by EOS or at the length limit, is scored over cur + 1
+        tokens; only the first N candidates may end; the early-stopping heuristic looks at the best running beam); "4.31" =
+        ``BeamSearchScorer`` / ``BeamHypotheses`` of the pinned release: ``add`` divides an EOS hypothesis by
+        ``hyp.shape[-1] ** length_penalty`` where the hypothesis excludes the EOS (cur tokens: with ``inputs_embeds`` the ids
+        start empty), ``is_done`` compares the best of ALL 2N candidates at (cur + 1) ** length_penalty with the worst kept
+        score, and at the length limit ``finalize`` adds every running beam at L ** length_penalty unless the prompt is done.
+        With the reference's default length_penalty = -1 the two rank hypotheses of different lengths differently.  The 4.31
+        conventions are restated from that release (it cannot be installed here): UNPINNED beyond a per-hypothesis restatement
+        in tests/test_host_logic.py.
 
         ``no_repeat_ngram_size`` adds the library's NoRepeatNGramLogitsProcessor to the pipeline; ``num_return_sequences`` = n
         returns the n best results of every prompt ([B * n, len], prompt-major: what Emu1's ``num_captions`` asks for,
@@ -600,7 +616,7 @@ class LlamaEngine:
         if (not do_sample and repetition_penalty == 1.0 and not ngram and trace is None and nb <= 8 and max_len <= 256
                 and V >= 2 * nb and hasattr(self, "handle") and logits.dtype == BF16):
             return self._beam_search_device(logits, B, S, nb, max_len, min_len, length_penalty, eos_id, pad_id, kstart_b, pos,
-                                            int(num_return_sequences))
+                                            int(num_return_sequences), hf_semantics == "4.31")
         logits = logits.float()
         running_seq = torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=dev)
         sequences = running_seq.clone()
@@ -618,7 +634,8 @@ class LlamaEngine:
         cur = 0
         lp_rows = logits[:, None, :].expand(B, nb, V)                                   # step 0: every beam = the prompt
         margin = float("inf")
-        old = do_sample and hf_semantics == "4.31"
+        v431 = hf_semantics == "4.31"
+        old = do_sample and v431
         while True:
             log_probs = torch.log_softmax(lp_rows, dim=-1)
             if do_sample or repetition_penalty != 1.0 or ngram:
@@ -644,7 +661,9 @@ class LlamaEngine:
             tok = top_idx % V
             cand_seq = gather(running_seq, src_beam)
             cand_seq[:, :, cur] = tok
-            hits = (tok == eos_id) | (cur + 1 >= max_len)
+            at_limit = cur + 1 >= max_len
+            # 4.31: at the length limit the non-EOS candidates still become running beams (finalize adds them below)
+            hits = (tok == eos_id) if v431 else (tok == eos_id) | at_limit
             # running beams for the next step: best N non-finished candidates
             run_lp = top_lp + hits.float() * NEG
             nxt = torch.topk(run_lp, k=nb)[1]
@@ -655,7 +674,8 @@ class LlamaEngine:
             running_scores = torch.gather(run_lp, 1, nxt)
             beam_idx = torch.gather(src_beam, 1, nxt)                                   # which old beam each new beam extends
             # finished results: only the top-N candidates may finish; merge with the kept ones
-            fin_lp = top_lp / float((cur + 1) ** length_penalty)
+            # 4.31 BeamHypotheses.add: an EOS hypothesis is scored over the cur tokens ahead of the EOS
+            fin_lp = top_lp / float((cur if (v431 and cur > 0) else cur + 1) ** length_penalty)
             fin_lp = fin_lp + (~heuristic_open).float() * NEG
             just = hits & top_mask[None, :]
             fin_lp = fin_lp + (~just).float() * NEG
@@ -670,9 +690,19 @@ class LlamaEngine:
             seq_len = torch.gather(m_len, 1, keep)
             cur += 1
             # early-stop heuristic (early_stopping=False): can the best running beam still beat the worst kept result?
-            best_run = running_scores[:, :1] / float(cur ** length_penalty)
+            # (4.31 is_done: the best of all 2N candidates, an EOS one included)
+            best_run = (top_lp[:, :1] if v431 else running_scores[:, :1]) / float(cur ** length_penalty)
             worst_fin = torch.where(finished, beam_scores.min(dim=1, keepdim=True)[0], torch.full_like(beam_scores, NEG))
             heuristic_open = heuristic_open & (best_run > worst_fin).any(dim=-1, keepdim=True)
+            if v431 and cur >= max_len:
+                # 4.31 finalize: the running beams (now L tokens) join the kept results at L ** length_penalty unless done
+                fin2 = running_scores / float(cur ** length_penalty) + (~heuristic_open).float() * NEG
+                m_sc = torch.cat((beam_scores, fin2), dim=1)
+                keep = torch.topk(m_sc, k=nb)[1]
+                sequences = gather(torch.cat((sequences, running_seq), dim=1), keep)
+                beam_scores = torch.gather(m_sc, 1, keep)
+                finished = torch.gather(torch.cat((finished, torch.ones_like(finished)), dim=1), 1, keep)
+                seq_len = torch.gather(torch.cat((seq_len, torch.full((B, nb), cur, dtype=torch.int64, device=dev)), dim=1), 1, keep)
             # (every candidate is a hit exactly when the length limit is reached: a beam contributes EOS at most once, so the 2N
             # candidates are never all EOS -- known on the host, one device read per step instead of two)
             if cur >= max_len or not bool(heuristic_open.any()):
@@ -703,7 +733,7 @@ class LlamaEngine:
 
     def _beam_search_device(self, logits0: torch.Tensor, B: int, S: int, nb: int, max_len: int, min_len: int,
                             length_penalty: float, eos_id: int, pad_id: int, kstart_b: torch.Tensor, pos: torch.Tensor,
-                            nret: int) -> torch.Tensor:
+                            nret: int, v431: bool = True) -> torch.Tensor:
         """The loop of ``beam_search_generate`` for the deterministic mode with every step's log-softmax, 2N-best selection and
         scorer bookkeeping in one launch (``emu_beam_step_bf16``, csrc/beam.hip: the same statements as the torch pipeline, which
         stays the specification and the fallback).  Per step the host enqueues: the beam-step kernel, the re-order of the
@@ -728,9 +758,8 @@ class LlamaEngine:
         cur = 0
         L = lib()
         while True:
-            len_div = float(torch.tensor(float((cur + 1) ** length_penalty), dtype=torch.float32))
-            check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, cur, int(cur < min_len), eos_id, len_div,
-                                       running_seq.data_ptr(), sequences.data_ptr(), running_scores.data_ptr(),
+            check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, cur, None, int(min_len), eos_id,
+                                       float(length_penalty), int(v431), running_seq.data_ptr(), sequences.data_ptr(), running_scores.data_ptr(),
                                        beam_scores.data_ptr(), finished.data_ptr(), seq_len.data_ptr(), still_open.data_ptr(),
                                        next_tok.data_ptr(), beam_flat.data_ptr(), ws.data_ptr(), ws.numel(),
                                        ops.stream(self.device)), "emu_beam_step_bf16", self.ctx.handle)

@@ -245,21 +245,28 @@ int emu_llama_greedy_step(emu_llama* m, int B, int32_t* cur_ids, int32_t* pos, i
                           size_t ws_bytes, emu_stream_t s);
 
 /* One step of transformers' beam search (lm.generate(num_beams=N), Emu2/emu/emu.py:163-172,213-229: the library's BeamSearchScorer
- * logic in its vectorised form), deterministic mode, in one launch: log-softmax of the N beams' logit rows of every prompt, the 2N
- * best continuations over beams x vocabulary of (log p + running score) with EOS masked while suppress_eos, then the bookkeeping --
+ * logic in its vectorised form), deterministic mode, in two launches: log-softmax of the N beams' logit rows of every prompt, the 2N
+ * best continuations over beams x vocabulary of (log p + running score) with EOS masked while cur < min_len, then the bookkeeping --
  * the N best non-finished candidates keep running; candidates among the first N that hit EOS or the length limit L compete with the
- * kept results at score / len_div (len_div = (cur + 1) ** length_penalty); the early-stopping heuristic (early_stopping=False)
- * clears heuristic_open[b] when the best running beam cannot beat the worst kept result any more.
+ * kept results at score / len ** length_penalty; the early-stopping heuristic (early_stopping=False) clears heuristic_open[b] when
+ * no continuation can beat the worst kept result any more.  hf431 selects the scorer conventions: 0 = transformers 5.x (the library
+ * installed beside this repo, which the golden fixtures pin: every ending hypothesis is scored over cur + 1 tokens, the heuristic
+ * looks at the best running beam); 1 = transformers 4.31, the release the reference pins (Emu2/requirements.txt:2;
+ * BeamHypotheses.add divides an EOS hypothesis by the cur tokens ahead of the EOS, is_done looks at the best of all 2N candidates,
+ * finalize adds the running beams at the length limit unless the prompt is done) -- restated from that release, not runnable here.
+ * cur: tokens generated so far; cur_dev (device int32, may be NULL) overrides it so that a captured hipGraph replays the step for
+ * every token (steps with cur >= L do nothing).
  * logits row of (prompt b, beam j) = logits + b * ld_prompt + j * ld_beam elements (step 0: ld_beam = 0).  State, updated in
  * place (device): running_seq / sequences int32 [B, nb, L], running_scores / beam_scores f32 [B, nb] (initial: running (0, -1e9, ...),
  * kept -1e9), finished u8 [B, nb], seq_len int32 [B, nb], heuristic_open u8 [B] (initial 1).  Out: next_tok int32 [B * nb] (the tokens
  * to feed), beam_flat int64 [B * nb] (cache row b * nb + beam each of them continues).  nb <= 8, L <= 256, cur < L.
  * workspace: emu_beam_step_workspace_bytes(B, nb, V) of device scratch (per-chunk partial results of the first of the two launches). */
 size_t emu_beam_step_workspace_bytes(int B, int nb, int V);
-int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, int B, int nb, int L, int cur, int suppress_eos,
-                       int eos_id, float len_div, int32_t* running_seq, int32_t* sequences, float* running_scores,
-                       float* beam_scores, unsigned char* finished, int32_t* seq_len, unsigned char* heuristic_open,
-                       int32_t* next_tok, long* beam_flat, void* workspace, size_t ws_bytes, emu_stream_t s);
+int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, int B, int nb, int L, int cur, const int32_t* cur_dev,
+                       int min_len, int eos_id, float length_penalty, int hf431, int32_t* running_seq, int32_t* sequences,
+                       float* running_scores, float* beam_scores, unsigned char* finished, int32_t* seq_len,
+                       unsigned char* heuristic_open, int32_t* next_tok, long* beam_flat, void* workspace, size_t ws_bytes,
+                       emu_stream_t s);
 
 /* ---- EVA-CLIP ViT engine -------------------------------------------------------------------------------
  * EVAVisionTransformer.forward_features (eva_vit.py:402-431), post-norm blocks (:296-300), naive attention

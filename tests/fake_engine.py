@@ -41,10 +41,12 @@ class FakeEngine:
             out[:, :, :min(sh, n_past)] = cache_l[first, :, :min(sh, n_past)]
         return out
 
-    def alloc_kv(self, batch, s_max):
+    def alloc_kv(self, batch, s_max, zero=True):
         L, H, D = self.rcfg.layers, self.rcfg.heads, self.rcfg.head_dim
-        self.kcache = torch.zeros(L, batch, H, s_max, D, dtype=self.dtype)
-        self.vcache = torch.zeros(L, batch, H, s_max, D, dtype=self.dtype)
+        # zero=False (the product's fan-out allocates without a fill): NaN here, so a read of a never-written slot cannot pass
+        make = torch.zeros if zero else (lambda *a, **k: torch.full(a, float("nan"), **k))
+        self.kcache = make(L, batch, H, s_max, D, dtype=self.dtype)
+        self.vcache = make(L, batch, H, s_max, D, dtype=self.dtype)
         self.kv_batch, self.s_max = batch, s_max
         self.share = (0, 0)
 

@@ -17,9 +17,9 @@ def topk_stable(x, k):
     return v[..., :k], i[..., :k]
 
 
-def torch_step(st, lp_rows, cur, min_len, max_len, length_penalty, eos_id):
+def torch_step(st, lp_rows, cur, min_len, max_len, length_penalty, eos_id, v431=False):
     """One iteration of the torch pipeline (emu_amd/llama.py::beam_search_generate, deterministic branch), on a dict of state, with
-    its three top-k calls made stable."""
+    its three top-k calls made stable.  v431: the scorer conventions of transformers 4.31 (hf_semantics="4.31")."""
     B, nb, V = lp_rows.shape
     dev = lp_rows.device
     gather = lambda t, idx: torch.gather(t, 1, idx.reshape(B, -1, *([1] * (t.dim() - 2))).expand(-1, -1, *t.shape[2:]))
@@ -32,13 +32,13 @@ def torch_step(st, lp_rows, cur, min_len, max_len, length_penalty, eos_id):
     src_beam, tok = top_idx // V, top_idx % V
     cand_seq = gather(st["running_seq"], src_beam)
     cand_seq[:, :, cur] = tok
-    hits = (tok == eos_id) | (cur + 1 >= max_len)
+    hits = (tok == eos_id) if v431 else (tok == eos_id) | (cur + 1 >= max_len)
     run_lp = top_lp + hits.float() * NEG
     nxt = topk_stable(run_lp, nb)[1]
     st["running_seq"] = gather(cand_seq, nxt)
     st["running_scores"] = torch.gather(run_lp, 1, nxt)
     beam_idx = torch.gather(src_beam, 1, nxt)
-    fin_lp = top_lp / float((cur + 1) ** length_penalty)
+    fin_lp = top_lp / float((cur if (v431 and cur > 0) else cur + 1) ** length_penalty)
     fin_lp = fin_lp + (~st["open"]).float() * NEG
     top_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)]).to(dev)
     just = hits & top_mask[None, :]
@@ -52,14 +52,23 @@ def torch_step(st, lp_rows, cur, min_len, max_len, length_penalty, eos_id):
     st["beam_scores"] = torch.gather(m_sc, 1, keep)
     st["finished"] = torch.gather(m_fin, 1, keep)
     st["seq_len"] = torch.gather(m_len, 1, keep)
-    best_run = st["running_scores"][:, :1] / float((cur + 1) ** length_penalty)
+    best_run = (top_lp[:, :1] if v431 else st["running_scores"][:, :1]) / float((cur + 1) ** length_penalty)
     worst_fin = torch.where(st["finished"], st["beam_scores"].min(dim=1, keepdim=True)[0], torch.full_like(st["beam_scores"], NEG))
     st["open"] = st["open"] & (best_run > worst_fin).any(dim=-1, keepdim=True)
     toks = st["running_seq"][:, :, cur].reshape(-1)
+    if v431 and cur + 1 >= max_len:                # finalize: the running beams join at L ** length_penalty unless the prompt is done
+        fin2 = st["running_scores"] / float((cur + 1) ** length_penalty) + (~st["open"]).float() * NEG
+        m_sc = torch.cat((st["beam_scores"], fin2), dim=1)
+        keep = topk_stable(m_sc, nb)[1]
+        st["sequences"] = gather(torch.cat((st["sequences"], st["running_seq"]), dim=1), keep)
+        st["beam_scores"] = torch.gather(m_sc, 1, keep)
+        st["finished"] = torch.gather(torch.cat((st["finished"], torch.ones_like(st["finished"])), dim=1), 1, keep)
+        st["seq_len"] = torch.gather(torch.cat((st["seq_len"], torch.full((B, nb), cur + 1, dtype=torch.int64, device=dev)), dim=1), 1, keep)
     flat = (beam_idx + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
     return toks, flat
 
 
+@pytest.mark.parametrize("v431", [False, True])
 @pytest.mark.parametrize("B,nb,V,max_len,min_len,lp,eos_boost", [
     (1, 5, 32274, 10, 1, -1.0, 0.0),           # the reference's defaults
     (2, 5, 32274, 12, 1, -1.0, 6.0),           # EOS often among the best: results finish, the heuristic closes
@@ -67,12 +76,14 @@ def torch_step(st, lp_rows, cur, min_len, max_len, length_penalty, eos_id):
     (2, 8, 4096, 6, 1, 0.0, 5.0),              # 8 beams, length_penalty 0 (Emu1's captions)
     (1, 2, 64, 5, 1, -1.0, 3.0),               # tiny vocabulary
 ])
-def test_beam_step_kernel_equals_the_torch_pipeline(B, nb, V, max_len, min_len, lp, eos_boost):
+def test_beam_step_kernel_equals_the_torch_pipeline(B, nb, V, max_len, min_len, lp, eos_boost, v431):
     """Random bf16 logits (exact ties included: bf16 takes few values), the EOS logit raised so that finished hypotheses, the merge
     with the kept results and the early-stopping heuristic all happen: after every step the kernel's state -- running and kept
     sequences, both score sets, finished flags, lengths, the heuristic flag -- and its outputs (tokens to feed, cache rows to
-    continue) equal the torch pipeline's under the same tie rule.  Scores are compared to 1e-4 (the log-sum-exp is summed in another
-    order; a near-tie closer than that between two beams could legitimately flip -- none does on these seeds)."""
+    continue) equal the torch pipeline's under the same tie rule, for both scorer conventions (hf431 = 0: transformers 5.x, 1: the
+    4.31 the reference pins).  Scores are compared to 1e-4 (the log-sum-exp is summed in another order; a near-tie closer than that
+    between two beams could legitimately flip -- none does on these seeds).  Under v431 the step index comes from a DEVICE counter
+    (the hipGraph-replay form of the call), and a call beyond the length limit must leave every piece of state untouched."""
     from emu_amd import ops
     from emu_amd._lib import lib, check
     dev = torch.device("cuda", 0)
@@ -96,6 +107,15 @@ def test_beam_step_kernel_equals_the_torch_pipeline(B, nb, V, max_len, min_len, 
     k_flat = torch.zeros(B * nb, dtype=torch.int64, device=dev)
     L = lib()
     ws = torch.empty(L.emu_beam_step_workspace_bytes(B, nb, V), dtype=torch.uint8, device=dev)
+    cur_dev = torch.zeros(1, **i32)
+
+    def call(cur):
+        check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, -7 if v431 else cur,
+                                   cur_dev.data_ptr() if v431 else None, min_len, eos, lp, int(v431),
+                                   k_run.data_ptr(), k_seq.data_ptr(), k_rs.data_ptr(), k_bs.data_ptr(), k_fin.data_ptr(),
+                                   k_len.data_ptr(), k_open.data_ptr(), k_tok.data_ptr(), k_flat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   ops.stream(dev)), "emu_beam_step_bf16")
+
     for cur in range(max_len):
         if cur == 0:
             lg = (torch.randn(B, V, generator=g) * 3.0).to(BF16).to(dev)
@@ -107,12 +127,9 @@ def test_beam_step_kernel_equals_the_torch_pipeline(B, nb, V, max_len, min_len, 
             lg[:, eos] += eos_boost
             lp_rows = lg.float().view(B, nb, V)
             ld_prompt, ld_beam = nb * lg.stride(0), lg.stride(0)
-        toks, flat = torch_step(ref, lp_rows, cur, min_len, max_len, lp, eos)
-        len_div = float(torch.tensor(float((cur + 1) ** lp), dtype=torch.float32))
-        check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, cur, int(cur < min_len), eos, len_div,
-                                   k_run.data_ptr(), k_seq.data_ptr(), k_rs.data_ptr(), k_bs.data_ptr(), k_fin.data_ptr(),
-                                   k_len.data_ptr(), k_open.data_ptr(), k_tok.data_ptr(), k_flat.data_ptr(), ws.data_ptr(), ws.numel(),
-                                   ops.stream(dev)), "emu_beam_step_bf16")
+        toks, flat = torch_step(ref, lp_rows, cur, min_len, max_len, lp, eos, v431)
+        cur_dev.fill_(cur)
+        call(cur)
         torch.cuda.synchronize()
         what = f"step {cur}"
         assert k_run.long().tolist() == ref["running_seq"].tolist(), what
@@ -126,6 +143,12 @@ def test_beam_step_kernel_equals_the_torch_pipeline(B, nb, V, max_len, min_len, 
             if bool(live.any()):
                 assert float((a_[live] - b_[live]).abs().max()) < 1e-4, what
     assert bool(ref["finished"].any())                                       # the scenario did finish hypotheses
+    if v431:                                                                 # a replay beyond the limit is a no-op
+        snap = [t_.clone() for t_ in (k_run, k_seq, k_rs, k_bs, k_fin, k_len, k_open, k_tok, k_flat)]
+        cur_dev.fill_(max_len)
+        call(max_len)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(snap, (k_run, k_seq, k_rs, k_bs, k_fin, k_len, k_open, k_tok, k_flat)))
 
 
 def test_beam_step_rejects_shapes_outside_its_range():
@@ -136,5 +159,6 @@ def test_beam_step_rejects_shapes_outside_its_range():
     lg = torch.zeros(1, 64, dtype=BF16, device=dev)
     p = z.data_ptr()
     for nb, L_, cur, V in ((9, 8, 0, 64), (2, 300, 0, 64), (2, 8, 8, 64), (5, 8, 0, 8)):
-        st = lib().emu_beam_step_bf16(lg.data_ptr(), 64, 0, V, 1, nb, L_, cur, 0, 2, 1.0, p, p, p, p, p, p, p, p, p, p, 1 << 20, ops.stream(dev))
+        st = lib().emu_beam_step_bf16(lg.data_ptr(), 64, 0, V, 1, nb, L_, cur, None, 0, 2, 1.0, 0, p, p, p, p, p, p, p, p, p, p, 1 << 20,
+                                      ops.stream(dev))
         assert st == -22, (nb, L_, cur, V, st)

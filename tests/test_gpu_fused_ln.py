@@ -46,8 +46,11 @@ def slot_stats(y):
     return torch.stack((v.sum(-1), (v * v).sum(-1)), dim=-1).permute(1, 0, 2).contiguous()
 
 
-# (M, N, K): attn out / to_q at 32^2, ff-out (K-sliced), proj at 64^2, ff-out at 64^2, a toy latent
-PRODUCER_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (8192, 640, 640), (8192, 640, 2560), (128, 1280, 1280), (512, 384, 320)]
+# (M, N, K): attn out / to_q at 32^2, ff-out (K-sliced), proj at 64^2, ff-out at 64^2, a toy latent, and a shape whose forced
+# 'H' launch really splits (320 tiles of 256 x 256: four tile columns on the ping-pong kernel + 256 remainder columns as a second
+# GEMM whose statistics slots start at slot 8 -- the remainder once wrote them at twice that index)
+PRODUCER_SHAPES = [(2048, 1280, 1280), (2048, 1280, 5120), (8192, 640, 640), (8192, 640, 2560), (128, 1280, 1280), (512, 384, 320),
+                   (16384, 1280, 1280)]
 
 
 @pytest.mark.parametrize("M,N,K", PRODUCER_SHAPES)

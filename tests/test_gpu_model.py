@@ -141,13 +141,20 @@ def test_generate_beam_search(tiny_model, golden_dir):
     m, W, cfg = tiny_model
     z = tiny.load(golden_dir, "generate_tiny.npz")
     img = _t(z["image"])
-    b3 = m.generate_ids(_t(z["ids3"]), _t(z["mask3"]), img.cuda(), max_new_tokens=6, num_beams=3)
+    # (the fixtures are ids of the installed transformers 5.x: its scorer conventions are selected explicitly; the product's
+    # default is the 4.31 the reference pins, which is covered on the CPU by tests/test_host_logic.py and below)
+    b3 = m.generate_ids(_t(z["ids3"]), _t(z["mask3"]), img.cuda(), max_new_tokens=6, num_beams=3, hf_semantics="5.x")
     assert b3.cpu().tolist() == z["beam3"].tolist()
     # the default mode on the fixture whose 5-beam pruning margins are >= 0.08 nat: ids of the REAL reference, exactly
     zm = tiny.load(golden_dir, "generate_margin_tiny.npz")
-    b5 = m.generate_ids(_t(zm["b5_ids"]), _t(zm["b5_mask"]), _t(zm["image"]).cuda(), max_new_tokens=int(zm["b5_n_new"]), num_beams=5)
+    b5 = m.generate_ids(_t(zm["b5_ids"]), _t(zm["b5_mask"]), _t(zm["image"]).cuda(), max_new_tokens=int(zm["b5_n_new"]), num_beams=5,
+                        hf_semantics="5.x")
     assert b5.cpu().tolist() == zm["b5_new"].tolist()
-    b1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), img.cuda(), max_new_tokens=10, num_beams=5)
+    # no hypothesis of these fixtures ends before the length limit, where the 4.31 conventions finalize the running beams at the
+    # same divisor: the default (4.31) mode must give the same ids through its own kernel path
+    assert m.hf_semantics == "4.31"
+    assert m.generate_ids(_t(z["ids3"]), _t(z["mask3"]), img.cuda(), max_new_tokens=6, num_beams=3).cpu().tolist() == z["beam3"].tolist()
+    b1 = m.generate_ids(_t(z["ids1"]), _t(z["mask1"]), img.cuda(), max_new_tokens=10, num_beams=5, hf_semantics="5.x")
     assert b1.shape == (1, 10)
 
     def ref_logprob(seq):
@@ -181,12 +188,13 @@ def test_generate_beam_sampling_and_penalised_beams(tiny_model, golden_dir):
     # penalised beam search on the ragged two-prompt fixture whose pruning margins are >= 0.08 nat in fp32
     # (tests/test_host_logic.py asserts them): BOTH rows must be the real reference's ids
     zm = tiny.load(golden_dir, "generate_margin_tiny.npz")
-    pen = m.generate_ids(_t(zm["pen_ids"]), _t(zm["pen_mask"]), None, max_new_tokens=8, num_beams=3, repetition_penalty=1.5).cpu()
+    pen = m.generate_ids(_t(zm["pen_ids"]), _t(zm["pen_mask"]), None, max_new_tokens=8, num_beams=3, repetition_penalty=1.5,
+                         hf_semantics="5.x").cpu()
     assert pen.tolist() == zm["pen_new"].tolist()
     # no_repeat_ngram_size + num_return_sequences (forwarded **kwargs of the reference's generate): 4 rows, prompt-major; the best
     # sequence of every prompt is the real reference's, no row repeats a bigram
     ng = m.generate_ids(_t(zm["pen_ids"]), _t(zm["pen_mask"]), None, max_new_tokens=8, num_beams=3, no_repeat_ngram_size=2,
-                        num_return_sequences=2).cpu()
+                        num_return_sequences=2, hf_semantics="5.x").cpu()
     assert ng.shape == (4, 8)
     # this search was not margin-screened: where the bf16 engine picks another best sequence than the reference, the two must be a
     # near-tie in the ORACLE's fp32 arithmetic (sum of log-probabilities of the 8 tokens; no token is banned on either path).

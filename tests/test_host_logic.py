@@ -112,7 +112,7 @@ def test_product_beam_search_host_logic_matches_reference(golden_dir, monkeypatc
     t = lambda a: torch.from_numpy(np.asarray(a))
     ids, mask = t(z["ids2"]), t(z["mask2"])
     x = R.embed_tokens(ids, W)
-    out = L.LlamaEngine.beam_search_generate(eng, x, mask, 5, 10)
+    out = L.LlamaEngine.beam_search_generate(eng, x, mask, 5, 10, hf_semantics="5.x")     # the fixture comes from the installed library
     assert out.tolist() == z["beam2"].tolist()
 
 
@@ -161,34 +161,69 @@ def test_product_beam_modes_on_margin_fixtures(golden_dir, monkeypatch):
     t = lambda a: torch.from_numpy(np.asarray(a))
     tr = {}
     out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), R.embed_tokens(t(z["pen_ids"]), W), t(z["pen_mask"]),
-                                             3, 8, repetition_penalty=1.5, trace=tr)
+                                             3, 8, repetition_penalty=1.5, trace=tr, hf_semantics="5.x")
     assert out.tolist() == z["pen_new"].tolist() and tr["margin"] >= 0.08, tr
     assert not bool(t(z["pen_mask"]).all())
     ids = t(z["b5_ids"])
     e = R.encode_image(t(z["image"]), W, cfg)
     x = R.scatter_image_embeds(R.embed_tokens(ids, W), ids, torch.nn.functional.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"]))
     tr = {}
-    out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, t(z["b5_mask"]), 5, int(z["b5_n_new"]), trace=tr)
+    out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, t(z["b5_mask"]), 5, int(z["b5_n_new"]), trace=tr,
+                                             hf_semantics="5.x")
     assert out.tolist() == z["b5_new"].tolist() and tr["margin"] >= 0.08, tr
 
 
-def _beam_sample_431(x, mask, W, cfg, nb, n_new, temperature, top_k, top_p, eos_id=2, pad_id=32000, length_penalty=-1.0):
-    """``GenerationMixin.beam_sample`` + ``BeamSearchScorer`` as transformers 4.31 (the version the reference pins) states
-    them, written per hypothesis with python lists and full recomputation of the decoder -- an independent statement of the
-    ordering the product's hf_semantics="4.31" mode claims: log_softmax -> MinLength -> + beam score -> temperature ->
-    top-k -> top-p (min_tokens_to_keep 2) -> multinomial(2N) -> sort by score -> scorer.  The 5.x scorer conventions the
-    product keeps in BOTH modes (a finished hypothesis is scored over its length INCLUDING the EOS; early stop by the
-    current length) are used here too: this test pins the sampling order, not the scorer."""
+class _Hyps431:
+    """``BeamHypotheses`` of transformers 4.31 (generation/beam_search.py), early_stopping=False: ``add`` scores a hypothesis by
+    sum_logprobs / len(hyp) ** length_penalty and keeps the num_beams best; ``is_done`` compares the worst kept score with
+    best_sum_logprobs / cur_len ** length_penalty."""
+
+    def __init__(self, nb, lp):
+        self.nb, self.lp, self.beams, self.worst = nb, lp, [], 1e9
+
+    def add(self, hyp, sum_logprobs):
+        score = sum_logprobs / (len(hyp) ** self.lp)
+        if len(self.beams) < self.nb or score > self.worst:
+            self.beams.append((score, list(hyp)))
+            if len(self.beams) > self.nb:
+                srt = sorted((sc, i) for i, (sc, _) in enumerate(self.beams))
+                del self.beams[srt[0][1]]
+                self.worst = srt[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.beams) < self.nb:
+            return False
+        return self.worst >= best_sum_logprobs / cur_len ** self.lp
+
+
+def _beam_431(x, mask, W, cfg, nb, n_new, do_sample=False, temperature=None, top_k=None, top_p=None, eos_id=2, pad_id=32000,
+              length_penalty=-1.0, min_len=1):
+    """``GenerationMixin.beam_search`` / ``beam_sample`` + ``BeamSearchScorer.process`` / ``finalize`` as transformers 4.31 (the
+    release the reference pins) states them, written per hypothesis with python lists and full recomputation of the decoder -- an
+    independent statement of what the product's hf_semantics="4.31" mode claims:
+      * sampling order: log_softmax -> MinLength -> + beam score -> temperature -> top-k -> top-p (min_tokens_to_keep 2) ->
+        multinomial(2N) -> sort by score -> scorer; every beam starts at score 0 (beam_search: (0, -1e9, ...));
+      * scorer: with ``inputs_embeds`` the ids start EMPTY, so a hypothesis that ends with EOS is added as the cur tokens ahead of
+        the EOS (``hyp.shape[-1] ** length_penalty`` = cur ** lp), only while its rank is < N; ``is_done`` gets the best of all 2N
+        candidate scores and cur_len = cur + 1; a done prompt adds nothing more; when the length limit ends the loop ``finalize``
+        adds every running beam (L tokens) unless the prompt is done; the result is the best kept hypothesis (+ EOS if it fits).
+    Restated from memory of that release -- it cannot be installed here: this pins the product to THIS statement, not to the library."""
     B, S, _ = x.shape
     V = W["decoder.lm.lm_head.weight"].shape[0]
     seqs = [[[] for _ in range(nb)] for _ in range(B)]
     scores = torch.zeros(B, nb)
-    hyps = [[] for _ in range(B)]                                      # (score, ids)
-    open_ = [True] * B
+    if not do_sample:
+        scores[:, 1:] = -1.0e9
+    hyps = [_Hyps431(nb, length_penalty) for _ in range(B)]
+    done = [False] * B
     for cur in range(n_new):
         nxt_seqs, nxt_scores = [], []
-        all_hit = True
         for b in range(B):
+            if done[b]:                                                 # process(): a done prompt is padded
+                nxt_seqs.append([sq + [pad_id] for sq in seqs[b]]); nxt_scores.append([0.0] * nb)
+                continue
             rows = []
             for j in range(nb):
                 xe = torch.cat((x[b:b + 1], R.embed_tokens(torch.tensor([seqs[b][j]], dtype=torch.long).view(1, -1), W)), dim=1) \
@@ -197,48 +232,59 @@ def _beam_sample_431(x, mask, W, cfg, nb, n_new, temperature, top_k, top_p, eos_
                 pos = (me.long().cumsum(-1) - 1).masked_fill(me == 0, 1)
                 h = R.llama_model(xe, me, W, cfg.llama, position_ids=pos)
                 lp = torch.log_softmax(torch.nn.functional.linear(h[0, -1], W["decoder.lm.lm_head.weight"]).float(), -1)
-                if cur < 1:
+                if cur < min_len:
                     lp[eos_id] = -float("inf")
                 rows.append(lp + scores[b, j])
             acc = torch.stack(rows)                                     # [nb, V] accumulated
-            if temperature is not None and temperature != 1.0:
-                acc = acc / temperature
-            if top_k:
-                kth = torch.topk(acc, max(top_k, 2))[0][:, -1:]
-                acc = acc.masked_fill(acc < kth, -float("inf"))
-            if top_p is not None and top_p < 1.0:
-                srt, idx = torch.sort(acc, descending=False)
-                rm = srt.softmax(-1).cumsum(-1) <= (1 - top_p)
-                rm[:, -2:] = False
-                acc = acc.masked_fill(rm.scatter(1, idx, rm), -float("inf"))
-            flat = acc.reshape(-1)
-            draw = torch.multinomial(torch.softmax(flat, -1), num_samples=2 * nb)
-            sc = flat[draw]
-            sc, order = torch.sort(sc, descending=True)
-            draw = draw[order]
+            if do_sample:
+                if temperature is not None and temperature != 1.0:
+                    acc = acc / temperature
+                if top_k:
+                    kth = torch.topk(acc, max(top_k, 2))[0][:, -1:]
+                    acc = acc.masked_fill(acc < kth, -float("inf"))
+                if top_p is not None and top_p < 1.0:
+                    srt, idx = torch.sort(acc, descending=False)
+                    rm = srt.softmax(-1).cumsum(-1) <= (1 - top_p)
+                    rm[:, -2:] = False
+                    acc = acc.masked_fill(rm.scatter(1, idx, rm), -float("inf"))
+                flat = acc.reshape(-1)
+                draw = torch.multinomial(torch.softmax(flat, -1), num_samples=2 * nb)
+                sc = flat[draw]
+                sc, order = torch.sort(sc, descending=True)
+                draw = draw[order]
+            else:
+                sc, draw = torch.topk(acc.reshape(-1), 2 * nb)
             run = []
-            for rank in range(2 * nb):
+            for rank in range(2 * nb):                                  # BeamSearchScorer.process
                 j, tok = int(draw[rank]) // V, int(draw[rank]) % V
-                hit = tok == eos_id or cur + 1 >= n_new
-                if hit:
-                    if rank < nb and open_[b]:
-                        hyps[b].append((float(sc[rank]) / float((cur + 1) ** length_penalty), seqs[b][j] + [tok]))
-                        hyps[b] = sorted(hyps[b], key=lambda t_: -t_[0])[:nb]
-                elif len(run) < nb:
+                if tok == eos_id:
+                    if rank >= nb:
+                        continue
+                    hyps[b].add(seqs[b][j], float(sc[rank]))            # input_ids of the beam: WITHOUT the EOS
+                else:
                     run.append((float(sc[rank]), seqs[b][j] + [tok]))
-                if not hit:
-                    all_hit = False
-            while len(run) < nb:
-                run.append((-1.0e9, [pad_id] * (cur + 1)))
+                if len(run) == nb:
+                    break
             nxt_seqs.append([r[1] for r in run]); nxt_scores.append([r[0] for r in run])
-            if len(hyps[b]) == nb and open_[b]:
-                open_[b] = run[0][0] / float((cur + 1) ** length_penalty) > hyps[b][-1][0]
+            done[b] = done[b] or hyps[b].is_done(float(sc.max()), cur + 1)
         seqs, scores = nxt_seqs, torch.tensor(nxt_scores)
-        if not any(open_) or all_hit:
+        if all(done):
             break
-    best = [hyps[b][0][1] for b in range(B)]
-    n = max(len(s) for s in best)
-    return torch.tensor([s + [pad_id] * (n - len(s)) for s in best])
+    for b in range(B):                                                  # BeamSearchScorer.finalize
+        if done[b]:
+            continue
+        for j in range(nb):
+            hyps[b].add(seqs[b][j], float(scores[b, j]))
+    best = []
+    for b in range(B):
+        sc, hyp = sorted(hyps[b].beams, key=lambda t_: t_[0])[-1]
+        best.append(hyp + ([eos_id] if len(hyp) < n_new else []))
+    n = max(len(s_) for s_ in best)
+    return torch.tensor([s_ + [pad_id] * (n - len(s_)) for s_ in best])
+
+
+def _beam_sample_431(x, mask, W, cfg, nb, n_new, temperature, top_k, top_p, **kw):
+    return _beam_431(x, mask, W, cfg, nb, n_new, do_sample=True, temperature=temperature, top_k=top_k, top_p=top_p, **kw)
 
 
 @pytest.mark.parametrize("kw", [dict(temperature=0.7, top_k=40, top_p=0.9), dict(temperature=None, top_k=None, top_p=None)])
@@ -267,6 +313,48 @@ def test_product_beam_sample_431_ordering(golden_dir, monkeypatch, kw):
     new = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 3, 6, do_sample=True,
                                              hf_semantics="5.x", **kw)
     assert new.shape[0] == 1                                            # the other ordering runs; it need not agree
+
+
+def test_product_beam_search_431_scorer(golden_dir, monkeypatch):
+    """Deterministic beam search under hf_semantics="4.31" (the default of EmuModel: the reference pins transformers 4.31.0):
+    the product's vectorised bookkeeping equals the per-hypothesis restatement of that release's BeamSearchScorer /
+    BeamHypotheses -- on prompts where hypotheses END EARLY, which is where 4.31 and 5.x differ (an EOS hypothesis scored over
+    cur instead of cur + 1 tokens, is_done on the best of all candidates, finalize of the running beams).  Random-init weights
+    never emit the real EOS, so tokens the searches do produce are declared EOS in turn; with length_penalty -1 (the reference's
+    default), 0 and 1.  At least one case must differ from the 5.x conventions, or the test would not see the difference."""
+    import numpy as np
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    ids, mask = t(z["ids2"]), t(z["mask2"])
+    x = R.embed_tokens(ids, W)
+    nb, n_new = 3, 6
+    base = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, nb, n_new, hf_semantics="5.x")
+    eos_choices = sorted({int(base[0, 1]), int(base[0, 3]), int(base[-1, 2])})
+    differs = 0
+    for eos in eos_choices:
+        for lp in (-1.0, 0.0, 1.0):
+            for b in range(ids.shape[0]):                               # per prompt: rows of different progress never interact
+                xb, mb = x[b:b + 1], mask[b:b + 1]
+                got = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), xb, mb, nb, n_new, length_penalty=lp,
+                                                         eos_id=eos, hf_semantics="4.31")
+                want = _beam_431(xb, mb, W, cfg, nb, n_new, eos_id=eos, length_penalty=lp)
+                assert got.tolist() == want.tolist(), (eos, lp, b, got.tolist(), want.tolist())
+                new = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), xb, mb, nb, n_new, length_penalty=lp,
+                                                         eos_id=eos, hf_semantics="5.x")
+                differs += int(new.tolist() != got.tolist())
+    assert differs > 0
+    # a batch of both prompts = the rows alone (padded to the longer result)
+    got2 = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, nb, n_new, eos_id=eos_choices[0],
+                                              hf_semantics="4.31")
+    want2 = _beam_431(x, mask, W, cfg, nb, n_new, eos_id=eos_choices[0])
+    assert got2.tolist() == want2.tolist()
 
 
 def _contrastive_uncached(x, mask, W, cfg, n_new, alpha, k, eos_id=2, pad_id=32000):
@@ -461,7 +549,7 @@ def test_product_ngram_ban_and_several_returned_sequences_match_reference(golden
     t = lambda a: torch.from_numpy(np.asarray(a))
     x, mask = R.embed_tokens(t(z["pen_ids"]), W), t(z["pen_mask"])
     out = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, 3, 8, no_repeat_ngram_size=2,
-                                             num_return_sequences=2)
+                                             num_return_sequences=2, hf_semantics="5.x")
     assert out.tolist() == z["ngram_new"].tolist() and out.shape[0] == 4
     for row in out.tolist():                                             # no bigram twice
         big = list(zip(row, row[1:]))
@@ -496,7 +584,7 @@ def test_emu1_num_captions_and_ngram_ban_match_real_reference(golden_dir, monkey
     eng = FakeEngine(l, vocab, Wb, cfg.llama, dtype=torch.bfloat16)      # bf16 arithmetic, as the reference runs the model
     tr = {}
     out = L.LlamaEngine.beam_search_generate(eng, x, mask, 5, 8, length_penalty=0.0, no_repeat_ngram_size=2, num_return_sequences=2,
-                                             trace=tr)
+                                             trace=tr, hf_semantics="5.x")     # Emu1 leaves transformers unpinned
     want = z["beam_cap2_ngram2"].tolist()
     assert out.shape == (2, 8) and out[0].tolist() == want[0]
     if tr["margin"] >= 0.05:
