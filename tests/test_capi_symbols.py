@@ -27,7 +27,7 @@ def test_library_exports_all_declared_symbols():
     missing = [s for s in declared if not hasattr(l, s)]
     assert not missing, missing
     assert set(declared) == set(_lib._PROTOS), set(declared) ^ set(_lib._PROTOS)
-    assert l.emu_version() == 1
+    assert l.emu_version() == _lib.ABI_VERSION
 
 
 def test_header_cites_reference_lines():
