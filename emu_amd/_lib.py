@@ -54,6 +54,8 @@ class UNetCfgC(C.Structure):
 
 _PROTOS = {
     "emu_version": (i32, []),
+    "emu_gemm_trace": (None, [vp]),
+    "emu_gemm_trace_built": (i32, []),
     "emu_profile_gemv": (i32, [i32]),
     "emu_profile_gemv_read": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "emu_ctx_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
@@ -121,6 +123,8 @@ _PROTOS = {
     "emu_unet_finalize": (i32, [vp]),
     "emu_unet_set_fusion": (i32, [vp, i32]),
     "emu_unet_temb_total": (i32, [vp]),
+    "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
+    "emu_vit_blocks": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
     "emu_unet_workspace_bytes": (sz, [vp, i32, i32]),
     "emu_unet_context_bytes": (sz, [vp, i32]),
     "emu_unet_set_context": (i32, [vp, vp, i32, vp, i32, vp, sz, vp, sz, vp]),

@@ -32,16 +32,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, trace: bool = False) -> str:
+    """trace=True: the tools-only twin libemu_hip_trace.so (-DEMU_TRACE: GEMM kernels write per-workgroup timelines,
+    tools/gemm_trace.py), objects in csrc/trace_obj/; never loaded by the product (emu_amd/_lib.py)."""
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    odir = os.path.join(CSRC, "trace_obj") if trace else CSRC
+    os.makedirs(odir, exist_ok=True)
+    lib_path = os.path.join(CSRC, "libemu_hip_trace.so") if trace else LIB
+    flags = FLAGS + (["-DEMU_TRACE"] if trace else [])
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(odir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -55,11 +61,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         for warn in ex.map(run, jobs):
             if warn and verbose:
                 print(warn, file=sys.stderr)
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB,
+    if force or jobs or _stale(lib_path, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path,
              "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, trace="--trace" in sys.argv))

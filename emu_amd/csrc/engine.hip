@@ -80,6 +80,14 @@ int emu_version(void) { return 2; }      // ABI version: emu_amd/_lib.py::ABI_VE
 void emu_set_splitk_scratch(void* ptr, size_t bytes) { emu_gemm_set_splitk_scratch(reinterpret_cast<float*>(ptr), bytes / sizeof(float)); }
 void emu_gemm_force_config(int cfg) { emu_gemm_force_config_set(cfg); }
 void emu_gemm_tune(int mask) { emu_gemm_tune_set(mask); }
+void emu_gemm_trace(void* buf) { emu_gemm_trace_set(reinterpret_cast<unsigned long long*>(buf)); }
+int emu_gemm_trace_built(void) {
+#ifdef EMU_TRACE
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int emu_profile_gemv(int enable) {
     g_prof.on = enable != 0;
@@ -305,6 +313,7 @@ struct emu_llama {
     bf16_t *kcache = nullptr, *vcache = nullptr;
     int kv_batch = 0, s_max = 0;
     int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
+    int l0 = 0, l1 = -1;                         // emu_llama_set_layer_range: layers [l0, l1) run (l1 < 0: all)
 };
 
 namespace {
@@ -420,6 +429,11 @@ int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots) {
     m->kv_share_nb = beams; m->kv_share_len = shared_slots;
     return 0;
 }
+int emu_llama_set_layer_range(emu_llama* m, int l0, int l1) {
+    if (!m || l0 < 0 || l1 > m->cfg.layers || (l1 >= 0 && l1 < l0)) return -22;
+    m->l0 = l0; m->l1 = l1;
+    return 0;
+}
 size_t emu_llama_workspace_bytes(const emu_llama* m, int Bn, int T) {
     if (!m) return 0;
     return llama_ws(m, Bn, T, nullptr).total;
@@ -444,7 +458,8 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     const size_t kv_layer = (size_t)Bn * Hl * m->s_max * D;
     const int spad = (ctx + 63) / 64 * 64;
     bf16_t* hA = B(hidden);
-    for (int l = 0; l < c.layers; ++l) {
+    const int l_end = m->l1 < 0 ? c.layers : m->l1;
+    for (int l = m->l0; l < l_end; ++l) {
         const emu_llama::Layer& L = m->layers[l];
         if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
         bf16_t* kc = m->kcache + l * kv_layer;
@@ -618,23 +633,15 @@ int emu_vit_set_block(emu_vit* m, int layer, const void* wqkv, const void* bqkv,
 }
 size_t emu_vit_workspace_bytes(const emu_vit* m, int Bn) { return m ? vit_ws(m, Bn, nullptr).total : 0; }
 
-int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, void* out_tokens, void* workspace,
-                    size_t ws_bytes, emu_stream_t s_) {
-    if (!m || !image || !out_tokens || !m->wpatch) return -22;
+// blocks [l0, l1) in place on tokens x [B * N, C]
+static int vit_blocks(emu_vit* m, bf16_t* x, int Bn, int l0, int l1, const VitWs& w, hipStream_t s) {
     emu_ctx* cx = m->ctx;
     const emu_vit_cfg& c = m->cfg;
-    const VitWs w = vit_ws(m, Bn, workspace);
-    if (w.total > ws_bytes) return fail(cx, -12, "emu_vit_forward: workspace too small");
-    hipStream_t s = S(s_);
     const int g = c.image_size / c.patch_size, T = g * g, N = T + 1, M = Bn * N, C = c.width, Hh = c.heads;
     const int QK = Hh * VIT_DP, F = c.mlp_hidden;
     const int npad = (N + 63) / 64 * 64;
     const float scale = 1.0f / sqrtf((float)c.head_width);
-    bf16_t* x = B(out_tokens);
-    TRY(cx, launch_patchify(image, image_is_f32, w.patches, Bn, 3, c.image_size, c.patch_size, c.kpad, s));
-    TRY(cx, linear(w.patches, m->wpatch, m->bpatch, nullptr, nullptr, w.pemb, Bn * T, C, c.kpad, c.kpad, c.kpad, 0, C, 0.f, EPI_NONE, s));
-    TRY(cx, launch_vit_assemble(w.pemb, m->cls, m->pos, x, Bn, T, C, s));
-    for (int l = 0; l < c.layers; ++l) {
+    for (int l = l0; l < l1; ++l) {
         const emu_vit::Block& Bk = m->blocks[l];
         if (!Bk.wqkv) return fail(cx, -22, "emu_vit_forward: block weights not set");
         const bf16_t* ain = x;                           // attention input
@@ -665,6 +672,29 @@ int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, voi
         }
     }
     return 0;
+}
+
+int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int Bn, void* out_tokens, void* workspace,
+                    size_t ws_bytes, emu_stream_t s_) {
+    if (!m || !image || !out_tokens || !m->wpatch) return -22;
+    emu_ctx* cx = m->ctx;
+    const emu_vit_cfg& c = m->cfg;
+    const VitWs w = vit_ws(m, Bn, workspace);
+    if (w.total > ws_bytes) return fail(cx, -12, "emu_vit_forward: workspace too small");
+    hipStream_t s = S(s_);
+    const int g = c.image_size / c.patch_size, T = g * g, C = c.width;
+    bf16_t* x = B(out_tokens);
+    TRY(cx, launch_patchify(image, image_is_f32, w.patches, Bn, 3, c.image_size, c.patch_size, c.kpad, s));
+    TRY(cx, linear(w.patches, m->wpatch, m->bpatch, nullptr, nullptr, w.pemb, Bn * T, C, c.kpad, c.kpad, c.kpad, 0, C, 0.f, EPI_NONE, s));
+    TRY(cx, launch_vit_assemble(w.pemb, m->cls, m->pos, x, Bn, T, C, s));
+    return vit_blocks(m, x, Bn, 0, c.layers, w, s);
+}
+
+int emu_vit_blocks(emu_vit* m, void* tokens, int Bn, int l0, int l1, void* workspace, size_t ws_bytes, emu_stream_t s_) {
+    if (!m || !tokens || l0 < 0 || l1 > m->cfg.layers || l1 < l0) return -22;
+    const VitWs w = vit_ws(m, Bn, workspace);
+    if (w.total > ws_bytes) return fail(m->ctx, -12, "emu_vit_blocks: workspace too small");
+    return vit_blocks(m, B(tokens), Bn, l0, l1, w, S(s_));
 }
 
 }  // extern "C"

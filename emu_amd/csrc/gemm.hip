@@ -64,6 +64,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
+    EMU_TRACE_MARK(a.trace, 0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave / (T::WN * T::WM), wtile = wave % (T::WN * T::WM);
     const int wn = wtile / T::WM, wm = wtile % T::WM;
@@ -222,6 +223,9 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt<(T::NSTG - 2) * T::LPT>();          // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                  // ... and everyone's; everyone is also done reading tile kt-1
+#ifdef EMU_TRACE
+        if (kt == 0) EMU_TRACE_MARK(a.trace, 1);
+#endif
         issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
         const char* sW = smem + (kt % T::NSTG) * T::ST_BYTES;
         const char* sA = sW + T::W_BYTES;
@@ -252,6 +256,10 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
     }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
+    EMU_TRACE_MARK(a.trace, 2);
+#ifdef EMU_TRACE
+    struct TraceEnd { unsigned long long* t; __device__ ~TraceEnd() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EMU_TRACE_MARK(t, 3); } } trace_end{a.trace};
+#endif
 
     if constexpr (T::KG > 1) {
         // sum the two k-groups' partial accumulators through LDS (the ring is dead now): group 1 writes, group 0 adds
@@ -478,6 +486,7 @@ using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves
 
 float* g_splitk_scratch = nullptr;
 size_t g_splitk_floats = 0;
+unsigned long long* g_trace = nullptr;   // emu_gemm_trace_set
 int g_force_cfg = 0;                     // emu_gemm_force_config: tests / benches pin one tile configuration
 int g_tune = 0;                          // emu_gemm_tune: A/B switches of single dispatch decisions (tools/unet_ab.py)
 
@@ -488,6 +497,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     GemmArgs b = a;
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
+    b.trace = g_trace;
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
     if (fx) {                                           // launch_gemm has checked gemm_fx_ok(epi, fx)
@@ -673,6 +683,8 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
 void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch = ptr; g_splitk_floats = floats; }
 void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; }
 void emu_gemm_tune_set(int mask) { g_tune = mask; }
+void emu_gemm_trace_set(unsigned long long* buf) { g_trace = buf; }
+unsigned long long* emu_gemm_trace_get() { return g_trace; }
 int emu_gemm_tune_get() { return g_tune; }
 
 int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {

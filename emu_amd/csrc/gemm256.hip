@@ -77,6 +77,7 @@ template <int EPI, bool CONV, bool F8, int FX = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * QXB];
     const int tid = threadIdx.x, lane = tid & 63;
+    EMU_TRACE_MARK(a.trace, 0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -337,12 +338,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         wait_vmcnt<2>();
     }
     bar();
+    EMU_TRACE_MARK(a.trace, 1);
     if (wr == 1) bar();                             // group 1 runs one barrier behind group 0
     for (int t = 0; t < nk; t += 2) {
         tile(IC<0>{}, t);
         if (t + 1 < nk) tile(IC<1>{}, t + 1);
     }
     if (wr == 0) bar();
+    EMU_TRACE_MARK(a.trace, 2);
+#ifdef EMU_TRACE
+    struct TraceEnd { unsigned long long* t; __device__ ~TraceEnd() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EMU_TRACE_MARK(t, 3); } } trace_end{a.trace};
+#endif
 
     // ---- epilogue: accumulator (x, y, i): rows n = n0 + wr*128 + x*64 + i*32 + 8*g + 4*hi + e, column m = .. + l31
     auto emit = [&](int m, int nb, float (&v)[4], RowFx& fx, const QuadIn& q) {
@@ -493,6 +499,7 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     GemmArgs b = a;
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
+    b.trace = emu_gemm_trace_get();
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
     if (fx) {                                           // gemm256_ok: bf16 plain GEMM; launch_gemm: an instantiated (epi, mask) pair

@@ -21,6 +21,27 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Per-workgroup timeline of a GEMM kernel (only in a library built with -DEMU_TRACE: `python -m emu_amd.build --trace`,
+// tools/gemm_trace.py).  Record = 8 x u64 at trace[blockIdx.x * 8]: [0] entry, [1] first k tile landed (after the first
+// barrier of the main loop), [2] main loop done, [3] epilogue stores complete -- all s_memrealtime (100 MHz, chip-wide) --,
+// [4] XCC_ID | HW_ID << 8, [5] / [6] s_memtime (shader clock) at entry / loop end, [7] logical tile.
+#ifdef EMU_TRACE
+__device__ __forceinline__ void trace_mark(unsigned long long* t, int slot) {
+    if (t && threadIdx.x == 0) {
+        t[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
+        if (slot == 0) {
+            t[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(6164) |      // XCC_ID[3:0]
+                                            ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8);   // HW_ID
+            t[(size_t)blockIdx.x * 8 + 5] = clock64();
+        }
+        if (slot == 2) t[(size_t)blockIdx.x * 8 + 6] = clock64();
+    }
+}
+#define EMU_TRACE_MARK(t, slot) trace_mark((t), (slot))
+#else
+#define EMU_TRACE_MARK(t, slot) do {} while (0)
+#endif
+
 // input pixel of output pixel (py, px) under filter tap (ky, kx); false when the tap falls outside the image
 __device__ __forceinline__ bool conv_tap(const ConvGeom& g, int py, int px, int ky, int kx, int& yi, int& xi) {
     if (g.mode == CONV_3X3_S2) {

@@ -94,8 +94,13 @@ struct GemmArgs {
     const bf16_t* cross_vt = nullptr;
     int cross_ldk = 0, cross_n = 0, cross_npad = 0, cross_rows = 0;
     float cross_scale = 0.f;
+    // ---- per-workgroup timeline (tools/gemm_trace.py; written only by a library built with -DEMU_TRACE): 8 x u64 per workgroup
+    unsigned long long* trace = nullptr;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// tools hook: where the next GEMM launches of a -DEMU_TRACE build write their per-workgroup timelines (nullptr = off)
+void emu_gemm_trace_set(unsigned long long* buf);
+unsigned long long* emu_gemm_trace_get();
 // fp8 x fp8 -> bf16 on the block-scaled MFMA (256x256 ping-pong tile only): K % 128 == 0, a.a_scale / a.w_scale set
 int launch_gemm_fp8(const GemmArgs& a, hipStream_t s);
 // the 256x256 ping-pong tile (gemm256.hip), dispatched by launch_gemm; tiles [0, full_tiles) whole-K, the rest in ksplit

@@ -329,6 +329,11 @@ class LlamaEngine:
               "emu_llama_forward", self.ctx.handle)
         return hidden
 
+    def set_layer_range(self, l0: int = 0, l1: int = -1) -> None:
+        """Parity hook (include/emu_hip.h: emu_llama_set_layer_range): ``forward`` / ``prefill`` run layers [l0, l1) only;
+        (0, -1) restores the whole stack.  Tests only."""
+        check(lib().emu_llama_set_layer_range(self.handle, int(l0), int(l1)), "emu_llama_set_layer_range", self.ctx.handle)
+
     def final_norm_rows(self, hidden: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(hidden)
         check(lib().emu_llama_final_norm(self.handle, hidden.data_ptr(), out.data_ptr(), hidden.shape[0], ops.stream(self.device)),

@@ -134,3 +134,15 @@ class VitEngine:
         return out
 
     __call__ = forward
+
+    @torch.no_grad()
+    def run_blocks(self, tokens: torch.Tensor, l0: int, l1: int) -> torch.Tensor:
+        """Parity hook (include/emu_hip.h: emu_vit_blocks): blocks [l0, l1) on a COPY of tokens [B, 1+g*g, C] bf16."""
+        x = tokens.to(device=self.device, dtype=BF16).contiguous().clone()
+        B = x.shape[0]
+        need = lib().emu_vit_workspace_bytes(self.handle, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        check(lib().emu_vit_blocks(self.handle, x.data_ptr(), B, int(l0), int(l1), self._ws.data_ptr(), self._ws.numel(),
+                                   ops.stream(self.device)), "emu_vit_blocks", self.ctx.handle)
+        return x

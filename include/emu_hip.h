@@ -73,6 +73,13 @@ void emu_gemm_force_config(int cfg);
  * v_dot2c / register-fed MFMA kernels as before round 3; bits 8-11: variant of that stream (tools/thin_ab.py). */
 void emu_gemm_tune(int mask);
 
+/* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at
+ * buf[blockIdx * 8]: entry, first k tile landed, main loop done, stores complete (s_memrealtime, 100 MHz), XCC / HW id, shader
+ * clock at entry / loop end, unused.  Written only by a library built with -DEMU_TRACE (`python -m emu_amd.build --trace` ->
+ * libemu_hip_trace.so; emu_gemm_trace_built() says which one is loaded); NULL = off.  The production library ignores it. */
+void emu_gemm_trace(void* buf);
+int emu_gemm_trace_built(void);
+
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while
  * enabled (eager launches only, not inside stream capture).  read: sum of launch durations (ms), algorithmic
  * weight bytes (2*N*K per launch) and launch count since the last enable. */
@@ -223,6 +230,10 @@ int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_
  * serves all but the first), and only slots >= shared_slots are per-row.  beams <= 1 switches it off
  * (emu_llama_set_kv does too).  -22 for beams > 8, a batch the group size does not divide, or slots beyond the capacity. */
 int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots);
+/* Parity hook: emu_llama_forward runs decoder layers [l0, l1) only (l1 < 0: through the last; default 0, -1 = all), each on the
+ * KV-cache plane of its own index.  The full-size tests feed ONE layer the fp32 oracle's input of that layer (a common input per
+ * layer instead of 60 layers of accumulated bf16 rounding); production code never calls it. */
+int emu_llama_set_layer_range(emu_llama* m, int l0, int l1);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
 /* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
  * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).
@@ -288,6 +299,10 @@ size_t emu_vit_workspace_bytes(const emu_vit* m, int B);
 /* image NCHW (fp32 or bf16) -> tokens [B, 1+g*g, C] bf16 (raw block output incl. cls, eva_vit.py:433-445) */
 int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int B, void* out_tokens, void* workspace,
                     size_t ws_bytes, emu_stream_t s);
+
+/* Parity hook: blocks [l0, l1) of the encoder in place on tokens [B, 1+g*g, C] bf16 (what emu_vit_forward runs after the stem
+ * for l0 = 0, l1 = layers); the full-size tests compare every block on a common input.  Same workspace as emu_vit_forward. */
+int emu_vit_blocks(emu_vit* m, void* tokens, int B, int l0, int l1, void* workspace, size_t ws_bytes, emu_stream_t s);
 
 /* ---- SDXL-style UNet denoise engine ---------------------------------------------------------------------
  * One call = one iteration of EmuVisualGeneration's denoising loop (Emu2/emu/diffusion.py:130-149):
