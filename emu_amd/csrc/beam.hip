@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const BeamStepArgs a, con
 size_t beam_step_ws_floats(int B, int nb, int V) { return (size_t)B * nb * ((V + CHUNK - 1) / CHUNK) * PART; }
 
 int launch_beam_step(const BeamStepArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
-    if (a.B < 1 || a.nb < 1 || a.nb > BEAM_MAXN || a.L < 1 || a.L > BEAM_MAXL || a.cur < 0 || a.cur >= a.L || a.V < 2 * a.nb ||
+    if (a.B < 1 || a.nb < 1 || a.nb > BEAM_MAXN || a.L < 1 || a.L > BEAM_MAXL || (!a.cur_dev && (a.cur < 0 || a.cur >= a.L)) || a.V < 2 * a.nb ||
         a.min_len < 0 || !ws || ws_floats < beam_step_ws_floats(a.B, a.nb, a.V))
         return -22;
     const int nchunk = (a.V + CHUNK - 1) / CHUNK;

@@ -58,8 +58,10 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     // row-statistics exchange between the two waves of a 128-column slot: behind the k-group sums where those exist (the ring is
     // dead by then), else 8 KiB of its own behind the ring (other waves may still be reading tiles when the first one arrives)
     constexpr int EX_BYTES = (FX & FX_STATS) != 0 ? T::WN * T::WM * T::MF * 64 * 8 : 0;
-    constexpr int EX_OFF = T::KG > 1 ? RED_BYTES : T::NSTG * T::ST_BYTES;
-    constexpr int RING_BYTES = T::NSTG * T::ST_BYTES > RED_BYTES ? T::NSTG * T::ST_BYTES : RED_BYTES;
+    // staged epilogue: the tile of results (bf16) sits behind the k-group sums (the residual tile arrives while they are summed)
+    constexpr int STAGE_OFF = RED_BYTES, STAGE_BYTES = T::BMv * T::BNv * 2;
+    constexpr int EX_OFF = STAGE_OFF + STAGE_BYTES > T::NSTG * T::ST_BYTES ? STAGE_OFF + STAGE_BYTES : T::NSTG * T::ST_BYTES;
+    constexpr int RING_BYTES = T::NSTG * T::ST_BYTES > STAGE_OFF + STAGE_BYTES ? T::NSTG * T::ST_BYTES : STAGE_OFF + STAGE_BYTES;
     constexpr int SMEM_BYTES = RING_BYTES > EX_OFF + EX_BYTES ? RING_BYTES : EX_OFF + EX_BYTES;
     static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -261,9 +263,19 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     struct TraceEnd { unsigned long long* t; __device__ ~TraceEnd() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EMU_TRACE_MARK(t, 3); } } trace_end{a.trace};
 #endif
 
+    // Staged epilogue (gemm_tile.h::EpiStage): whole-K tiles that lie inside N and carry no V^T / cross-attention output
+    constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
+    using Stage = EpiStage<T::BMv, GLU ? T::BNv / 2 : T::BNv, T::THREADS>;
+    bool staged = a.stage && nsl == 1 && n0 + T::BNv <= a.N && (FX & FX_CROSS) == 0;
+    if constexpr ((FX & FX_VT) != 0) staged = staged && n0 + T::BNv <= a.vt_col0;
+    char* stage = smem + STAGE_OFF;
+    if (staged || T::KG > 1) __syncthreads();          // every wave is done with the ring, every tail DMA has landed
+    if constexpr (EPI == EPI_RESID) {
+        if (staged) Stage::load(stage, a.res, a.ldres, m0, n0, a.M);   // in flight under the k-group sums below
+    }
+
     if constexpr (T::KG > 1) {
         // sum the two k-groups' partial accumulators through LDS (the ring is dead now): group 1 writes, group 0 adds
-        __syncthreads();
         float* red = reinterpret_cast<float*>(smem) + (size_t)wtile * T::NF * T::MF * 16 * 64;
         if (kg == 1) {
 #pragma unroll
@@ -274,18 +286,20 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
                     for (int r = 0; r < 16; ++r) red[((i * T::MF + j) * 16 + r) * 64 + lane] = acc[i][j][r];
         }
         __syncthreads();
-        if (kg == 1) {
+        if (kg == 1 && !staged) {
             if constexpr ((FX & FX_STATS) != 0) {
                 if (nsl == 1) __syncthreads();         // the statistics exchange of the epilogue below (workgroup-wide barrier)
             }
             return;
         }
+        if (kg == 0) {
 #pragma unroll
-        for (int i = 0; i < T::NF; ++i)
+            for (int i = 0; i < T::NF; ++i)
 #pragma unroll
-            for (int j = 0; j < T::MF; ++j)
+                for (int j = 0; j < T::MF; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::MF + j) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * T::MF + j) * 16 + r) * 64 + lane];
+        }
     }
 
     static_assert(T::NF == 2, "a wave's columns of one row are half a 128-column row-statistics slot");
@@ -410,6 +424,50 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     RowFx rows[T::MF];
 #pragma unroll
     for (int j = 0; j < T::MF; ++j) rows[j] = rowfx[j];
+    if (staged) {
+        if constexpr (EPI == EPI_RESID) {
+            wait_vmcnt<0>();                           // this wave's share of the residual tile ...
+            __syncthreads();                           // ... and everyone's
+        }
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < T::NF; ++i) {
+                QuadIn qin[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) quad_load_cols<EPI, FX>(a, n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi, qin[g]);
+#pragma unroll
+                for (int j = 0; j < T::MF; ++j) {
+                    const int row = (wm * T::MF + j) * 32 + l31, m = m0 + row;
+                    if (m >= a.M) continue;
+                    if (a.bias2) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nb = n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi;
+                            qin[g].bias2 = *reinterpret_cast<const u32x2*>(a.bias2 + (size_t)(m / a.rows_per_batch) * a.ld_bias2 + nb);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = (wn * T::NF + i) * 32 + 8 * g + 4 * hi;       // column inside the tile
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                        if constexpr (GLU) {
+                            const u32x2 ov = quad_value<EPI, FX>(a, v, rows[j], qin[g]);
+                            *reinterpret_cast<uint32_t*>(stage + Stage::off(row, col >> 1)) = ov.x;
+                        } else {
+                            u32x2* cell = reinterpret_cast<u32x2*>(stage + Stage::off(row, col));
+                            if constexpr (EPI == EPI_RESID) qin[g].res = *cell;
+                            *cell = quad_value<EPI, FX>(a, v, rows[j], qin[g]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        Stage::store(stage, a.C, a.ldc, m0, GLU ? n0 >> 1 : n0, a.M);
+    } else {
 #pragma unroll
     for (int i = 0; i < T::NF; ++i) {
         QuadIn qin[4];
@@ -449,19 +507,20 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    }
     // fused LayerNorm, producer side: a 128-column statistics slot of a row = the 64 columns of wave (wn, wm) + those of wave
     // (wn + 1, wm), each split over lanes l and l + 32.  Odd wn hands its sums to its even neighbour through LDS.
     if constexpr ((FX & FX_STATS) != 0) {
         static_assert(T::WN % 2 == 0, "waves pair up along n");
         if (nsl == 1) {                                // workgroup-uniform
             f32x2_t* ex = reinterpret_cast<f32x2_t*>(smem + EX_OFF);
-            if (wn & 1) {
+            if ((wn & 1) && kg == 0) {
 #pragma unroll
                 for (int j = 0; j < T::MF; ++j) ex[(wtile * T::MF + j) * 64 + lane] = f32x2_t{rows[j].rs, rows[j].rq};
             }
             __syncthreads();
             const int nslot = n0 + wn * 64;
-            if (!(wn & 1) && nslot < a.N) {
+            if (!(wn & 1) && kg == 0 && nslot < a.N) {
 #pragma unroll
                 for (int j = 0; j < T::MF; ++j) {
                     const int m = m0 + (wm * T::MF + j) * 32 + l31;
@@ -476,6 +535,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
     }
 }
+
 
 using CfgB = TileCfg<2, 2, 2, 2, 2>;     // 128 x 128, 4 waves, 2 stages (64 KiB, 2 workgroups per CU)
 using CfgC = TileCfg<4, 2, 2, 2, 3>;     // 256(n) x 128(m), 8 waves, 3 stages (144 KiB)
@@ -498,6 +558,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     b.trace = g_trace;
+    b.stage = stage_ok(b) && !(g_tune & 8);
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
     if (fx) {                                           // launch_gemm has checked gemm_fx_ok(epi, fx)

@@ -366,6 +366,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             store_quad<EPI, FX>(a, m, nb, v, fx, q);
         }
     };
+    // Staged epilogue (gemm_tile.h::EpiStage): the 256 x 256 results leave through the (now dead) k-tile ring as whole rows
+    constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
+    using Stage = EpiStage<256, GLU ? 128 : 256, 512>;
+    bool staged = a.stage && nsl == 1 && n0 + 256 <= a.N;
+    if constexpr ((FX & FX_VT) != 0) staged = staged && n0 + 256 <= a.vt_col0;
+    if (staged) {
+        __syncthreads();                               // both wave groups are out of the loop
+        if constexpr (EPI == EPI_RESID) Stage::load(smem, a.res, a.ldres, m0, n0, a.M);
+    }
     RowFx rowfx[2];
     if constexpr ((FX & FX_LN) != 0) {                 // fused LayerNorm, consumer side: both rows of this lane in one batch of loads
         if (nsl == 1) {
@@ -377,6 +386,62 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             ln_rows_finish<2>(a, raw, rowfx);
         }
     }
+    if (staged) {
+        if constexpr (EPI == EPI_RESID) {
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            QuadIn qin[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) quad_load_cols<EPI, FX>(a, n0 + wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi, qin[i][g]);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int row = wc * 64 + y * 32 + l31, m = m0 + row;
+                if (m >= a.M) continue;
+                RowFx& fx = rowfx[y];
+                float sa = 1.f;
+                if constexpr (F8) sa = a.a_scale[m];
+                if (a.bias2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nb = n0 + wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi;
+                            qin[i][g].bias2 = *reinterpret_cast<const u32x2*>(a.bias2 + (size_t)(m / a.rows_per_batch) * a.ld_bias2 + nb);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[x][y][i][4 * g + e];
+                        if constexpr (F8) {
+                            const f32x4_t ws4 = *reinterpret_cast<const f32x4_t*>(a.w_scale + n0 + col);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= sa * ws4[e];
+                        }
+                        if constexpr (GLU) {
+                            const u32x2 ov = quad_value<EPI, FX>(a, v, fx, qin[i][g]);
+                            *reinterpret_cast<uint32_t*>(smem + Stage::off(row, col >> 1)) = ov.x;
+                        } else {
+                            u32x2* cell = reinterpret_cast<u32x2*>(smem + Stage::off(row, col));
+                            if constexpr (EPI == EPI_RESID) qin[i][g].res = *cell;
+                            *cell = quad_value<EPI, FX>(a, v, fx, qin[i][g]);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        Stage::store(smem, a.C, a.ldc, m0, GLU ? n0 >> 1 : n0, a.M);
+    } else {
     // Sub-tile x (64 columns) at a time: its column-only operands (bias / fused-LayerNorm vectors) are fetched once for both row
     // blocks y, a row block's residual / per-batch bias for all of its 8 quads before its first store (gemm_tile.h::QuadIn).
 #pragma unroll
@@ -418,6 +483,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 }
         }
         __builtin_amdgcn_sched_barrier(0);             // keep the next sub-tile's loads from piling up (256-VGPR kernel)
+    }
     }
     // fused LayerNorm, producer side: this wave's 128 columns of a row = one statistics slot, halves in lanes l / l + 32
     if constexpr ((FX & FX_STATS) != 0) {
@@ -500,6 +566,7 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
     b.trace = emu_gemm_trace_get();
+    b.stage = stage_ok(b) && !(emu_gemm_tune_get() & 8);
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
     if (fx) {                                           // gemm256_ok: bf16 plain GEMM; launch_gemm: an instantiated (epi, mask) pair

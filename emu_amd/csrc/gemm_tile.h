@@ -159,55 +159,68 @@ __device__ __forceinline__ void quad_load_row(const GemmArgs& a, int m, int nb, 
     if constexpr (EPI == EPI_RESID) q.res = *reinterpret_cast<const u32x2*>(a.res + (size_t)m * a.ldres + nb);
 }
 
+// The value part of the epilogue of one FULL accumulator quad (quad_full): bias / fused-LayerNorm correction / per-batch bias /
+// activation / residual with the reference's bf16 rounding points, packed to bf16.  Non-GLU: 4 columns in (x, y); GLU: the 2
+// output columns in x.  Row statistics (FX_STATS) accumulate in fx.  res_in = the quad's residual values (EPI_RESID).
+template <int EPI, int FX>
+__device__ __forceinline__ u32x2 quad_value(const GemmArgs& a, float (&v)[4], RowFx& fx, const QuadIn& q) {
+    if constexpr ((FX & FX_LN) != 0) {             // LayerNorm folded into this GEMM (launch_gemm: N % 4 == 0, no bias)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(fx.rstd, v[e] - fx.mean * q.c[e], q.d[e]);
+    } else if (a.bias) {
+        v[0] += bflo(q.bias.x); v[1] += bfhi(q.bias.x); v[2] += bflo(q.bias.y); v[3] += bfhi(q.bias.y);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = bfround(v[e]);
+    if (a.bias2) {
+        v[0] = bfround(v[0] + bflo(q.bias2.x)); v[1] = bfround(v[1] + bfhi(q.bias2.x));
+        v[2] = bfround(v[2] + bflo(q.bias2.y)); v[3] = bfround(v[3] + bfhi(q.bias2.y));
+    }
+    u32x2 ov{0u, 0u};
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) {
+        // interleaved rows (2j, 2j+1): SwiGLU = (gate, up) -> bf16(bf16(silu(gate)) * up)
+        //                               GEGLU  = (hidden, gate) -> bf16(hidden * bf16(gelu(gate)))
+        float o0, o1;
+        if constexpr (EPI == EPI_SWIGLU) {
+            o0 = bfround(silu(v[0])) * v[1];
+            o1 = bfround(silu(v[2])) * v[3];
+        } else {
+            o0 = v[0] * bfround(gelu_erf(v[1]));
+            o1 = v[2] * bfround(gelu_erf(v[3]));
+        }
+        ov.x = packbf(o0, o1);
+    } else {
+        if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bfround(silu(v[e]));
+        }
+        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bfround(gelu_erf(v[e]));
+        }
+        if constexpr (EPI == EPI_RESID) {
+            v[0] += bflo(q.res.x); v[1] += bfhi(q.res.x); v[2] += bflo(q.res.y); v[3] += bfhi(q.res.y);
+        }
+        ov.x = packbf(v[0], v[1]);
+        ov.y = packbf(v[2], v[3]);
+        if constexpr ((FX & FX_STATS) != 0) {      // statistics of what the next LayerNorm will read: the bf16 values
+            const float r0 = bflo(ov.x), r1 = bfhi(ov.x), r2 = bflo(ov.y), r3 = bfhi(ov.y);
+            fx.rs += (r0 + r1) + (r2 + r3);
+            fx.rq += fmaf(r0, r0, r1 * r1) + fmaf(r2, r2, r3 * r3);
+        }
+    }
+    return ov;
+}
+
 // Epilogue for one accumulator quad: lane-local 4 consecutive output columns nb..nb+3 of row m; q = its memory operands.
 // FX = 0 compiles every fused-LayerNorm / V^T feature out (the instantiations all other callers use are unchanged).
 template <int EPI, int FX = 0>
 __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, float (&v)[4], RowFx& fx, const QuadIn& q) {
     if (quad_full<EPI>(a, nb)) {
-        if constexpr ((FX & FX_LN) != 0) {             // LayerNorm folded into this GEMM (launch_gemm: N % 4 == 0, no bias)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(fx.rstd, v[e] - fx.mean * q.c[e], q.d[e]);
-        } else if (a.bias) {
-            v[0] += bflo(q.bias.x); v[1] += bfhi(q.bias.x); v[2] += bflo(q.bias.y); v[3] += bfhi(q.bias.y);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = bfround(v[e]);
-        if (a.bias2) {
-            v[0] = bfround(v[0] + bflo(q.bias2.x)); v[1] = bfround(v[1] + bfhi(q.bias2.x));
-            v[2] = bfround(v[2] + bflo(q.bias2.y)); v[3] = bfround(v[3] + bfhi(q.bias2.y));
-        }
+        const u32x2 ov = quad_value<EPI, FX>(a, v, fx, q);
         if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GEGLU) {
-            // interleaved rows (2j, 2j+1): SwiGLU = (gate, up) -> bf16(bf16(silu(gate)) * up)
-            //                               GEGLU  = (hidden, gate) -> bf16(hidden * bf16(gelu(gate)))
-            float o0, o1;
-            if constexpr (EPI == EPI_SWIGLU) {
-                o0 = bfround(silu(v[0])) * v[1];
-                o1 = bfround(silu(v[2])) * v[3];
-            } else {
-                o0 = v[0] * bfround(gelu_erf(v[1]));
-                o1 = v[2] * bfround(gelu_erf(v[3]));
-            }
-            *reinterpret_cast<uint32_t*>(a.C + (size_t)m * a.ldc + (nb >> 1)) = packbf(o0, o1);
+            *reinterpret_cast<uint32_t*>(a.C + (size_t)m * a.ldc + (nb >> 1)) = ov.x;
         } else {
-            if constexpr (EPI == EPI_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = bfround(silu(v[e]));
-            }
-            if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = bfround(gelu_erf(v[e]));
-            }
-            if constexpr (EPI == EPI_RESID) {
-                v[0] += bflo(q.res.x); v[1] += bfhi(q.res.x); v[2] += bflo(q.res.y); v[3] += bfhi(q.res.y);
-            }
-            u32x2 ov;
-            ov.x = packbf(v[0], v[1]);
-            ov.y = packbf(v[2], v[3]);
-            if constexpr ((FX & FX_STATS) != 0) {      // statistics of what the next LayerNorm will read: the bf16 values
-                const float r0 = bflo(ov.x), r1 = bfhi(ov.x), r2 = bflo(ov.y), r3 = bfhi(ov.y);
-                fx.rs += (r0 + r1) + (r2 + r3);
-                fx.rq += fmaf(r0, r0, r1 * r1) + fmaf(r2, r2, r3 * r3);
-            }
             if ((FX & FX_VT) != 0 && nb >= a.vt_col0) {   // V heads: key-contiguous store for the P.V MFMA (wave-uniform branch)
                 const int b = m / a.vt_s, sidx = m - b * a.vt_s;
                 bf16_t* dst = a.vt_out + ((size_t)b * (a.N - a.vt_col0) + (nb - a.vt_col0)) * a.vt_spad + sidx;
@@ -250,6 +263,60 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, int m, int nb, flo
             }
         }
     }
+}
+
+// ---- Staged epilogue.  In the accumulator layout a lane owns 4 consecutive columns of ONE row, so a direct store instruction
+// writes 8 bytes to each of 32 different rows: 32 cache lines touched per instruction, and the residual loads likewise.  Traced
+// per workgroup (profiles/r04_gemm_trace_baseline_*.log) that tail is 4-6 us on the 128 x 64 tile and 10-19 us on the 256 x 256
+// tile -- a third to a half of a K = 640 / 1280 GEMM.  Here the workgroup's tile of results goes through LDS (the k-tile ring is
+// dead by then): the residual tile comes in by LDS-DMA, 16 bytes per lane and row-contiguous; every lane reads its quads' residual
+// from LDS, computes and writes the packed results back IN PLACE (each element has exactly one owner lane); then the tile leaves
+// with 16-byte stores, 64 lanes covering whole rows.  16-byte slots of a row are XOR-swizzled with the row so that the 8-byte
+// quad accesses of 16 consecutive rows hit distinct banks; the same XOR is applied to the global column of the DMA source / the
+// store, which only permutes 16-byte pieces inside a row.
+// BMv rows x NOUT output columns (bf16) per tile; the tile must lie inside N (rows beyond M are clamped on the way in and skipped
+// on the way out).
+template <int BMv, int NOUT, int THREADS>
+struct EpiStage {
+    static constexpr int ROWB = NOUT * 2, SLOTS = ROWB / 16, KEYM = SLOTS >= 16 ? 15 : SLOTS - 1;
+    static constexpr int BYTES = BMv * ROWB;
+    static constexpr int ROUNDS = (BMv * SLOTS) / THREADS;
+    static_assert((BMv * SLOTS) % THREADS == 0 && (SLOTS & (SLOTS - 1)) == 0, "tile splits into whole rounds of 16-byte pieces");
+    // byte offset of output column col (element index inside the tile row; the access must not cross a 16-byte slot)
+    __device__ static __forceinline__ int off(int row, int col) {
+        return row * ROWB + ((((col >> 3) ^ row) & KEYM) << 4 | ((col >> 3) & ~KEYM) << 4) + ((col & 7) << 1);
+    }
+    // residual tile [m0 .. m0 + BMv) x [c0 .. c0 + NOUT) -> LDS (LDS-DMA; caller waits vmcnt(0) + barrier)
+    __device__ static __forceinline__ void load(char* lds, const bf16_t* src, int ld, int m0, int c0, int M) {
+        const int tid = threadIdx.x;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int idx = r * THREADS + tid, row = idx / SLOTS, ps = idx % SLOTS;
+            const int ls = (ps & ~KEYM) | ((ps ^ row) & KEYM);           // logical slot held at physical slot ps of this row
+            int m = m0 + row; m = m < M ? m : M - 1;
+            glds16(src + (size_t)m * ld + c0 + ls * 8, lds + (r * THREADS + wave * 64) * 16);
+        }
+    }
+    // LDS tile -> C, 16 bytes per lane (after a barrier that follows the last in-place write)
+    __device__ static __forceinline__ void store(const char* lds, bf16_t* dst, int ld, int m0, int c0, int M) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int idx = r * THREADS + tid, row = idx / SLOTS, ps = idx % SLOTS;
+            const int ls = (ps & ~KEYM) | ((ps ^ row) & KEYM);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + idx * 16);
+            if (m0 + row < M) *reinterpret_cast<u32x4*>(dst + (size_t)(m0 + row) * ld + c0 + ls * 8) = v;
+        }
+    }
+};
+// host side: may this launch take the staged epilogue?  16-byte alignment of C (and the residual) rows; the kernels add the
+// per-tile conditions (tile inside N, whole-K tile, no V^T columns, no remainder-row accumulator)
+inline bool stage_ok(const GemmArgs& a) {
+    const bool glu = a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU;
+    if ((a.ldc & 7) || ((uintptr_t)a.C & 15) || (a.N & (glu ? 15 : 7))) return false;
+    if (a.epi == EPI_RESID && ((a.ldres & 7) || ((uintptr_t)a.res & 15))) return false;
+    return true;
 }
 
 // Reduce kernels: consecutive lanes walk consecutive quads of a row, so an aligned 32-lane half-wave holds 128 columns = one

@@ -70,7 +70,9 @@ void emu_gemm_force_config(int cfg);
  * splits into whole rounds of the 256x256 tile + a remainder GEMM run as ONE launch of 128x128 tiles.  Bit 1: the K-slice
  * workgroups of a split GEMM are dealt tile by tile round-robin over the XCDs (the order before round 3) instead of the
  * XCD-aware slice-major order.  Bit 2: 4..16-row linears skip the LDS-DMA + MFMA stream (gemv_thin.hip) and run on the
- * v_dot2c / register-fed MFMA kernels as before round 3; bits 8-11: variant of that stream (tools/thin_ab.py). */
+ * v_dot2c / register-fed MFMA kernels as before round 3; bit 3: the GEMM / conv epilogues store straight from the accumulator
+ * layout (8 bytes per lane to 32 rows per instruction, as before round 4) instead of through the LDS-staged, row-contiguous
+ * 16-byte form; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
 void emu_gemm_tune(int mask);
 
 /* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at

@@ -123,3 +123,62 @@ def test_logits_rows_with_unaligned_stride(force):
         out = torch.zeros(M, N, dtype=BF16, device="cuda")
         ops.linear(x, w, out=out)
         check(out, ref_linear(x, w, None, None, 0), f"logits cfg {cfg}")
+
+
+@pytest.mark.parametrize("M,N,K,epis", [(2048, 1280, 1280, (0, 1, 3, 4)), (2048, 2560, 1280, (2, 5)), (770, 1536, 6656, (0, 1, 2)),
+                                        (1025, 1792, 2048, (1, 4)), (8192, 640, 640, (1,)), (300, 384, 512, (0, 1, 5)),
+                                        (2048, 1288, 1280, (0, 1))])
+def test_staged_epilogue_is_bit_identical_to_the_direct_one(force, M, N, K, epis):
+    """Round 4: the results of a whole tile leave through LDS as row-contiguous 16-byte stores (and the residual tile comes in by
+    LDS-DMA) instead of 8 bytes per lane to 32 different rows (gemm_tile.h::EpiStage).  Same arithmetic, same rounding points: every
+    tile configuration must give the bits of the direct epilogue (emu_gemm_tune bit 3 switches the staged form off), on full tiles,
+    ragged rows (M = 770, 1025, 300), ragged column tiles (N = 1288, 384: the last tile column keeps the direct form) and with an
+    output / residual row stride wider than N."""
+    from emu_amd import ops
+    from emu_amd._lib import lib
+    L = lib()
+    x, w = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5)
+    try:
+        for epi in epis:
+            bias = rnd(N, seed=33) if epi in (0, 1, 4, 5) else None
+            wide = N + 64
+            res_full = rnd(M, wide, seed=34) if epi == 1 else None
+            res = res_full[:, :N] if epi == 1 else None                       # row stride != N
+            nout = N // 2 if epi in (2, 5) else N
+            for cfg in CFGS:
+                force(cfg)
+                outs = []
+                for tune in (8, 0):
+                    L.emu_gemm_tune(tune)
+                    buf = torch.full((M, nout + 8), float("nan"), dtype=BF16, device="cuda")
+                    out = buf[:, :nout]
+                    ops.linear(x, w, bias=bias, res=res, epi=epi, out=out)
+                    torch.cuda.synchronize()
+                    assert bool(torch.isnan(buf[:, nout:].float()).all()), f"cfg {cfg} epi {epi} tune {tune}: wrote beyond N"
+                    outs.append(out.clone())
+                assert torch.equal(outs[0], outs[1]), (f"cfg {cfg} M{M} N{N} K{K} epi {epi}: staged != direct, "
+                                                       f"{int((outs[0] != outs[1]).sum())} elements")
+            check(outs[1], ref_linear(x, w, bias, res, epi), f"staged M{M} N{N} K{K} epi{epi}")
+    finally:
+        L.emu_gemm_tune(0)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,mode", [(2, 32, 1280, 1280, 1), (2, 64, 640, 640, 2), (2, 32, 640, 640, 3)])
+def test_staged_conv_epilogue_is_bit_identical_to_the_direct_one(force, B, H, Cin, Cout, mode):
+    from emu_amd import ops
+    from emu_amd._lib import lib
+    L = lib()
+    x, w = rnd(B, H, H, Cin, seed=41), rnd(Cout, 3, 3, Cin, seed=42, scale=0.02)
+    bias, b2 = rnd(Cout, seed=43), rnd(B, Cout, seed=44)
+    Ho = H // 2 if mode == 2 else (2 * H if mode == 3 else H)
+    res = rnd(B, Ho, Ho, Cout, seed=45)
+    try:
+        for cfg in CFGS:
+            force(cfg)
+            outs = []
+            for tune in (8, 0):
+                L.emu_gemm_tune(tune)
+                outs.append(ops.conv3x3_nhwc(x, w, bias=bias, bias2=b2, res=res, mode=mode).clone())
+            assert torch.equal(outs[0], outs[1]), f"conv cfg {cfg} mode {mode}: staged != direct"
+    finally:
+        L.emu_gemm_tune(0)

@@ -36,8 +36,10 @@ def main():
     ap.add_argument("--shapes", default="unet")
     ap.add_argument("--cfgs", default="0")
     ap.add_argument("--dump", default="")
+    ap.add_argument("--tune", type=int, default=0, help="emu_gemm_tune mask (8 = staged epilogue off)")
     a = ap.parse_args()
     L = lib()
+    L.emu_gemm_tune(a.tune)
     assert L.emu_gemm_trace_built() == 1, "load the -DEMU_TRACE twin: EMU_HIP_TOOLS=1 EMU_HIP_LIB=.../libemu_hip_trace.so"
     dev = torch.device("cuda", 0)
     sk = torch.zeros(512 * 288 * 256, dtype=torch.float32, device=dev)
