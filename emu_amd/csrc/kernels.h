@@ -94,6 +94,8 @@ struct GemmArgs {
     const bf16_t* cross_vt = nullptr;
     int cross_ldk = 0, cross_n = 0, cross_npad = 0, cross_rows = 0;
     float cross_scale = 0.f;
+    int sup_m = 0, sup_n = 0;   // set by launch_gemm (lock-step tiles, unsplit launches): every XCD owns one sup_m x sup_n block of
+                            // tiles instead of a run of the column-major order (fewer distinct A + W rows per L2); 0 = off
     int stage = 0;          // set by launch_gemm: the staged (LDS-transposed, 16-byte coalesced) epilogue may be taken (gemm_tile.h)
     // ---- per-workgroup timeline (tools/gemm_trace.py; written only by a library built with -DEMU_TRACE): 8 x u64 per workgroup
     unsigned long long* trace = nullptr;
