@@ -112,8 +112,19 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int qblk = blockIdx.x * 128;
+    // Workgroup -> (batch, head, query block).  Block i runs on XCD i % 8 (observed dispatch order): dealt straight, the query
+    // blocks of ONE head land on 8 different XCDs and every XCD's L2 has to fetch the K / V of every head (UNet 32^2 level: 40 heads
+    // x 256 KB = 10 MB per 4 MB L2: 85 MB fetched for 15.7 MB of operands, every key tile a fabric round trip).  Remapped so that an
+    // XCD owns a run of consecutive (head, query block) pairs -- whole heads where the counts allow: K / V cross the fabric once.
+    const int nq = (a.Sq + 127) >> 7, total = nq * a.H * a.B;
+    int lin = blockIdx.x;
+    if (a.xcd_remap) {
+        const int xcd = lin & 7, q8 = total >> 3, r8 = total & 7;
+        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    }
+    const int qb = lin % nq, bh = lin / nq;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int qblk = qb * 128;
     const int q0 = qblk + wave * 32;
     const int off = a.Sk - a.Sq;                      // causal: query i sees keys <= i + off
     const int kstart = a.kstart ? a.kstart[b] : 0;
@@ -248,6 +259,33 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
 
     const float ltot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    if (a.stage_o) {
+        // O leaves through LDS (the K / V tiles are dead): in the accumulator layout a store instruction writes 8 bytes to each of
+        // 32 query rows (32 cache lines touched); staged, 16 bytes per lane and whole rows of D values (gemm_tile.h::EpiStage)
+        constexpr int ROWB = D * 2, SLOTS = ROWB / 16, KEYM = SLOTS - 1;
+        static_assert(128 * ROWB <= KT_BYTES + VT_BYTES, "the O tile fits the K / V tiles' LDS");
+        __syncthreads();                               // every wave is done with the last K / V tile
+        const int row = wave * 32 + l31;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 ov;
+                ov.x = packbf(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+                ov.y = packbf(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+                const int col = db * 32 + 8 * g + 4 * hi;
+                *reinterpret_cast<u32x2*>(smem + row * ROWB + ((((col >> 3) ^ row) & KEYM) << 4) + ((col & 7) << 1)) = ov;
+            }
+        __syncthreads();
+        bf16_t* ob = a.o + (size_t)b * a.o_sb + (size_t)h * a.o_sh;
+#pragma unroll
+        for (int r = 0; r < (128 * SLOTS) / 256; ++r) {
+            const int idx = r * 256 + tid, rw = idx / SLOTS, ps = idx % SLOTS, ls = (ps ^ rw) & KEYM;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + idx * 16);
+            if (qblk + rw < a.Sq) *reinterpret_cast<u32x4*>(ob + (size_t)(qblk + rw) * a.o_ss + ls * 8) = v;
+        }
+        return;
+    }
     if (qi < a.Sq) {
         bf16_t* op = a.o + (size_t)b * a.o_sb + (size_t)h * a.o_sh + (size_t)qi * a.o_ss;
 #pragma unroll
@@ -366,9 +404,13 @@ int launch_flash_attn(const FlashArgs& a, hipStream_t s) {
     if (a.Sq < 1 || a.Sk < 1 || (a.Sk_pad & 63) || a.Sk_pad < a.Sk) return -22;
     if ((a.q_ss & 7) || (a.k_ss & 7) || (a.o_ss & 3) || (a.q_sh & 7) || (a.k_sh & 7) || (a.o_sh & 3) ||
         (a.q_sb & 7) || (a.k_sb & 7) || (a.o_sb & 3)) return -22;
-    const dim3 grid((a.Sq + 127) / 128, a.H, a.B), block(256);
-    if (a.D == 128) hipLaunchKernelGGL(flash_kernel<128>, grid, block, 0, s, a);
-    else if (a.D == 64) hipLaunchKernelGGL(flash_kernel<64>, grid, block, 0, s, a);
+    const dim3 grid(((a.Sq + 127) / 128) * a.H * a.B), block(256);
+    FlashArgs b = a;
+    const int tune = emu_gemm_tune_get();              // A/B switches: bit 6 = straight block order, bit 7 = direct O stores
+    b.xcd_remap = !(tune & 64);
+    b.stage_o = !(tune & 128) && !((a.o_ss | a.o_sh | a.o_sb) & 7) && !((uintptr_t)a.o & 15);
+    if (a.D == 128) hipLaunchKernelGGL(flash_kernel<128>, grid, block, 0, s, b);
+    else if (a.D == 64) hipLaunchKernelGGL(flash_kernel<64>, grid, block, 0, s, b);
     else return -22;
     EMU_CHECK_LAUNCH();
     return 0;

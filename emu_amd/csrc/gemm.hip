@@ -30,19 +30,13 @@ constexpr int BK = 64;
 // Tile configuration: WN x WM waves, each owning NF x MF 32x32 accumulators; NSTG-deep LDS ring of 64-wide k tiles.
 // KG > 1: KG groups of WN x WM waves split the four 16-wide k-steps of every tile between them (intra-workgroup split-K:
 // twice the waves per SIMD for the same tile, partial accumulators summed through LDS in the epilogue).
-// PF = 1: one more wave per workgroup that only WARMS THE L2: it walks the workgroup's A / W panel k tile by k tile, far ahead of
-// the LDS-DMA of the working waves (a line per lane, into a dump slot of LDS), so that their k tiles come from the XCD's L2
-// (~300 cycles) instead of the fabric (~1 us under load, which with a prefetch distance of two tiles is what the 128 x 64 tile's
-// loop was waiting for).  It has its own vmcnt (the working waves' counted waits return in order and would queue behind such
-// loads), takes part in no barrier and simply ends (S_BARRIER waits on the surviving waves only).
-template <int WN_, int WM_, int NF_, int MF_, int NSTG_, int KG_ = 1, int PF_ = 0>
+template <int WN_, int WM_, int NF_, int MF_, int NSTG_, int KG_ = 1>
 struct TileCfg {
-    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_, KG = KG_, PF = PF_;
-    static constexpr int THREADS = WN * WM * KG * 64;                         // working threads
-    static constexpr int LAUNCH = THREADS + 64 * PF;
+    static constexpr int WN = WN_, WM = WM_, NF = NF_, MF = MF_, NSTG = NSTG_, KG = KG_;
+    static constexpr int THREADS = WN * WM * KG * 64;
     // waves per SIMD the register allocation must leave room for: the 128 x 64 two-k-group tile lives on TWO workgroups per
     // CU (72 KiB of LDS each), i.e. 4 waves per SIMD = at most 128 VGPRs; the others run 2 waves per SIMD
-    static constexpr int MINW = (KG == 2 && NSTG_ * (WN_ * NF_ + WM_ * MF_) * 32 * 128 <= 80 * 1024) ? (PF_ ? 5 : 4) : 2;
+    static constexpr int MINW = (KG == 2 && NSTG_ * (WN_ * NF_ + WM_ * MF_) * 32 * 128 <= 80 * 1024) ? 4 : 2;
     static_assert(KG == 1 || KG == 2, "k-groups: 1 or 2");
     static constexpr int BNv = WN * NF * 32, BMv = WM * MF * 32;
     static constexpr int ROWB = BK * 2;                                       // bytes per LDS row (128)
@@ -58,7 +52,7 @@ struct TileCfg {
 };
 
 template <int EPI, bool CONV, class T, int FX = 0>
-__global__ __launch_bounds__(T::LAUNCH, T::MINW) void gemm2_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
     // row-statistics exchange between the two waves of a 128-column slot: behind the k-group sums where those exist (the ring is
@@ -71,8 +65,7 @@ __global__ __launch_bounds__(T::LAUNCH, T::MINW) void gemm2_kernel(const GemmArg
     constexpr int STAGE_OFF = STAGE_BEHIND ? RED_BYTES : 0;
     constexpr int EX_OFF = STAGE_OFF + STAGE_BYTES > T::NSTG * T::ST_BYTES ? STAGE_OFF + STAGE_BYTES : T::NSTG * T::ST_BYTES;
     constexpr int RING_BYTES = T::NSTG * T::ST_BYTES > STAGE_OFF + STAGE_BYTES ? T::NSTG * T::ST_BYTES : STAGE_OFF + STAGE_BYTES;
-    constexpr int PF_OFF = RING_BYTES > EX_OFF + EX_BYTES ? RING_BYTES : EX_OFF + EX_BYTES;       // dump slots of the L2-warming wave
-    constexpr int SMEM_BYTES = PF_OFF + (T::PF ? 1024 : 0);
+    constexpr int SMEM_BYTES = RING_BYTES > EX_OFF + EX_BYTES ? RING_BYTES : EX_OFF + EX_BYTES;
     static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,33 +205,6 @@ __global__ __launch_bounds__(T::LAUNCH, T::MINW) void gemm2_kernel(const GemmArg
         }
     };
 
-    if constexpr (T::PF != 0 && !CONV) {
-        if (wave == NW) {                              // the L2-warming wave
-            constexpr int AHEAD = 8;                   // k tiles in flight (3 or 4 line-loads each)
-            constexpr int NR = (T::BNv + T::BMv) / 64; // 64-row groups of the panel
-            static_assert((T::BNv % 64) == 0 && (T::BMv % 64) == 0 && NR * AHEAD <= 60, "whole 64-row groups, vmcnt is 6 bits");
-            const bf16_t* row[NR];
-#pragma unroll
-            for (int g = 0; g < NR; ++g) {
-                const bool w = g < T::BNv / 64;
-                int r = (w ? n0 : m0 - T::BNv) + g * 64 + lane;
-                r = r < (w ? a.N : a.M) ? r : (w ? a.N : a.M) - 1;
-                row[g] = (w ? a.W + (size_t)r * a.ldw : a.A + (size_t)r * a.lda) + (size_t)kt0 * BK;
-            }
-            char* dump = smem + PF_OFF;
-            for (int kt = T::NSTG - 1; kt < nk; ++kt) {      // the first NSTG - 1 tiles are requested by the working waves at once
-                if ((kt + 1) * BK <= a.K - kt0 * BK) {
-#pragma unroll
-                    for (int g = 0; g < NR; ++g)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row[g] + kt * BK),
-                                                         (__attribute__((address_space(3))) void*)(dump + (g & 3) * 256), 4, 0, 0);
-                }
-                wait_vmcnt<NR * (AHEAD - 1)>();
-            }
-            wait_vmcnt<0>();
-            return;
-        }
-    }
     f32x16_t acc[T::NF][T::MF];
 #pragma unroll
     for (int i = 0; i < T::NF; ++i)
@@ -590,14 +556,12 @@ __global__ __launch_bounds__(T::LAUNCH, T::MINW) void gemm2_kernel(const GemmArg
 using CfgB = TileCfg<2, 2, 2, 2, 2>;     // 128 x 128, 4 waves, 2 stages (64 KiB, 2 workgroups per CU)
 using CfgC = TileCfg<4, 2, 2, 2, 3>;     // 256(n) x 128(m), 8 waves, 3 stages (144 KiB)
 using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves, 3 stages (72 KiB, 2 workgroups per CU)
-// Round 4 (after the per-workgroup timelines of profiles/r04_gemm_trace_*): the 128 x 64 tile's loop is bound by the latency of
-// k tiles that are new to the XCD's L2 every time (0.45 us per k tile alone on a CU, prefetch distance 2) and a 320-tile launch
-// leaves 64 CUs with two workgroups (14 us of loop against 9); the 256 x 128 tile runs 1.05 us per k tile for 0.5 us of MFMA
-// work with 2 waves per SIMD in lock step.  Two more shapes of the same pipeline:
-using CfgD = TileCfg<2, 2, 2, 2, 4, 2>;  // 128 x 128, 2 k-groups x 4 waves, FOUR stages (128 KiB, 1 workgroup per CU): distance 3
-using CfgE = TileCfg<4, 2, 2, 2, 3, 2>;  // 256(n) x 128(m), 2 k-groups x 8 waves = 1024 threads, 3 stages: 4 waves per SIMD
-using CfgF = TileCfg<2, 2, 2, 1, 3, 2, 1>;  // the 128 x 64 tile of CfgK + an L2-warming wave (576 threads, still 2 workgroups per CU)
-using CfgG = TileCfg<2, 2, 2, 2, 2, 1, 1>;  // the 128 x 128 tile of CfgB + an L2-warming wave
+// Round 4, measured with per-workgroup timelines and not kept (profiles/r04_gemm_trace_configs_DEFG.log): 128 x 128 with two
+// k-groups and a FOUR-stage ring (10.9 us of loop on the UNet's 2048 x 1280 x 1280 against 11.6 for CfgB: the loop does not wait
+// for the fabric); 256 x 128 with two k-groups = 1024 threads (slower than CfgC everywhere, and its fused-LayerNorm forms spill at
+// 128 VGPRs); an extra L2-WARMING wave per workgroup for the 128 x 64 and 128 x 128 tiles (walks the panel ahead of the LDS-DMA
+// through its own vmcnt): the first k tile lands after 5.6 us instead of 1.5 and the kernel is 25-60 % slower -- the loops of these
+// tiles are bound by what one CU can move into LDS per clock (24-32 KiB per k tile against 256-512 MFMA cycles), not by latency.
 // Measured and not kept (profiles/r01_gemm_tilecfg_sweep_*.log): deeper rings of the 128-wide tiles, 128(n) x 256(m),
 // 64 x 64, 32-wide k tiles (twice the barriers per FLOP), 4 waves of 128 x 64 / 128 x 128 on the big tiles, and a
 // 256 x 256 tile on this lock-step pipeline (-40 %: what the big tile needs is the phase schedule of gemm256.hip).
@@ -637,14 +601,14 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
         if constexpr (!CONV) {
             gemm_fx_dispatch<EPI>(fx, [&](auto m) {
                 constexpr int FXM = decltype(m)::value;
-                hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(T::LAUNCH), 0, s, b);
+                hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
                 if (tail > 0)
                     hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv, FXM>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
             });
         }
         return;
     }
-    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(b.full_tiles + tail * ksplit), dim3(T::LAUNCH), 0, s, b);
+    hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
     if (tail > 0)
         hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }
@@ -784,6 +748,12 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
         // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
         // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
+        // Round 4, with the staged epilogue (its tail was 6.5-9 us on the 128 x 128 tile, now 3): about one round of 128 x 128 tiles
+        // (the UNet's 2048 x 1280 and 8192 x 640 outputs: 160 / 320 tiles, every CU one or two workgroups and no ragged last
+        // round) beats the 128 x 64 tile's 1.25 rounds and the 256 x 128 tile's 0.3-0.75 by 13-17 % (profiles/r04_gemm_ab_*.log);
+        // not for ragged M (the ViT's 1025 rows: a ninth row of tiles for one row)
+        else if (!CONV && tiles_of(a, 128, 128) >= 144 && tiles_of(a, 128, 128) < 400 &&
+                 ((a.M + 127) / 128) * 128 <= a.M + a.M / 16 && !(g_tune & 32)) cfg = 'B';
         else if (tc >= 1024) cfg = 'C';
         else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step): 256x128 29.4, 128x128 29.4, 256x256 29.8 ms
         else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: ViT qkv
@@ -805,10 +775,6 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         }
         case 'C': launch_cfg<EPI, CONV, CfgC>(a, s); break;
         case 'K': launch_cfg<EPI, CONV, CfgK>(a, s); break;
-        case 'D': launch_cfg<EPI, CONV, CfgD>(a, s); break;
-        case 'E': launch_cfg<EPI, CONV, CfgE>(a, s); break;
-        case 'F': if constexpr (!CONV) { launch_cfg<EPI, CONV, CfgF>(a, s); } else { launch_cfg<EPI, CONV, CfgK>(a, s); } break;
-        case 'G': if constexpr (!CONV) { launch_cfg<EPI, CONV, CfgG>(a, s); } else { launch_cfg<EPI, CONV, CfgB>(a, s); } break;
         default:  launch_cfg<EPI, CONV, CfgB>(a, s); break;
     }
     EMU_CHECK_LAUNCH();

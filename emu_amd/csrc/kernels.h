@@ -168,6 +168,8 @@ struct FlashArgs {
     int B, H, Sq, Sk, Sk_pad, D;               // D in {64, 128}
     int causal;                                // query i attends keys <= i + (Sk - Sq)
     float scale;
+    int xcd_remap = 1;                         // set by launch_flash_attn: XCD-aware (head, query block) order
+    int stage_o = 0;                           // set by launch_flash_attn: O leaves through LDS as 16-byte row-contiguous stores
 };
 int launch_flash_attn(const FlashArgs& a, hipStream_t s);
 

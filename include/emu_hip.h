@@ -61,8 +61,7 @@ unsigned int emu_tp_p2p_giveups(void);
 void emu_set_splitk_scratch(void* ptr, size_t bytes);
 /* Test / bench hook: pin the tile configuration of every following GEMM / conv launch of this process.  0 (default) =
  * the shape heuristic; 'B' 128x128, 'C' 256(n)x128(m), 'K' 128x64 with two k-groups, 'S' 256x128 K-sliced,
- * 'D' 128x128 with two k-groups and a four-stage ring, 'E' 256x128 with two k-groups (1024 threads), 'F' / 'G' the 'K' / 'B'
- * tiles with an L2-warming wave (round 4), 'P' 256x256 ping-pong (K-sliced under half a round of tiles), 'Q' the same never sliced (both: K % 64 == 0 and
+ * 'P' 256x256 ping-pong (K-sliced under half a round of tiles), 'Q' the same never sliced (both: K % 64 == 0 and
  * operands within 2 GiB, else the heuristic), 'H' whole rounds of the 256x256 tile + the remaining columns as a second
  * GEMM (where the tile count allows, else the heuristic).  The parity tests walk every configuration over the
  * bench's true shapes with it (tests/test_gpu_ops.py); production code never calls it. */
@@ -73,7 +72,9 @@ void emu_gemm_force_config(int cfg);
  * XCD-aware slice-major order.  Bit 2: 4..16-row linears skip the LDS-DMA + MFMA stream (gemv_thin.hip) and run on the
  * v_dot2c / register-fed MFMA kernels as before round 3; bit 3: the GEMM / conv epilogues store straight from the accumulator
  * layout (8 bytes per lane to 32 rows per instruction, as before round 4) instead of through the LDS-staged, row-contiguous
- * 16-byte form; bit 4: the lock-step tiles keep the column-major XCD runs instead of 2-D tile blocks per XCD; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
+ * 16-byte form; bit 4: the lock-step tiles keep the column-major XCD runs instead of 2-D tile blocks per XCD; bit 5: no 128 x 128
+ * tile for one-round problems; bit 6: the attention kernel deals its workgroups in launch order (query blocks of a head on 8
+ * different XCDs); bit 7: it stores O straight from the accumulator layout; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
 void emu_gemm_tune(int mask);
 
 /* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at
