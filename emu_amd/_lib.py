@@ -122,6 +122,7 @@ _PROTOS = {
     "emu_unet_set_weight": (i32, [vp, C.c_char_p, vp]),
     "emu_unet_finalize": (i32, [vp]),
     "emu_unet_set_fusion": (i32, [vp, i32]),
+    "emu_unet_set_prefetch_stream": (i32, [vp, vp, i32, vp]),
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
     "emu_vit_blocks": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
@@ -157,6 +158,10 @@ def lib() -> C.CDLL:
         if _OVERRIDE:
             import sys
             print(f"emu_amd: EMU_HIP_LIB override active, loaded {LIB_PATH} (tools A/B mode)", file=sys.stderr)
+        if os.environ.get("EMU_HIP_TOOLS") == "1" and os.environ.get("EMU_GEMM_TUNE"):
+            # tools A/B mode only: start with the given emu_gemm_tune mask (profiling one variant of a whole leg under rocprofv3)
+            l.emu_gemm_tune.restype, l.emu_gemm_tune.argtypes = None, [i32]
+            l.emu_gemm_tune(int(os.environ["EMU_GEMM_TUNE"]))
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args

@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--shapes", default="", help="extra GEMM cases M,N,K,epi;M,N,K,epi;... (run instead of the built-in list)")
+    ap.add_argument("--cold-mb", type=int, default=0, help="cycle through copies of the weight matrix totalling this many MB, so that "
+                    "every launch finds its weights in HBM, not in the 256 MB infinity cache (what a model's forward pass sees)")
     a = ap.parse_args()
     L = lib()
     sk = torch.zeros(512 * 288 * 256, dtype=torch.float32, device="cuda")
@@ -120,10 +122,17 @@ def main():
         res = r(M, N) if epi == 1 else None
         want = None if a.no_check else ref_linear(x, w, bias, res, epi)
         cells, outs = [], {}
+        ws = [w]
+        if a.cold_mb:
+            ws = [w] + [w.clone() for _ in range(max(1, a.cold_mb * 1000000 // (w.numel() * 2)))]
+        it = [0]
+
+        def fn():
+            it[0] += 1
+            return ops.linear(x, ws[it[0] % len(ws)], bias=bias, res=res, epi=epi)
         for c, tn in zip(cfgs, tunes):
             L.emu_gemm_force_config(c)
             L.emu_gemm_tune(tn)
-            fn = lambda: ops.linear(x, w, bias=bias, res=res, epi=epi)
             t = timeit(fn, a.iters if M * N * K > 1e9 else 3)
             tag = ""
             if want is not None and (c >> 8) == 0:
