@@ -122,7 +122,6 @@ _PROTOS = {
     "emu_unet_set_weight": (i32, [vp, C.c_char_p, vp]),
     "emu_unet_finalize": (i32, [vp]),
     "emu_unet_set_fusion": (i32, [vp, i32]),
-    "emu_unet_set_prefetch_stream": (i32, [vp, vp, i32, vp]),
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
     "emu_vit_blocks": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),

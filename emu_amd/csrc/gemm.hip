@@ -748,11 +748,13 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
         // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
         // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
-        // Round 4, with the staged epilogue (its tail was 6.5-9 us on the 128 x 128 tile, now 3): about one round of 128 x 128 tiles
-        // (the UNet's 2048 x 1280 and 8192 x 640 outputs: 160 / 320 tiles, every CU one or two workgroups and no ragged last
-        // round) beats the 128 x 64 tile's 1.25 rounds and the 256 x 128 tile's 0.3-0.75 by 13-17 % (profiles/r04_gemm_ab_*.log);
-        // not for ragged M (the ViT's 1025 rows: a ninth row of tiles for one row)
-        else if (!CONV && tiles_of(a, 128, 128) >= 144 && tiles_of(a, 128, 128) < 400 &&
+        // Round 4, with the staged epilogue (its tail was 6.5-9 us on the 128 x 128 tile, now 3): one to one and a half rounds of
+        // 128 x 128 tiles (the UNet's 8192 x 640 outputs: 320 tiles; the 2048-column remainder of the GEGLU: 256) beat the 128 x 64
+        // and 256 x 128 tiles by 10-15 % also with COLD weights (profiles/r04_gemm_ab_staged_unet_cold_weights.log); below 200
+        // tiles (2048 x 1280: 160 tiles, one workgroup per CU and a two-stage ring) the 128 x 128 tile wins by 15 % on weights
+        // that sit in the cache and loses in the model, where every launch finds them in HBM (same-box kernel stats: 24.7 vs 22.3
+        // us); not for ragged M (the ViT's 1025 rows: a ninth row of tiles for one row)
+        else if (!CONV && tiles_of(a, 128, 128) >= 200 && tiles_of(a, 128, 128) < 400 &&
                  ((a.M + 127) / 128) * 128 <= a.M + a.M / 16 && !(g_tune & 32)) cfg = 'B';
         else if (tc >= 1024) cfg = 'C';
         else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step): 256x128 29.4, 128x128 29.4, 256x256 29.8 ms

@@ -253,10 +253,6 @@ int launch_add_silu(const bf16_t* a, const bf16_t* b, bf16_t* sum_out, bf16_t* s
 // out[r, :] = table[step[0], :] for r < rows
 int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out, int rows, int cols, hipStream_t s);
 
-// one dword of every 128-byte line of [p, p + bytes) is read (weights into the infinity cache ahead of their GEMM); sink: any
-// device dword (written only if the xor of the data hits one magic value)
-int launch_touch_lines(const void* p, size_t bytes, uint32_t* sink, hipStream_t s);
-
 // in-place row softmax of x [rows, ld] over the first `cols` columns: x = bf16(softmax(float(x) * scale))
 // (materialised-score attention for head dims the flash kernel does not cover: the VAE mid block, D = 512)
 // per-row fp8 e4m3fn quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = rne(w / scale)

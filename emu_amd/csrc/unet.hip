@@ -293,24 +293,3 @@ int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out
     EMU_CHECK_LAUNCH();
     return 0;
 }
-
-// ---- weight touch: one dword of every 128-byte line of [p, p + bytes), from a few workgroups.  Run on a side stream ahead of the
-// GEMM that will stream these weights, it pulls them from HBM into the 256 MB infinity cache (memory side: every XCD's later miss
-// finds them there) -- the UNet's 5 GB of weights are cold in every step, and cold weights cost the K = 640 / 1280 GEMMs 10-25 %
-// (tools/mall_prefetch_probe.py, profiles/r04_mall_prefetch_probe.log).
-namespace {
-__global__ __launch_bounds__(256) void touch_lines_kernel(const uint32_t* p, size_t lines, uint32_t* sink) {
-    uint32_t acc = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < lines; i += (size_t)gridDim.x * 256) acc ^= p[i * 32];
-    if (acc == 0x9e3779b9u && sink) *sink = acc;       // keeps the loads alive; practically never taken, harmless if it is
-}
-}  // namespace
-int launch_touch_lines(const void* p, size_t bytes, uint32_t* sink, hipStream_t s) {
-    const size_t lines = bytes / 128;
-    if (!p || lines == 0) return 0;
-    const int grid = lines < 32 * 256 ? (int)((lines + 255) / 256) : 32;
-    hipLaunchKernelGGL(touch_lines_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(p), lines, sink);
-    EMU_CHECK_LAUNCH();
-    return 0;
-}
-

@@ -77,16 +77,6 @@ struct emu_unet {
     const bf16_t* ctx_cache = nullptr;
     const bf16_t* aug_emb = nullptr;
     std::string err;
-    // ---- weight prefetch on a side stream (emu_unet_set_prefetch_stream): the weight matrices in launch order as the previous
-    // step saw them, the position in that list, and the fork events
-    hipStream_t pf_stream = nullptr;
-    int pf_look = 1;
-    std::vector<std::pair<const void*, size_t>> pf_plan, pf_rec;
-    size_t pf_pos = 0;
-    std::vector<hipEvent_t> pf_events;
-    size_t pf_ev_used = 0;
-    bool pf_forked = false;
-    uint32_t* pf_sink = nullptr;
 };
 
 namespace {
@@ -221,51 +211,8 @@ struct Fx {
     float cross_scale = 0.f;
 };
 
-// Weight prefetch (emu_unet_set_prefetch_stream).  Called ahead of every weight-consuming launch with ITS weights: they are recorded
-// (the launch sequence of a step is fixed for a latent size and fusion mask, so the previous step's record is this step's plan), and
-// the weights of the launch `pf_look` positions further down the plan are touched on the side stream, forked off the main stream at
-// this point -- the touch runs beside this launch and is done long before its consumer starts.  Under stream capture the fork /
-// join events become graph edges: the touches are a parallel branch of the step's graph.
-int note_weights(emu_unet* u, const void* w, size_t bytes, hipStream_t s) {
-    if (!u || !u->pf_stream) return 0;
-    u->pf_rec.emplace_back(w, bytes);
-    const size_t at = u->pf_pos++;
-    if (u->pf_plan.empty() || at + u->pf_look >= u->pf_plan.size() || u->pf_plan[at].first != w) return 0;   // no (matching) plan yet
-    const auto& nxt = u->pf_plan[at + u->pf_look];
-    if (nxt.second < (1u << 20)) return 0;             // small matrices (time embeddings, conv_in / conv_out) are not worth a launch
-    if (u->pf_ev_used == u->pf_events.size()) {
-        hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -12;
-        u->pf_events.push_back(e);
-    }
-    hipEvent_t e = u->pf_events[u->pf_ev_used++];
-    if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(u->pf_stream, e, 0) != hipSuccess) return -5;
-    u->pf_forked = true;
-    return launch_touch_lines(nxt.first, nxt.second, u->pf_sink, u->pf_stream);
-}
-// end of a step: join the side stream, keep this step's record as the next step's plan
-int finish_prefetch(emu_unet* u, hipStream_t s) {
-    if (!u->pf_stream) return 0;
-    int st = 0;
-    if (u->pf_forked) {
-        if (u->pf_ev_used == u->pf_events.size()) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -12;
-            u->pf_events.push_back(e);
-        }
-        hipEvent_t e = u->pf_events[u->pf_ev_used++];
-        if (hipEventRecord(e, u->pf_stream) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) st = -5;
-    }
-    u->pf_plan.swap(u->pf_rec);
-    u->pf_rec.clear();
-    u->pf_pos = 0; u->pf_ev_used = 0; u->pf_forked = false;
-    return st;
-}
-
 int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, const bf16_t* res, bf16_t* C, int M, int N, int K,
          int lda, int ldres, int ldc, int epi, hipStream_t s, const Fx* fx = nullptr) {
-    // (M <= 8: a GEMV streams its matrix once at HBM rate whatever the cache holds -- recorded, never prefetched)
-    { int st = note_weights(u, (fx && fx->ln) ? fx->ln->w : Wt, M <= 8 ? 0 : (size_t)N * K * 2, s); if (st) return st; }
     if (M <= 8) {
         if (fx) return -22;
         GemvArgs g{A, Wt, nullptr, bias, res, C, M, N, K, lda, K, ldres, ldc, 0.f, epi, 0, nullptr};
@@ -294,7 +241,6 @@ int conv3(emu_unet* u, const bf16_t* x, const bf16_t* Wt, const bf16_t* bias, co
     GemmArgs g{x, Wt, bias, res, y, Bn * Ho * Wo, Cout, 9 * Cin, 0, 9 * Cin, Cout, Cout, res ? EPI_RESID : EPI_NONE,
                ConvGeom{mode, Hin, Win, Ho, Wo, Cin}, bias2, Ho * Wo, ldb2};
     if (u) { g.partial = u->splitk; g.partial_floats = u->splitk_floats; }    // primitives (u == null): process scratch
-    { int st = note_weights(u, Wt, (size_t)Cout * 9 * Cin * 2, s); if (st) return st; }
     return launch_gemm(g, s);
 }
 
@@ -408,21 +354,7 @@ int emu_unet_create(emu_ctx* ctx, const emu_unet_cfg* cfg, emu_unet** out) {
     *out = u;
     return 0;
 }
-void emu_unet_destroy(emu_unet* u) {
-    if (!u) return;
-    for (hipEvent_t e : u->pf_events) (void)hipEventDestroy(e);
-    delete u;
-}
-
-int emu_unet_set_prefetch_stream(emu_unet* u, emu_stream_t side, int lookahead, void* sink) {
-    if (!u || lookahead < 1 || lookahead > 8) return -22;
-    u->pf_stream = S(side);
-    u->pf_look = lookahead;
-    u->pf_sink = reinterpret_cast<uint32_t*>(sink);
-    u->pf_plan.clear(); u->pf_rec.clear();
-    u->pf_pos = 0; u->pf_ev_used = 0; u->pf_forked = false;
-    return 0;
-}
+void emu_unet_destroy(emu_unet* u) { delete u; }
 
 int emu_unet_set_weight(emu_unet* u, const char* name, const void* ptr) {
     if (!u || !name || !ptr) return -22;
@@ -634,12 +566,10 @@ int emu_unet_step(emu_unet* u, void* latents, int H, int W, const void* temb_tab
     u->splitk = w.splitk; u->splitk_floats = w.splitk_floats;
     if (w.total > ws_bytes) return ufail(u, -12, "emu_unet_step: workspace too small");
     hipStream_t s = S(s_);
-    u->pf_rec.clear(); u->pf_pos = 0;                  // (emu_unet_set_context went through gemm() too)
     UTRY(launch_unet_prep_input(reinterpret_cast<bf16_t*>(latents), reinterpret_cast<const float*>(sigmas), step_dev, w.colin,
                                 u->cfg.in_ch, H, W, u->cfg.kpad_in, s));
     bf16_t* eps = w.t1;                                  // [2*H*W, 4], t1 is free once the last resnet is done
     { int st = unet_body(u, w, H, W, B16(temb_table), step_dev, eps, s); if (st) return st; }
-    UTRY(finish_prefetch(u, s));
     UTRY(launch_cfg_euler_step(eps, reinterpret_cast<bf16_t*>(latents), reinterpret_cast<const float*>(sigmas), step_dev, guidance,
                                u->cfg.in_ch, H * W, s));
     return 0;
@@ -655,12 +585,9 @@ int emu_unet_forward(emu_unet* u, const void* latents, int H, int W, const void*
     u->splitk = w.splitk; u->splitk_floats = w.splitk_floats;
     if (w.total > ws_bytes) return ufail(u, -12, "emu_unet_forward: workspace too small");
     hipStream_t s = S(s_);
-    u->pf_rec.clear(); u->pf_pos = 0;
     UTRY(launch_unet_prep_input(B16(latents), reinterpret_cast<const float*>(sigmas), step_dev, w.colin, u->cfg.in_ch, H, W,
                                 u->cfg.kpad_in, s));
-    { int st = unet_body(u, w, H, W, B16(temb_table), step_dev, reinterpret_cast<bf16_t*>(eps_out), s); if (st) return st; }
-    UTRY(finish_prefetch(u, s));
-    return 0;
+    return unet_body(u, w, H, W, B16(temb_table), step_dev, reinterpret_cast<bf16_t*>(eps_out), s);
 }
 
 }  // extern "C"

@@ -184,8 +184,6 @@ class UNetEngine:
         self._ws = self._cache = None
         self.schedule: Optional[EulerDiscreteSchedule] = None
         self._graph = None
-        self._pf_stream = self._pf_sink = None
-        self.set_prefetch(1)
 
     # ------------------------------------------------------------------ weights
     def _reg(self, name: str, t: torch.Tensor):
@@ -197,20 +195,6 @@ class UNetEngine:
         t = t.to(device=self.device, dtype=torch.float32).contiguous()
         self._keep[name] = t
         check(lib().emu_unet_set_weight(self.handle, name.encode(), t.data_ptr()), "emu_unet_set_weight")
-
-    def set_prefetch(self, lookahead: int = 1) -> None:
-        """Weight prefetch on a side stream (include/emu_hip.h: emu_unet_set_prefetch_stream): every weight-consuming launch of a
-        step forks a small kernel that pulls the weights of the launch ``lookahead`` positions later into the infinity cache;
-        0 = off.  Invalidates a captured hipGraph (the touches are a branch of it)."""
-        self._graph = None
-        if lookahead <= 0:
-            check(lib().emu_unet_set_prefetch_stream(self.handle, None, 1, None), "emu_unet_set_prefetch_stream", self.ctx.handle)
-            return
-        if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=self.device)
-            self._pf_sink = torch.zeros(4, dtype=torch.int32, device=self.device)
-        check(lib().emu_unet_set_prefetch_stream(self.handle, self._pf_stream.cuda_stream, int(lookahead), self._pf_sink.data_ptr()),
-              "emu_unet_set_prefetch_stream", self.ctx.handle)
 
     def set_fusion(self, mask: int) -> int:
         """Launch fusions of the transformer blocks (bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv

@@ -345,13 +345,6 @@ int emu_unet_finalize(emu_unet* u);                       /* -2 + emu_last_error
  * over the (<= 64) prompt tokens runs inside the attn2.to_q projection's epilogue (no q tensor, no attention launch).  0 = the
  * unfused launch sequence (A/B timing, parity of fused vs unfused).  Returns the mask in effect. */
 int emu_unet_set_fusion(emu_unet* u, int mask);
-/* Weight prefetch.  A denoise step streams the UNet's 5 GB of weights once; every GEMM finds its matrix cold in HBM, which costs the
- * K = 640 / 1280 GEMMs of the transformer blocks 10-25 % against weights that sit in the 256 MB infinity cache.  With a side stream
- * set, every weight-consuming launch of emu_unet_step / emu_unet_forward forks a small kernel onto it that touches the weights of the
- * launch `lookahead` (1..8) positions later (known from the previous call's launch sequence: the first call only records), and the
- * step joins the side stream at its end; under stream capture the touches become a parallel branch of the graph.  sink: any device
- * dword.  NULL stream = off (default). */
-int emu_unet_set_prefetch_stream(emu_unet* u, emu_stream_t side_stream, int lookahead, void* sink);
 int emu_unet_temb_total(const emu_unet* u);               /* rows of temb_proj_all (sum of resnet out channels) */
 size_t emu_unet_workspace_bytes(const emu_unet* u, int H, int W);
 size_t emu_unet_context_bytes(const emu_unet* u, int n_ctx);

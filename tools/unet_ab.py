@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """Same-run A/B of the UNet denoise step under different launch-fusion masks (emu_unet_set_fusion): one engine, one set of
 weights, the variants alternated inside one process (box-to-box variance of the MFMA-bound legs is ~12 %, so only same-run
-comparisons are evidence).  A variant is a fusion mask, optionally followed by "t<N>" = emu_gemm_tune(N) (e.g. "3t1") and / or
-"p<N>" = weight-prefetch lookahead N (0 = off; default 1), e.g. "7t8p0".
+comparisons are evidence).  A variant is a fusion mask, optionally followed by "t<N>" = emu_gemm_tune(N) (e.g. "3t1").
 Usage: python tools/unet_ab.py [steps] [variant,variant,...] [rounds]"""
 import os, sys, time
 import torch
@@ -24,11 +23,9 @@ best = {}
 with torch.no_grad():
     for r in range(rounds):
         for m in masks:
-            mm, _, pf = m.partition("p")
-            fm, _, tn = mm.partition("t")
+            fm, _, tn = m.partition("t")
             from emu_amd._lib import lib
             lib().emu_gemm_tune(int(tn or 0))
-            eng.set_prefetch(int(pf) if pf != "" else 1)
             got = eng.set_fusion(int(fm))
             eng.set_timesteps(50)
             eng.set_context(prompt, 1024, 1024)
