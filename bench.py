@@ -620,17 +620,30 @@ def main():
             with torch.no_grad():
                 lm.beam_search_generate(x.view(1, S, -1), mask, 5, 2, min_len=2)        # warm: cache allocation, lazy loads
                 torch.cuda.synchronize(); t = time.perf_counter()
-                out = lm.beam_search_generate(x.view(1, S, -1), mask, 5, n_new, min_len=n_new)
+                out = lm.beam_search_generate(x.view(1, S, -1), mask, 5, n_new, min_len=n_new)   # first call of this signature: captures
+                torch.cuda.synchronize(); dt_first = time.perf_counter() - t
+                torch.cuda.synchronize(); t = time.perf_counter()
+                out = lm.beam_search_generate(x.view(1, S, -1), mask, 5, n_new, min_len=n_new)   # the step graph is re-used
                 torch.cuda.synchronize(); dtb = time.perf_counter() - t
+                lm.beam_graph = False
+                torch.cuda.synchronize(); t = time.perf_counter()
+                lm.beam_search_generate(x.view(1, S, -1), mask, 5, n_new, min_len=n_new)         # the same launches, eager
+                torch.cuda.synchronize(); dt_eager = time.perf_counter() - t
+                lm.beam_graph = True
                 torch.cuda.synchronize(); t = time.perf_counter()
                 lm.prefill(x.view(1, S, -1), mask, lm.kv_capacity(S + n_new))
                 torch.cuda.synchronize(); dpf = time.perf_counter() - t
             steps_b = max(1, out.shape[1] - 1)
             beam = {"num_beams": 5, "new_tokens": int(out.shape[1]), "call_ms": dtb * 1e3,
                     "ms_per_beam_step": (dtb - dpf) * 1e3 / steps_b, "tokens_per_s": steps_b / max(1e-9, dtb - dpf),
+                    "first_call_ms_incl_graph_capture": dt_first * 1e3,
+                    "ms_per_beam_step_eager_launches": (dt_eager - dpf) * 1e3 / steps_b,
                     "note": "5 rows per weight stream (LDS-DMA stages + 16x16x32 MFMA, gemv_thin.hip), the prompt's KV kept once per prompt "
-                            "and read by all beams (emu_llama_set_kv_share), every step's 2N-best selection and scorer bookkeeping in two launches "
-                            "(emu_beam_step_bf16) with one flag read by the host; prefill excluded from the per-step time"}
+                            "and read by all beams (emu_llama_set_kv_share); round 4: the whole step -- slot / position bookkeeping, re-order of "
+                            "the generated KV slots, embedding gather, 60 layers on 5 rows, logits, 2N-best selection and scorer bookkeeping "
+                            "(emu_beam_step_bf16) -- reads its step index on the device and is replayed from one hipGraph, the host looks at the "
+                            "done flags every 4 steps; the graph is captured once per (prompt length, beams, limits): first_call includes "
+                            "that; prefill excluded from the per-step time"}
         except Exception as e:
             beam = {"num_beams": 5, "note": f"beam leg failed: {e}"}
 

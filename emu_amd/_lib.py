@@ -124,6 +124,8 @@ _PROTOS = {
     "emu_unet_set_fusion": (i32, [vp, i32]),
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
+    "emu_beam_advance": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "emu_llama_beam_reorder_kv": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_vit_blocks": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
     "emu_unet_workspace_bytes": (sz, [vp, i32, i32]),
     "emu_unet_context_bytes": (sz, [vp, i32]),

@@ -261,7 +261,73 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const BeamStepArgs a, con
     }
 }
 
+// ---- the rest of a beam step that used to be host work: with these two the whole step {advance, re-order, embed, 60 layers,
+// logits, beam_step_kernel} reads its step index from a device counter and is replayed from one hipGraph.
+// Step bookkeeping.  phase 0 (ahead of the decoder step that feeds token cur - 1): slot = slot0 + cur - 1, pos = pos0 + cur - 1;
+// phase 1 (behind beam_step_kernel): cur += 1.  Steps at the length limit change nothing (replays beyond it are no-ops).
+__global__ void beam_advance_kernel(int32_t* cur_dev, int32_t* pos, int32_t* slot, const int32_t* pos0, int slot0, int rows, int L,
+                                    int phase) {
+    const int c = *cur_dev;
+    if (c >= L) return;
+    if (phase == 0) {
+        for (int i = threadIdx.x; i < rows; i += blockDim.x) { slot[i] = slot0 + c - 1; pos[i] = pos0[i] + c - 1; }
+    } else if (threadIdx.x == 0) {
+        *cur_dev = c + 1;
+    }
+}
+
+// transformers' _reorder_cache for the GENERATED slots [slot0, slot0 + cur - 1) (the prompt's slots are shared by the beams of a
+// group and never move): cache row r takes the slots of row beam_flat[r].  In place: one workgroup owns a (layer, head, slot) of
+// all the rows of a group -- it loads the nb source vectors, then stores them (a barrier in between).  grid = (layers * heads,
+// slot chunks, groups); D / 8 lanes per row.
+template <int D>
+__global__ __launch_bounds__(256) void beam_reorder_kernel(bf16_t* kc, bf16_t* vc, const long* beam_flat, const int32_t* cur_dev,
+                                                           int rows, int Hl, int s_max, int nb, int slot0, int L, int chunk) {
+    constexpr int LPR = D / 8;                         // lanes per row (16-byte pieces)
+    const int c = *cur_dev;
+    if (c >= L) return;
+    const int ngen = c - 1;
+    const int lh = blockIdx.x, layer = lh / Hl, h = lh - layer * Hl, grp = blockIdx.z;
+    const int j = threadIdx.x / LPR, piece = threadIdx.x - j * LPR;
+    const bool live = j < nb;
+    const int dst_row = grp * nb + j;
+    const int src_row = live ? (int)beam_flat[dst_row] : 0;
+    const size_t plane = (size_t)rows * Hl * s_max * D;
+    for (int sl = blockIdx.y * chunk; sl < ngen && sl < (blockIdx.y + 1) * chunk; ++sl) {
+        const size_t so = (((size_t)layer * rows + src_row) * Hl + h) * s_max + slot0 + sl;
+        const size_t dofs = (((size_t)layer * rows + dst_row) * Hl + h) * s_max + slot0 + sl;
+        u32x4 kv, vv;
+        if (live) { kv = ld16(kc + so * D + piece * 8); vv = ld16(vc + so * D + piece * 8); }
+        __syncthreads();                               // every source of this slot is in registers
+        if (live) { st16(kc + dofs * D + piece * 8, kv); st16(vc + dofs * D + piece * 8, vv); }
+        __syncthreads();
+    }
+    (void)plane;
+}
+
 }  // namespace
+
+int launch_beam_advance(int32_t* cur_dev, int32_t* pos, int32_t* slot, const int32_t* pos0, int slot0, int rows, int L, int phase,
+                        hipStream_t s) {
+    if (!cur_dev || rows < 1 || (phase == 0 && (!pos || !slot || !pos0))) return -22;
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(64), 0, s, cur_dev, pos, slot, pos0, slot0, rows, L, phase);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_beam_reorder(bf16_t* kc, bf16_t* vc, const long* beam_flat, const int32_t* cur_dev, int layers, int rows, int Hl, int s_max,
+                        int D, int nb, int slot0, int L, hipStream_t s) {
+    if (!kc || !vc || !beam_flat || !cur_dev || nb < 1 || nb > BEAM_MAXN || rows % nb || (D != 64 && D != 128) ||
+        slot0 < 0 || slot0 + L > s_max + 1)
+        return -22;
+    if (L < 2) return 0;                               // never a generated slot to move
+    constexpr int CHUNK_SLOTS = 8;
+    const dim3 grid(layers * Hl, (L - 1 + CHUNK_SLOTS - 1) / CHUNK_SLOTS, rows / nb);
+    if (D == 128) hipLaunchKernelGGL(beam_reorder_kernel<128>, grid, dim3(nb * 16 <= 128 ? 128 : 256), 0, s, kc, vc, beam_flat, cur_dev, rows, Hl, s_max, nb, slot0, L, CHUNK_SLOTS);
+    else hipLaunchKernelGGL(beam_reorder_kernel<64>, grid, dim3(64), 0, s, kc, vc, beam_flat, cur_dev, rows, Hl, s_max, nb, slot0, L, CHUNK_SLOTS);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
 
 size_t beam_step_ws_floats(int B, int nb, int V) { return (size_t)B * nb * ((V + CHUNK - 1) / CHUNK) * PART; }
 

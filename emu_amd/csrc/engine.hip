@@ -532,6 +532,17 @@ int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, 
     return launch_beam_step(a, reinterpret_cast<float*>(workspace), ws_bytes / sizeof(float), S(s));
 }
 
+int emu_beam_advance(int32_t* cur_dev, int32_t* pos, int32_t* slot, const int32_t* pos0, int slot0, int rows, int L, int phase,
+                     emu_stream_t s) {
+    return launch_beam_advance(cur_dev, pos, slot, pos0, slot0, rows, L, phase, S(s));
+}
+int emu_llama_beam_reorder_kv(emu_llama* m, const long* beam_flat, const int32_t* cur_dev, int beams, int slot0, int L,
+                              emu_stream_t s) {
+    if (!m || !m->kcache) return -22;
+    return launch_beam_reorder(m->kcache, m->vcache, beam_flat, cur_dev, m->cfg.layers, m->kv_batch, m->cfg.heads_local, m->s_max,
+                               m->cfg.head_dim, beams, slot0, L, S(s));
+}
+
 int emu_llama_final_norm(emu_llama* m, const void* hidden, void* out, int rows, emu_stream_t s) {
     if (!m || !m->final_norm) return -22;
     return launch_rmsnorm(B(hidden), m->final_norm, B(out), rows, m->cfg.hidden, m->cfg.hidden, m->cfg.hidden,

@@ -229,6 +229,11 @@ struct BeamStepArgs {
     unsigned char* heuristic_open;             // [B]
     int32_t* next_tok; long* beam_flat;        // [B * nb] out: token to feed / cache row it continues
 };
+// device-side step bookkeeping and KV re-order of a hipGraph-replayed beam step (beam.hip)
+int launch_beam_advance(int32_t* cur_dev, int32_t* pos, int32_t* slot, const int32_t* pos0, int slot0, int rows, int L, int phase,
+                        hipStream_t s);
+int launch_beam_reorder(bf16_t* kc, bf16_t* vc, const long* beam_flat, const int32_t* cur_dev, int layers, int rows, int Hl, int s_max,
+                        int D, int nb, int slot0, int L, hipStream_t s);
 size_t beam_step_ws_floats(int B, int nb, int V);     // scratch of the two-launch step (chunk partials)
 int launch_beam_step(const BeamStepArgs& a, float* ws, size_t ws_floats, hipStream_t s);
 

@@ -259,18 +259,29 @@ class LlamaEngine:
                 return b
         return cap
 
-    def alloc_kv(self, batch: int, s_max: int, zero: bool = True) -> None:
-        if batch == self.kv_batch and s_max == self.s_max and self.kcache is not None:
+    def alloc_kv(self, batch: int, s_max: int, zero: bool = True, which: str = "main") -> None:
+        """Make a cache of ``batch`` rows x ``s_max`` slots the engine's current one.  Two caches persist side by side, the
+        "main" one (prefill, greedy / sampling) and the "beam" one (``fan_out_kv``: prompts x beams rows), each re-used while its
+        shape stays the same: the pointers a captured hipGraph holds stay valid from call to call."""
+        slots = self.__dict__.setdefault("_kv_slots", {})
+        cur = slots.get(which)
+        if cur is None or cur[2] != batch or cur[3] != s_max:
+            L, Hl, D = self.cfg.num_hidden_layers, self.plan.heads_local, self.cfg.head_dim
+            slots[which] = None                            # free the old one first
+            cur = None
+            make = torch.zeros if zero else torch.empty
+            cur = (make(L, batch, Hl, s_max, D, device=self.device, dtype=BF16),
+                   make(L, batch, Hl, s_max, D, device=self.device, dtype=BF16), batch, s_max)
+            slots[which] = cur
+            self._ws = None
+            self.__dict__.pop("_beam_graphs", None)        # graphs captured on the replaced cache are void
+        if self.kcache is cur[0]:
             self.set_kv_share(0, 0)
             return
-        L, Hl, D = self.cfg.num_hidden_layers, self.plan.heads_local, self.cfg.head_dim
-        make = torch.zeros if zero else torch.empty
-        self.kcache = make(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
-        self.vcache = make(L, batch, Hl, s_max, D, device=self.device, dtype=BF16)
-        self.kv_batch, self.s_max = batch, s_max
+        self.kcache, self.vcache, self.kv_batch, self.s_max = cur
         check(lib().emu_llama_set_kv(self.handle, self.kcache.data_ptr(), self.vcache.data_ptr(), batch, s_max),
               "emu_llama_set_kv")
-        self._ws = None
+        self._kv_share = False
 
     KV_SHARE_MAX = 8                                   # DECODE_SHARE_MAX of the decode attention kernel
 
@@ -288,23 +299,18 @@ class LlamaEngine:
         n <= 8, they stay in ONE row per prompt and the decode attention reads them from there (``set_kv_share``): no n-fold
         copy (6 GB at S = 770, 5 beams, 60 layers) and the prompt's keys cross the memory system once per step, not n times."""
         k_old, v_old = self.kcache, self.vcache
-        self.kcache = self.vcache = None
         # no zero fill: every slot a row reads was written first (the prompt's by the copy below -- with set_kv_share only the
         # group's first row is ever read there -- and a generated slot by the step that appends it)
-        self.alloc_kv(B * n, s_max, zero=False)
+        self.alloc_kv(B * n, s_max, zero=False, which="beam")
         if 2 <= n <= self.KV_SHARE_MAX:
             first = torch.arange(B, device=self.device) * n
             self.kcache[:, first, :, :S] = k_old[:, :, :, :S]
-            del k_old
             self.vcache[:, first, :, :S] = v_old[:, :, :, :S]
-            del v_old
             self.set_kv_share(n, S)
         else:
             rep = torch.arange(B, device=self.device).repeat_interleave(n)
             self.kcache[:, :, :, :S] = k_old[:, rep, :, :S]
-            del k_old
             self.vcache[:, :, :, :S] = v_old[:, rep, :, :S]
-            del v_old
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         need = lib().emu_llama_workspace_bytes(self.handle, B, T)
@@ -736,57 +742,102 @@ class LlamaEngine:
             return sequences[:, 0, :out_len]
         return sequences[:, :nret, :out_len].reshape(B * nret, out_len)
 
+    BEAM_POLL = 4          # graph-replayed beam steps between two looks at the done flags
+
     def _beam_search_device(self, logits0: torch.Tensor, B: int, S: int, nb: int, max_len: int, min_len: int,
                             length_penalty: float, eos_id: int, pad_id: int, kstart_b: torch.Tensor, pos: torch.Tensor,
                             nret: int, v431: bool = True) -> torch.Tensor:
-        """The loop of ``beam_search_generate`` for the deterministic mode with every step's log-softmax, 2N-best selection and
-        scorer bookkeeping in one launch (``emu_beam_step_bf16``, csrc/beam.hip: the same statements as the torch pipeline, which
-        stays the specification and the fallback).  Per step the host enqueues: the beam-step kernel, the re-order of the
-        generated KV slots, the embedding gather, the decoder step and the logits -- and reads one flag."""
-        dev, V = self.device, self.vocab
-        i32 = dict(dtype=torch.int32, device=dev)
-        running_seq = torch.full((B, nb, max_len), pad_id, **i32)
-        sequences = running_seq.clone()
-        running_scores = torch.zeros(B, nb, device=dev)
-        running_scores[:, 1:] = -1.0e9
-        beam_scores = torch.full((B, nb), -1.0e9, device=dev)
-        finished = torch.zeros(B, nb, dtype=torch.uint8, device=dev)
-        seq_len = torch.zeros(B, nb, **i32)
-        still_open = torch.ones(B, dtype=torch.uint8, device=dev)
-        next_tok = torch.zeros(B * nb, **i32)
-        beam_flat = torch.zeros(B * nb, dtype=torch.int64, device=dev)
-        hid = torch.empty(B * nb, self.cfg.hidden_size, device=dev, dtype=BF16)
-        slot = torch.full((B * nb,), S - 1, **i32)
-        pos = pos.clone()
-        ws = torch.empty(lib().emu_beam_step_workspace_bytes(B, nb, V), dtype=torch.uint8, device=dev)
-        lg, ld_prompt, ld_beam = logits0, logits0.stride(0), 0          # step 0: every beam continues the prompt
-        cur = 0
+        """The loop of ``beam_search_generate`` for the deterministic mode, with nothing left on the host but the replay of a
+        hipGraph: per step {``emu_beam_advance`` (slot / position of the token to feed from the device-side step counter) ->
+        ``emu_llama_beam_reorder_kv`` (the generated KV slots follow the beam permutation) -> embedding gather -> the decoder
+        step on prompts x beams rows -> logits -> ``emu_beam_step_bf16`` (log-softmax, 2N-best selection and the scorer's
+        bookkeeping, csrc/beam.hip: the same statements as the torch pipeline, which stays the specification and the fallback) ->
+        counter + 1}.  The first step (every beam continues the prompt) runs eagerly on the prefill's logits; the graph is
+        captured once per (prompt length, batch, beams, limits) on the persistent beam cache and replayed ``BEAM_POLL`` steps at
+        a time between two reads of the done flags -- steps replayed beyond the end of the search change nothing (kept results
+        are frozen once a prompt is done, and the kernels do nothing from the length limit on).  ``self.beam_graph = False``
+        runs the same launches eagerly."""
+        dev, V, rows = self.device, self.vocab, B * nb
         L = lib()
-        while True:
-            check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, cur, None, int(min_len), eos_id,
-                                       float(length_penalty), int(v431), running_seq.data_ptr(), sequences.data_ptr(), running_scores.data_ptr(),
-                                       beam_scores.data_ptr(), finished.data_ptr(), seq_len.data_ptr(), still_open.data_ptr(),
-                                       next_tok.data_ptr(), beam_flat.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       ops.stream(self.device)), "emu_beam_step_bf16", self.ctx.handle)
-            cur += 1
-            if cur >= max_len or not bool(still_open.any()):
+        key = (B, nb, S, self.s_max, max_len, int(min_len), float(length_penalty), int(eos_id), bool(v431), self.kcache.data_ptr())
+        cache = self.__dict__.setdefault("_beam_graphs", {})
+        st = cache.get(key)
+        if st is None:
+            cache.clear()                                   # one signature at a time: its buffers are a few MB, its graph ~430 nodes
+            i32 = dict(dtype=torch.int32, device=dev)
+            st = dict(running_seq=torch.empty(B, nb, max_len, **i32), sequences=torch.empty(B, nb, max_len, **i32),
+                      running_scores=torch.empty(B, nb, device=dev), beam_scores=torch.empty(B, nb, device=dev),
+                      finished=torch.empty(B, nb, dtype=torch.uint8, device=dev), seq_len=torch.empty(B, nb, **i32),
+                      still_open=torch.empty(B, dtype=torch.uint8, device=dev), next_tok=torch.empty(rows, **i32),
+                      beam_flat=torch.empty(rows, dtype=torch.int64, device=dev),
+                      hid=torch.empty(rows, self.cfg.hidden_size, device=dev, dtype=BF16), slot=torch.empty(rows, **i32),
+                      pos=torch.empty(rows, **i32), pos0=torch.empty(rows, **i32), kstart=torch.empty(rows, **i32),
+                      cur=torch.empty(1, **i32), lg=torch.empty(rows, V, device=dev, dtype=BF16),
+                      ws=torch.empty(L.emu_beam_step_workspace_bytes(B, nb, V), dtype=torch.uint8, device=dev), graph=None)
+            # the decoder step's workspace: owned here, because the pointers a captured graph holds must outlive any
+            # re-allocation of the engine's shared workspace by a later, larger call
+            need = max(int(L.emu_llama_workspace_bytes(self.handle, rows, 1)), rows * self.cfg.hidden_size * 2)
+            st["fws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            cache[key] = st
+        st["running_seq"].fill_(pad_id); st["sequences"].fill_(pad_id)
+        st["running_scores"].zero_(); st["running_scores"][:, 1:] = -1.0e9
+        st["beam_scores"].fill_(-1.0e9); st["finished"].zero_(); st["seq_len"].zero_(); st["still_open"].fill_(1)
+        st["pos0"].copy_(pos); st["kstart"].copy_(kstart_b)
+        stream = lambda: ops.stream(self.device)           # (inside a capture the current stream is the capturing one)
+
+        def beam_step(lg, ld_prompt, ld_beam, cur, cur_dev):
+            check(L.emu_beam_step_bf16(lg.data_ptr(), ld_prompt, ld_beam, V, B, nb, max_len, cur, cur_dev, int(min_len), eos_id,
+                                       float(length_penalty), int(v431), st["running_seq"].data_ptr(), st["sequences"].data_ptr(),
+                                       st["running_scores"].data_ptr(), st["beam_scores"].data_ptr(), st["finished"].data_ptr(),
+                                       st["seq_len"].data_ptr(), st["still_open"].data_ptr(), st["next_tok"].data_ptr(),
+                                       st["beam_flat"].data_ptr(), st["ws"].data_ptr(), st["ws"].numel(), stream()),
+                  "emu_beam_step_bf16", self.ctx.handle)
+
+        def body():
+            """One step, every index read on the device."""
+            sm = stream()
+            check(L.emu_beam_advance(st["cur"].data_ptr(), st["pos"].data_ptr(), st["slot"].data_ptr(), st["pos0"].data_ptr(), S, rows,
+                                     max_len, 0, sm), "emu_beam_advance")
+            check(L.emu_llama_beam_reorder_kv(self.handle, st["beam_flat"].data_ptr(), st["cur"].data_ptr(), nb, S, max_len, sm),
+                  "emu_llama_beam_reorder_kv", self.ctx.handle)
+            ops.embed_gather(st["next_tok"], self.embed, out=st["hid"])
+            check(L.emu_llama_forward(self.handle, st["hid"].data_ptr(), rows, 1, st["pos"].data_ptr(), st["slot"].data_ptr(),
+                                      st["kstart"].data_ptr(), None, min(S + max_len, self.s_max), st["fws"].data_ptr(),
+                                      st["fws"].numel(), sm), "emu_llama_forward", self.ctx.handle)
+            check(L.emu_llama_logits(self.handle, st["hid"].data_ptr(), st["hid"].stride(0), rows, st["lg"].data_ptr(),
+                                     st["lg"].stride(0), st["fws"].data_ptr(), st["fws"].numel(), sm), "emu_llama_logits",
+                  self.ctx.handle)
+            beam_step(st["lg"], nb * st["lg"].stride(0), st["lg"].stride(0), 0, st["cur"].data_ptr())
+            check(L.emu_beam_advance(st["cur"].data_ptr(), None, None, None, S, rows, max_len, 1, sm), "emu_beam_advance")
+
+        beam_step(logits0, logits0.stride(0), 0, 0, None)     # step 0: every beam continues the prompt
+        st["cur"].fill_(1)
+        done_steps = 1
+        use_graph = getattr(self, "beam_graph", True)
+        while done_steps < max_len:
+            if not bool(st["still_open"].any()):
                 break
-            ctx = S + cur - 1
-            if ctx > S:                                # only the generated slots move with the beam permutation
-                self.kcache[:, :, :, S:ctx] = self.kcache[:, beam_flat, :, S:ctx]
-                self.vcache[:, :, :, S:ctx] = self.vcache[:, beam_flat, :, S:ctx]
-            ops.embed_gather(next_tok, self.embed, out=hid)
-            slot += 1
-            self.forward(hid, B * nb, 1, pos, slot, kstart_b, ctx=ctx + 1)
-            pos += 1
-            lg = self.logits(hid)
-            ld_prompt, ld_beam = nb * lg.stride(0), lg.stride(0)
+            n = min(self.BEAM_POLL, max_len - done_steps)
+            if use_graph and st["graph"] is None:
+                body()                                      # warm-up outside capture: a real step
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                st["graph"] = g
+                done_steps += 1
+                continue
+            for _ in range(n):
+                if use_graph:
+                    st["graph"].replay()
+                else:
+                    body()
+            done_steps += n
         self.set_kv_share(0, 0)
-        out_len = int(seq_len[:, :nret].max().item())
+        out_len = int(st["seq_len"][:, :nret].max().item())
         self.ctx.check_p2p()
-        seqs = sequences.long()
+        seqs = st["sequences"].long()
         if nret == 1:
-            return seqs[:, 0, :out_len]
+            return seqs[:, 0, :out_len].clone()
         return seqs[:, :nret, :out_len].reshape(B * nret, out_len)
 
 

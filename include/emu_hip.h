@@ -283,6 +283,17 @@ int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, 
                        unsigned char* heuristic_open, int32_t* next_tok, long* beam_flat, void* workspace, size_t ws_bytes,
                        emu_stream_t s);
 
+/* The host work of a beam step moved to the device, so that {advance, re-order, embed, decoder step, logits, emu_beam_step_bf16} can
+ * be captured once and replayed for every token (the reference's default decoding mode must not run at the speed of the host):
+ * emu_beam_advance phase 0: slot[i] = slot0 + cur - 1, pos[i] = pos0[i] + cur - 1 for the step that feeds token cur - 1 (cur read
+ *   from cur_dev; rows = prompts x beams); phase 1: cur_dev += 1.  Nothing happens once cur >= L.
+ * emu_llama_beam_reorder_kv: transformers' _reorder_cache for the generated slots [slot0, slot0 + cur - 1) of the engine's current
+ *   cache (rows in groups of `beams`; the shared prompt slots never move): row r takes the slots of row beam_flat[r], in place. */
+int emu_beam_advance(int32_t* cur_dev, int32_t* pos, int32_t* slot, const int32_t* pos0, int slot0, int rows, int L, int phase,
+                     emu_stream_t s);
+int emu_llama_beam_reorder_kv(emu_llama* m, const long* beam_flat, const int32_t* cur_dev, int beams, int slot0, int L,
+                              emu_stream_t s);
+
 /* ---- EVA-CLIP ViT engine -------------------------------------------------------------------------------
  * EVAVisionTransformer.forward_features (eva_vit.py:402-431), post-norm blocks (:296-300), naive attention
  * (:182-252) with heads zero-padded from head_width to 128 at pack time (see emu_amd/vit.py):

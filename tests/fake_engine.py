@@ -41,7 +41,7 @@ class FakeEngine:
             out[:, :, :min(sh, n_past)] = cache_l[first, :, :min(sh, n_past)]
         return out
 
-    def alloc_kv(self, batch, s_max, zero=True):
+    def alloc_kv(self, batch, s_max, zero=True, which="main"):
         L, H, D = self.rcfg.layers, self.rcfg.heads, self.rcfg.head_dim
         # zero=False (the product's fan-out allocates without a fill): NaN here, so a read of a never-written slot cannot pass
         make = torch.zeros if zero else (lambda *a, **k: torch.full(a, float("nan"), **k))

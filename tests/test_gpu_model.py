@@ -170,6 +170,47 @@ def test_generate_beam_search(tiny_model, golden_dir):
     assert ref_logprob(b1[0].cpu().tolist()) > ref_logprob(z["beam1"][0].tolist()) - 1.5
 
 
+def test_beam_search_graph_replay_equals_eager_steps(tiny_model, golden_dir):
+    """The default decoding mode replays its step from a hipGraph (device-side step counter, KV re-order and bookkeeping kernels:
+    emu_beam_advance / emu_llama_beam_reorder_kv / emu_beam_step_bf16).  Same ids as the eagerly launched steps and as the real
+    reference's fixture; a second call re-uses the captured graph (same prompt length), another prompt length captures anew; both
+    scorer conventions; a search that ends early (a frequent token declared EOS) stops at the same result although the graph is
+    replayed a few steps past the end."""
+    m, W, cfg = tiny_model
+    lm = m.decoder.lm
+    zm = tiny.load(golden_dir, "generate_margin_tiny.npz")
+    z = tiny.load(golden_dir, "generate_tiny.npz")
+    img = _t(zm["image"]).cuda()
+    n_new = int(zm["b5_n_new"])
+    outs = {}
+    for mode in (True, False, True):
+        lm.beam_graph = mode
+        for sem in ("5.x", "4.31"):
+            outs[(mode, sem)] = m.generate_ids(_t(zm["b5_ids"]), _t(zm["b5_mask"]), img, max_new_tokens=n_new, num_beams=5,
+                                               hf_semantics=sem).cpu().tolist()
+    lm.beam_graph = True
+    assert outs[(True, "5.x")] == outs[(False, "5.x")] == zm["b5_new"].tolist()
+    assert outs[(True, "4.31")] == outs[(False, "4.31")]
+    assert len(lm._beam_graphs) == 1 and next(iter(lm._beam_graphs.values()))["graph"] is not None
+    # another prompt (other length, 3 beams, ragged batch): captured anew, equal to eager
+    a = m.generate_ids(_t(z["ids3"]), _t(z["mask3"]), _t(z["image"]).cuda(), max_new_tokens=6, num_beams=3, hf_semantics="5.x").cpu()
+    lm.beam_graph = False
+    b = m.generate_ids(_t(z["ids3"]), _t(z["mask3"]), _t(z["image"]).cuda(), max_new_tokens=6, num_beams=3, hf_semantics="5.x").cpu()
+    assert a.tolist() == b.tolist() == z["beam3"].tolist()
+    # early end: the second token of the best sequence plays EOS -> hypotheses finish at step 1, the heuristic closes the prompt
+    x = m._prompt_embeds(_t(zm["b5_ids"]), img, m.n_query).view(1, _t(zm["b5_ids"]).shape[1], -1)
+    eos = int(zm["b5_new"][0][1])
+    res = {}
+    for mode in (True, False):
+        lm.beam_graph = mode
+        for sem in ("5.x", "4.31"):
+            res[(mode, sem)] = lm.beam_search_generate(x, _t(zm["b5_mask"]), 5, 12, eos_id=eos, hf_semantics=sem).cpu().tolist()
+    lm.beam_graph = True
+    assert res[(True, "5.x")] == res[(False, "5.x")] and res[(True, "4.31")] == res[(False, "4.31")]
+    st = next(iter(lm._beam_graphs.values()))
+    assert bool(st["finished"].any()) and int(st["cur"]) <= 12          # hypotheses did end with the stand-in EOS
+
+
 def test_generate_beam_sampling_and_penalised_beams(tiny_model, golden_dir):
     """num_beams > 1 with do_sample (beam-search multinomial sampling) and with repetition_penalty on the GPU engine.  The
     host logic is pinned to the real reference's ids on CPU (tests/test_host_logic.py, same torch seed); here: the device
