@@ -258,9 +258,39 @@ def denoise_leg(ctx, dev, steps, world, dist, fusion=-1):
     per_gpu = steps / dt
     finite = bool(torch.isfinite(lat.float()).all())
     denoise_leg.engine = eng
+    # per-kernel table of the same engine in the same process: two eagerly launched steps with HIP events around every GEMM /
+    # conv / attention launch (emu_profile_launches), aggregated by shape
+    table = None
+    try:
+        import ctypes as C
+        from emu_amd._lib import ProfRowC, lib
+        L = lib()
+        with torch.no_grad():
+            eng.set_timesteps(steps)
+            lat.copy_(lat0)
+            eng.denoise(lat, 3.0, use_graph=False, steps=1)
+            L.emu_profile_launches(1)
+            eng.denoise(lat, 3.0, use_graph=False, steps=2)
+            torch.cuda.synchronize()
+            rows = (ProfRowC * 256)()
+            n = L.emu_profile_launches_read(rows, 256)
+            L.emu_profile_launches(0)
+        rs = sorted((rows[i] for i in range(max(0, n))), key=lambda r: -r.ms)
+        tot = sum(r.ms for r in rs) / 2
+        epi_names = {0: "", 1: "+res", 2: "swiglu", 3: "silu", 4: "gelu", 5: "geglu"}
+        table = {"source": "this run: 2 eager steps, HIP events around each launch (emu_profile_launches); frac = FLOP / time / 2.5 PFLOP/s",
+                 "mfma_launch_ms_per_step": tot, "share_of_step": tot / (dt / steps * 1e3),
+                 "top": [{"kernel": (f"{r.klass.decode()} {r.M}x{r.N}x{r.K} {epi_names.get(r.tag & 255, '')}"
+                                     f"{' fx' + str(r.tag >> 8) if (r.tag >> 8) and r.klass != b'attn' else ''}"
+                                     f"{' heads*batch ' + str(r.tag) if r.klass == b'attn' else ''}").strip(),
+                          "calls_per_step": r.launches / 2, "us": r.ms * 1e3 / r.launches, "ms_per_step": r.ms / 2,
+                          "gflop": r.flops / r.launches / 1e9, "frac": r.flops / (r.ms * 1e-3) / MFMA_BF16_PEAK} for r in rs[:10]]}
+    except Exception as e:                                  # the table is a convenience, never a reason to lose the leg
+        table = {"note": f"kernel table failed: {e}"}
     return {"metric": "diffusion denoise steps/sec (UNet fwd CFG batch 2 + guidance + Euler step, 1024x1024, 64 ctx tokens)",
             "value": per_gpu * world, "unit": "steps/s", "per_gpu": per_gpu, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "scaling": "replicas only (independent images per GPU)", "launch": "hipGraph replay", "finite_output": finite,
+            "kernels": table,
             "fusion": {"mask": fusion, "layernorm_folded_into_gemm": bool(fusion & 1), "v_transpose_in_qkv_epilogue": bool(fusion & 2),
                        "cross_attention_in_to_q_epilogue": bool(fusion & 4)},
             "roofline": {"bound": "mfma", "achieved": UNET_FLOPS_PER_STEP * per_gpu / 1e12, "peak": MFMA_BF16_PEAK / 1e12,

@@ -46,6 +46,12 @@ class LinearFxC(C.Structure):
                 ("cross_scale", f32)]
 
 
+class ProfRowC(C.Structure):
+    """emu_prof_row (include/emu_hip.h)."""
+    _fields_ = [("klass", C.c_char * 16), ("M", i32), ("N", i32), ("K", i32), ("tag", i32), ("launches", i32),
+                ("ms", C.c_double), ("flops", C.c_double)]
+
+
 class UNetCfgC(C.Structure):
     _fields_ = [("in_ch", i32), ("out_ch", i32), ("ch", i32 * 3), ("layers_per_block", i32), ("depth", i32 * 3),
                 ("heads", i32 * 3), ("attn", i32 * 3), ("cross_dim", i32), ("groups", i32), ("gn_eps", f32),
@@ -56,6 +62,8 @@ _PROTOS = {
     "emu_version": (i32, []),
     "emu_gemm_trace": (None, [vp]),
     "emu_gemm_trace_built": (i32, []),
+    "emu_profile_launches": (i32, [i32]),
+    "emu_profile_launches_read": (i32, [vp, i32]),
     "emu_profile_gemv": (i32, [i32]),
     "emu_profile_gemv_read": (i32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "emu_ctx_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
@@ -124,6 +132,7 @@ _PROTOS = {
     "emu_unet_set_fusion": (i32, [vp, i32]),
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
+    "emu_regress_advance_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "emu_beam_advance": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "emu_llama_beam_reorder_kv": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_vit_blocks": (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),

@@ -409,9 +409,12 @@ int launch_flash_attn(const FlashArgs& a, hipStream_t s) {
     const int tune = emu_gemm_tune_get();              // A/B switches: bit 6 = straight block order, bit 7 = direct O stores
     b.xcd_remap = !(tune & 64);
     b.stage_o = !(tune & 128) && !((a.o_ss | a.o_sh | a.o_sb) & 7) && !((uintptr_t)a.o & 15);
+    if (a.D != 128 && a.D != 64) return -22;
+    const bool prof = emu_prof_on();
+    if (prof) emu_prof_begin(s);
     if (a.D == 128) hipLaunchKernelGGL(flash_kernel<128>, grid, block, 0, s, b);
-    else if (a.D == 64) hipLaunchKernelGGL(flash_kernel<64>, grid, block, 0, s, b);
-    else return -22;
+    else hipLaunchKernelGGL(flash_kernel<64>, grid, block, 0, s, b);
+    if (prof) emu_prof_end(s, "attn", a.Sq, a.Sk, a.D, a.B * a.H, (a.causal ? 2.0 : 4.0) * a.B * a.H * (double)a.Sq * a.Sk * a.D);
     EMU_CHECK_LAUNCH();
     return 0;
 }
@@ -432,7 +435,30 @@ __global__ void greedy_advance_kernel(const int32_t* cur_ids, int32_t* pos, int3
     if (b == 0) { *ctx += 1; *step = st + 1; }
 }
 
+// generate_image's loop state on the device (emu.py:92-153, KV-cached form): the step's output rows [B, cols] go to out_all[step]
+// and to `prev` (the next step's regression input), positions / slots / the step counter advance
+__global__ void regress_advance_kernel(const bf16_t* src, bf16_t* out_all, bf16_t* prev, int32_t* pos, int32_t* slot, int32_t* step,
+                                       int B, int cols) {
+    const int st = *step;
+    for (int i = threadIdx.x; i < B * cols; i += blockDim.x) {
+        const bf16_t v = src[i];
+        out_all[(size_t)st * B * cols + i] = v;
+        prev[i] = v;
+    }
+    if ((int)threadIdx.x < B) { pos[threadIdx.x] += 1; slot[threadIdx.x] += 1; }
+    __syncthreads();
+    if (threadIdx.x == 0) *step = st + 1;
+}
+
 }  // namespace
+
+int launch_regress_advance(const bf16_t* src, bf16_t* out_all, bf16_t* prev, int32_t* pos, int32_t* slot, int32_t* step, int B,
+                           int cols, hipStream_t s) {
+    if (B < 1 || B > 256 || cols < 1) return -22;
+    hipLaunchKernelGGL(regress_advance_kernel, dim3(1), dim3(256), 0, s, src, out_all, prev, pos, slot, step, B, cols);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, int32_t* ctx, int32_t* step,
                           int32_t* out_ids, int B, hipStream_t s) {

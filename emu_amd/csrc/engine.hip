@@ -40,6 +40,16 @@ struct GemvProfiler {
     double bytes = 0.0;
 } g_prof;
 
+// launch profiler: event pairs + what was launched, aggregated on read
+struct LaunchProfiler {
+    bool on = false;
+    struct Rec { hipEvent_t a, b; const char* klass; int M, N, K, tag; double flops; };
+    std::vector<Rec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+    hipEvent_t cur_a = nullptr, cur_b = nullptr;
+} g_lprof;
+
 int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* res, const bf16_t* norm_w,
            bf16_t* C, int M, int N, int K, int lda, int ldw, int ldres, int ldc, float eps, int epi, hipStream_t s,
            const float* wscale = nullptr, float* splitk = nullptr, size_t splitk_floats = 0) {
@@ -73,6 +83,25 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
 
 int emu_ctx_fail(emu_ctx* c, int code, const char* what) { return fail(c, code, what); }
 
+bool emu_prof_on() { return g_lprof.on; }
+void emu_prof_begin(hipStream_t s) {
+    if (g_lprof.used == g_lprof.pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_lprof.cur_a = nullptr; return; }
+        g_lprof.pool.emplace_back(a, b);
+    }
+    g_lprof.cur_a = g_lprof.pool[g_lprof.used].first;
+    g_lprof.cur_b = g_lprof.pool[g_lprof.used].second;
+    ++g_lprof.used;
+    (void)hipEventRecord(g_lprof.cur_a, s);
+}
+void emu_prof_end(hipStream_t s, const char* klass, int M, int N, int K, int tag, double flops) {
+    if (!g_lprof.cur_a) return;
+    (void)hipEventRecord(g_lprof.cur_b, s);
+    g_lprof.recs.push_back({g_lprof.cur_a, g_lprof.cur_b, klass, M, N, K, tag, flops});
+    g_lprof.cur_a = nullptr;
+}
+
 extern "C" {
 
 int emu_version(void) { return 2; }      // ABI version: emu_amd/_lib.py::ABI_VERSION must match
@@ -87,6 +116,33 @@ int emu_gemm_trace_built(void) {
 #else
     return 0;
 #endif
+}
+
+int emu_profile_launches(int enable) {
+    g_lprof.on = enable != 0;
+    g_lprof.recs.clear();
+    g_lprof.used = 0;
+    return 0;
+}
+int emu_profile_launches_read(emu_prof_row* rows, int cap) {
+    int n = 0;
+    for (const auto& r : g_lprof.recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return -5;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return -5;
+        int i = 0;
+        for (; i < n; ++i)
+            if (!strcmp(rows[i].klass, r.klass) && rows[i].M == r.M && rows[i].N == r.N && rows[i].K == r.K && rows[i].tag == r.tag) break;
+        if (i == n) {
+            if (n == cap) continue;
+            memset(&rows[n], 0, sizeof rows[n]);
+            strncpy(rows[n].klass, r.klass, sizeof rows[n].klass - 1);
+            rows[n].M = r.M; rows[n].N = r.N; rows[n].K = r.K; rows[n].tag = r.tag;
+            ++n;
+        }
+        rows[i].launches += 1; rows[i].ms += ms; rows[i].flops += r.flops;
+    }
+    return n;
 }
 
 int emu_profile_gemv(int enable) {
@@ -532,6 +588,11 @@ int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, 
     return launch_beam_step(a, reinterpret_cast<float*>(workspace), ws_bytes / sizeof(float), S(s));
 }
 
+int emu_regress_advance_bf16(const void* src, void* out_all, void* prev, int32_t* pos, int32_t* slot, int32_t* step_dev, int Bn,
+                             int cols, emu_stream_t s) {
+    if (!src || !out_all || !prev || !pos || !slot || !step_dev) return -22;
+    return launch_regress_advance(B(src), B(out_all), B(prev), pos, slot, step_dev, Bn, cols, S(s));
+}
 int emu_beam_advance(int32_t* cur_dev, int32_t* pos, int32_t* slot, const int32_t* pos0, int slot0, int rows, int L, int phase,
                      emu_stream_t s) {
     return launch_beam_advance(cur_dev, pos, slot, pos0, slot0, rows, L, phase, S(s));

@@ -802,7 +802,15 @@ int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {
     return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
 }
 
+static int launch_gemm_impl(const GemmArgs& a, hipStream_t s);
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (!emu_prof_on()) return launch_gemm_impl(a, s);
+    emu_prof_begin(s);
+    const int st = launch_gemm_impl(a, s);
+    emu_prof_end(s, a.conv.mode != CONV_NONE ? "conv" : "gemm", a.M, a.N, a.K, a.epi | (gemm_fx(a) << 8), 2.0 * a.M * a.N * a.K);
+    return st;
+}
+static int launch_gemm_impl(const GemmArgs& a, hipStream_t s) {
     if (a.M < 1 || a.N < 1 || (a.K & 7) || (a.ldw & 7)) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
     if (a.bias2 && a.rows_per_batch < 1) return -22;

@@ -122,6 +122,12 @@ void emu_gemm_force_config_set(int cfg);
 void emu_gemm_tune_set(int mask);
 int emu_gemm_tune_get();
 
+// ---- launch profiler (engine.hip; bench.py's per-kernel table of the denoise leg): HIP events around the MFMA-carrying launches
+// (GEMM / conv / attention) while enabled -- eager launches only.  klass: a short static string.
+bool emu_prof_on();
+void emu_prof_begin(hipStream_t s);
+void emu_prof_end(hipStream_t s, const char* klass, int M, int N, int K, int tag, double flops);
+
 // ---- row-wise / elementwise (elementwise.hip)
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);
 // y = (res ? res : 0) + LayerNorm(x) * w + b       (ViT post-norm residual, eva_vit.py:298-300)
@@ -190,6 +196,9 @@ int decode_attn_nsplit(int ctx);
 int launch_greedy_advance(const int32_t* cur_ids, int32_t* pos, int32_t* slot, int32_t* ctx, int32_t* step,
                           int32_t* out_ids, int B, hipStream_t s);
 int launch_decode_attn(const DecodeAttnArgs& a, hipStream_t s);
+// out_all[step[0]] = prev = src ([B, cols] bf16); pos[b]++, slot[b]++, step[0]++   (generate_image's loop state, on the device)
+int launch_regress_advance(const bf16_t* src, bf16_t* out_all, bf16_t* prev, int32_t* pos, int32_t* slot, int32_t* step, int B,
+                           int cols, hipStream_t s);
 
 // Decode step, fused: RoPE of q and of the new k, KV-cache append of the new token, and single-query attention over
 // the cache, in one launch (+ the split combine).  Context length of row b = slot[b] + 1, read on the device.

@@ -276,13 +276,68 @@ class EmuModel:
         # 0..len-1 behind left padding
         hidden, kstart, pos = lm.prefill(x.view(B, S, -1), mask, hf_generate_positions=True)
         h = lm.final_norm_rows(hidden[:, -1, :].contiguous())
-        outs = [self._project(h, self.project_down)]                               # [B, width]
-        for j in range(self.n_query - 1):
-            xin = self._project(outs[-1], self.project_up)                        # [B, hidden]
-            hj = lm.decode_embeds(xin, pos, S + j, kstart)
-            pos = pos + 1
-            outs.append(self._project(lm.final_norm_rows(hj), self.project_down))
-        return torch.stack(outs, dim=1)                                            # [B, n_query, width]
+        first = self._project(h, self.project_down)                                # [B, width]
+        if self.n_query == 1:
+            return first[:, None, :]
+        # replayed from a hipGraph where the host would bound the loop (tensor-parallel shards: a step is ~2.7 ms of small
+        # launches at TP = 8); at TP = 1 the eager loop stays ahead of the GPU and measured 2 % FASTER than the replay
+        # (10.25 vs 10.48 ms per step: profiles/r04_bench_tp1_*.json), so it is the default there
+        if not getattr(self, "regress_graph", self.ctx.tp_size > 1):
+            outs = [first]
+            for j in range(self.n_query - 1):
+                xin = self._project(outs[-1], self.project_up)                    # [B, hidden]
+                hj = lm.decode_embeds(xin, pos, S + j, kstart)
+                pos = pos + 1
+                outs.append(self._project(lm.final_norm_rows(hj), self.project_down))
+            return torch.stack(outs, dim=1)                                        # [B, n_query, width]
+        return self._regress_replayed(first, pos, S, kstart)
+
+    def _regress_replayed(self, first: torch.Tensor, pos: torch.Tensor, S: int, kstart: torch.Tensor) -> torch.Tensor:
+        """The n_query - 1 cached steps of ``generate_image`` with the loop state on the device: one step -- project_up, the decoder
+        step on the persistent KV cache, final norm, project_down, ``emu_regress_advance_bf16`` (stores the embedding at the
+        device-side step index, makes it the next input, advances positions and slots) -- is captured into a hipGraph once per
+        (batch, cache) and replayed; nothing returns to the host before the last step (at TP = 8 a shard's step is 2.7 ms of small
+        launches: an eager Python loop would bound it)."""
+        from ._lib import check, lib
+        lm = self.decoder.lm
+        B, width, hidden, dev = first.shape[0], first.shape[1], lm.cfg.hidden_size, self.ctx.device
+        L = lib()
+        key = (B, lm.s_max, self.n_query, lm.kcache.data_ptr())
+        st = getattr(self, "_regress_state", None)
+        if st is None or st["key"] != key:
+            i32 = dict(dtype=torch.int32, device=dev)
+            st = dict(key=key, prev=torch.empty(B, width, device=dev, dtype=BF16), xin=torch.empty(B, hidden, device=dev, dtype=BF16),
+                      normed=torch.empty(B, hidden, device=dev, dtype=BF16), cur=torch.empty(B, width, device=dev, dtype=BF16),
+                      out_all=torch.empty(self.n_query, B, width, device=dev, dtype=BF16), pos=torch.empty(B, **i32),
+                      slot=torch.empty(B, **i32), step=torch.empty(1, **i32), kstart=torch.empty(B, **i32), graph=None,
+                      ws=torch.empty(max(int(L.emu_llama_workspace_bytes(lm.handle, B, 1)), B * hidden * 2), dtype=torch.uint8, device=dev))
+            self._regress_state = st
+        st["prev"].copy_(first); st["out_all"][0].copy_(first)
+        st["pos"].copy_(pos); st["slot"].fill_(S); st["step"].fill_(1); st["kstart"].copy_(kstart)
+
+        def body():
+            sm = ops.stream(dev)
+            ops.linear(st["prev"], self.project_up, out=st["xin"])
+            check(L.emu_llama_forward(lm.handle, st["xin"].data_ptr(), B, 1, st["pos"].data_ptr(), st["slot"].data_ptr(),
+                                      st["kstart"].data_ptr(), None, lm.s_max, st["ws"].data_ptr(), st["ws"].numel(), sm),
+                  "emu_llama_forward", self.ctx.handle)
+            check(L.emu_llama_final_norm(lm.handle, st["xin"].data_ptr(), st["normed"].data_ptr(), B, sm), "emu_llama_final_norm")
+            ops.linear(st["normed"], self.project_down, out=st["cur"])
+            check(L.emu_regress_advance_bf16(st["cur"].data_ptr(), st["out_all"].data_ptr(), st["prev"].data_ptr(), st["pos"].data_ptr(),
+                                             st["slot"].data_ptr(), st["step"].data_ptr(), B, width, sm), "emu_regress_advance_bf16")
+
+        n = self.n_query - 1
+        if st["graph"] is None:
+            body()                                              # warm-up outside capture: a real step
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            st["graph"] = g
+            n -= 1
+        for _ in range(n):
+            st["graph"].replay()
+        lm.ctx.check_p2p()
+        return st["out_all"].permute(1, 0, 2).clone()                               # [B, n_query, width] (never a view of the state)
 
     @torch.no_grad()
     def generate_image(self, text: List[str], image: Optional[torch.Tensor] = None,

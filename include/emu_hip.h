@@ -90,6 +90,18 @@ int emu_gemm_trace_built(void);
 int emu_profile_gemv(int enable);
 int emu_profile_gemv_read(double* total_ms, double* weight_bytes, long* launches);
 
+/* Measurement hook (bench.py: per-kernel table of the denoise leg): HIP events around every MFMA-carrying launch -- GEMM, implicit-
+ * GEMM convolution, attention -- issued while enabled (eager launches only, not inside stream capture).  read: the launches since
+ * the last enable, aggregated by (class, M, N, K, tag): klass "gemm" / "conv" / "attn"; for attn M = Sq, N = Sk, K = head dim and
+ * tag = batch x heads; for gemm / conv tag = epilogue | fused-epilogue mask << 8.  Returns the number of rows written (<= cap). */
+typedef struct {
+    char klass[16];
+    int M, N, K, tag, launches;
+    double ms, flops;
+} emu_prof_row;
+int emu_profile_launches(int enable);
+int emu_profile_launches_read(emu_prof_row* rows, int cap);
+
 /* ---- primitive operators -------------------------------------------------------------------------------*/
 /* torch.nn.functional.linear on the hot path (eva_vit.py:106,112,198,250; LlamaAttention/LlamaMLP linears
  * reached from emu.py:133-138,213-229; project_up/down emu.py:53,55,131,147,201).
@@ -282,6 +294,12 @@ int emu_beam_step_bf16(const void* logits, long ld_prompt, long ld_beam, int V, 
                        float* running_scores, float* beam_scores, unsigned char* finished, int32_t* seq_len,
                        unsigned char* heuristic_open, int32_t* next_tok, long* beam_flat, void* workspace, size_t ws_bytes,
                        emu_stream_t s);
+
+/* Loop state of EmuModel.generate_image (emu.py:92-153, KV-cached form: step j feeds project_up(project_down(h_{j-1}))) on the
+ * device, so that {project_up, decoder step, final norm, project_down, this} is captured once and replayed n_query - 1 times:
+ * out_all[step_dev[0]] = prev = src ([B, cols] bf16: the step's visual embedding), pos[b]++, slot[b]++, step_dev[0]++. */
+int emu_regress_advance_bf16(const void* src, void* out_all, void* prev, int32_t* pos, int32_t* slot, int32_t* step_dev, int B,
+                             int cols, emu_stream_t s);
 
 /* The host work of a beam step moved to the device, so that {advance, re-order, embed, decoder step, logits, emu_beam_step_bf16} can
  * be captured once and replayed for every token (the reference's default decoding mode must not run at the speed of the host):

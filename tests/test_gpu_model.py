@@ -352,6 +352,15 @@ def test_generate_image_matches_reference(tiny_model, golden_dir):
     out = m.generate_image_ids(_t(z["prompt_img"]), img.cuda())
     want = R.emu_generate_image_uncached(_t(z["prompt_img"]), img.float(), W, cfg)
     assert rel_err(out, want) < 3e-2, rel_err(out, want)
+    # round 4: the regression loop is replayed from a hipGraph (loop state on the device): the bits of the eager Python loop,
+    # on the first call (warm-up step + capture) and on a later one (replays only)
+    m.regress_graph = True
+    try:
+        first = m.generate_image_ids(_t(z["prompt_img"]), img.cuda())
+        again = m.generate_image_ids(_t(z["prompt_img"]), img.cuda())
+    finally:
+        del m.regress_graph                              # back to the default (eager at TP = 1)
+    assert torch.equal(out, first) and torch.equal(again, first)
 
 
 def test_generate_image_ragged_batch_equals_rows_alone(tiny_model, golden_dir):
