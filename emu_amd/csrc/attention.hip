@@ -97,16 +97,21 @@ __device__ __forceinline__ int sw_off(int row, int chunk) {
     else return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
+// NW waves of 32 queries per workgroup share every K / V tile: 4 (128 queries) or 8 (256 queries: two waves per SIMD, so one wave's
+// softmax runs beside the other's MFMAs, and half the staging per query -- for launches that would otherwise leave 1.25-1.5 rounds
+// of 4-wave workgroups, e.g. the UNet's 32^2 level: 320 workgroups on 256 CUs, 64 CUs with two)
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void flash_kernel(const FlashArgs a) {
+    constexpr int THREADS = NW * 64, QB = NW * 32;
     constexpr int KROWB = D * 2;                      // K tile [64 keys][D]
     constexpr int KCH = D / 8;                        // 16-byte chunks per K row
     constexpr int NKK = D / 16;                       // k-steps of QK^T
     constexpr int NDB = D / 32;                       // 32-wide d blocks of O
     constexpr int KT_BYTES = 64 * KROWB;
     constexpr int VT_BYTES = D * 128;                 // Vt tile [D][64 keys]
-    constexpr int NLD = (KT_BYTES / 16) / 256;        // 16-byte chunks per thread per tile (= D/32)
-    __shared__ __attribute__((aligned(16))) char smem[KT_BYTES + VT_BYTES];
+    constexpr int NLD = (KT_BYTES / 16) / THREADS;    // 16-byte chunks per thread per tile
+    constexpr int SMEM_BYTES = (KT_BYTES + VT_BYTES) > QB * D * 2 ? (KT_BYTES + VT_BYTES) : QB * D * 2;   // K / V tiles, later the O tile
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     char* sK = smem;
     char* sV = smem + KT_BYTES;
 
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
     // blocks of ONE head land on 8 different XCDs and every XCD's L2 has to fetch the K / V of every head (UNet 32^2 level: 40 heads
     // x 256 KB = 10 MB per 4 MB L2: 85 MB fetched for 15.7 MB of operands, every key tile a fabric round trip).  Remapped so that an
     // XCD owns a run of consecutive (head, query block) pairs -- whole heads where the counts allow: K / V cross the fabric once.
-    const int nq = (a.Sq + 127) >> 7, total = nq * a.H * a.B;
+    const int nq = (a.Sq + QB - 1) / QB, total = nq * a.H * a.B;
     int lin = blockIdx.x;
     if (a.xcd_remap) {
         const int xcd = lin & 7, q8 = total >> 3, r8 = total & 7;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
     }
     const int qb = lin % nq, bh = lin / nq;
     const int b = bh / a.H, h = bh - b * a.H;
-    const int qblk = qb * 128;
+    const int qblk = qb * QB;
     const int q0 = qblk + wave * 32;
     const int off = a.Sk - a.Sq;                      // causal: query i sees keys <= i + off
     const int kstart = a.kstart ? a.kstart[b] : 0;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
 
     int last_key = a.Sk - 1;
     if (a.causal) {
-        int qmax = qblk + 127; qmax = qmax < a.Sq ? qmax : a.Sq - 1;
+        int qmax = qblk + QB - 1; qmax = qmax < a.Sq ? qmax : a.Sq - 1;
         last_key = qmax + off < last_key ? qmax + off : last_key;
     }
     const int ntile = last_key < 0 ? 0 : last_key / 64 + 1;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
         const int kt0 = t * 64;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int q = tid + 256 * i;
+            const int q = tid + THREADS * i;
             { const int row = q / KCH, c = q % KCH;
               int key = kt0 + row; key = key < a.Sk ? key : a.Sk - 1;
               rk[i] = ld16(kbase + (size_t)key * a.k_ss + c * 8); }
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
     auto sstore = [&]() {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int q = tid + 256 * i;
+            const int q = tid + THREADS * i;
             st16(sK + sw_off<KROWB>(q / KCH, q % KCH), rk[i]);
             st16(sV + sw_off<128>(q >> 3, q & 7), rv[i]);
         }
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
         // O leaves through LDS (the K / V tiles are dead): in the accumulator layout a store instruction writes 8 bytes to each of
         // 32 query rows (32 cache lines touched); staged, 16 bytes per lane and whole rows of D values (gemm_tile.h::EpiStage)
         constexpr int ROWB = D * 2, SLOTS = ROWB / 16, KEYM = SLOTS - 1;
-        static_assert(128 * ROWB <= KT_BYTES + VT_BYTES, "the O tile fits the K / V tiles' LDS");
+        constexpr int O_BYTES = QB * ROWB;             // (8 waves: twice the K / V tiles' LDS -- declared below)
         __syncthreads();                               // every wave is done with the last K / V tile
         const int row = wave * 32 + l31;
 #pragma unroll
@@ -278,9 +283,10 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const FlashArgs a) {
             }
         __syncthreads();
         bf16_t* ob = a.o + (size_t)b * a.o_sb + (size_t)h * a.o_sh;
+        static_assert(O_BYTES <= SMEM_BYTES, "the O tile fits");
 #pragma unroll
-        for (int r = 0; r < (128 * SLOTS) / 256; ++r) {
-            const int idx = r * 256 + tid, rw = idx / SLOTS, ps = idx % SLOTS, ls = (ps ^ rw) & KEYM;
+        for (int r = 0; r < (QB * SLOTS) / THREADS; ++r) {
+            const int idx = r * THREADS + tid, rw = idx / SLOTS, ps = idx % SLOTS, ls = (ps ^ rw) & KEYM;
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + idx * 16);
             if (qblk + rw < a.Sq) *reinterpret_cast<u32x4*>(ob + (size_t)(qblk + rw) * a.o_ss + ls * 8) = v;
         }
@@ -404,16 +410,23 @@ int launch_flash_attn(const FlashArgs& a, hipStream_t s) {
     if (a.Sq < 1 || a.Sk < 1 || (a.Sk_pad & 63) || a.Sk_pad < a.Sk) return -22;
     if ((a.q_ss & 7) || (a.k_ss & 7) || (a.o_ss & 3) || (a.q_sh & 7) || (a.k_sh & 7) || (a.o_sh & 3) ||
         (a.q_sb & 7) || (a.k_sb & 7) || (a.o_sb & 3)) return -22;
-    const dim3 grid(((a.Sq + 127) / 128) * a.H * a.B), block(256);
     FlashArgs b = a;
-    const int tune = emu_gemm_tune_get();              // A/B switches: bit 6 = straight block order, bit 7 = direct O stores
-    b.xcd_remap = !(tune & 64);
+    const int tune = emu_gemm_tune_get();              // A/B switches: bit 6 = straight block order, bit 7 = direct O stores,
+    b.xcd_remap = !(tune & 64);                        //               bits 12-13 = 1: always 4 waves, 2: always 8 waves
     b.stage_o = !(tune & 128) && !((a.o_ss | a.o_sh | a.o_sb) & 7) && !((uintptr_t)a.o & 15);
     if (a.D != 128 && a.D != 64) return -22;
+    // 256-query workgroups where 128-query ones would leave between one and one and a half rounds (D = 64 only: at D = 128 the
+    // kernel holds 242 registers, two waves per SIMD do not fit twice)
+    const int wg4 = ((a.Sq + 127) / 128) * a.H * a.B;
+    bool w8 = a.D == 64 && wg4 > 256 && wg4 <= 400 && a.Sq >= 256;
+    if (((tune >> 12) & 3) == 1) w8 = false;
+    if (((tune >> 12) & 3) == 2) w8 = a.D == 64;
+    const dim3 grid(w8 ? ((a.Sq + 255) / 256) * a.H * a.B : wg4), block(w8 ? 512 : 256);
     const bool prof = emu_prof_on();
     if (prof) emu_prof_begin(s);
-    if (a.D == 128) hipLaunchKernelGGL(flash_kernel<128>, grid, block, 0, s, b);
-    else hipLaunchKernelGGL(flash_kernel<64>, grid, block, 0, s, b);
+    if (a.D == 128) hipLaunchKernelGGL((flash_kernel<128, 4>), grid, block, 0, s, b);
+    else if (w8) hipLaunchKernelGGL((flash_kernel<64, 8>), grid, block, 0, s, b);
+    else hipLaunchKernelGGL((flash_kernel<64, 4>), grid, block, 0, s, b);
     if (prof) emu_prof_end(s, "attn", a.Sq, a.Sk, a.D, a.B * a.H, (a.causal ? 2.0 : 4.0) * a.B * a.H * (double)a.Sq * a.Sk * a.D);
     EMU_CHECK_LAUNCH();
     return 0;

@@ -351,6 +351,29 @@ def test_flash_attn(D, Sq, Sk, causal):
     close(got, ref_attention(q, k, v, causal, scale), atol=2e-2, what=f"flash D{D} {Sq}x{Sk} causal{causal}")
 
 
+@pytest.mark.parametrize("Sq,Sk,causal,H", [(1024, 1024, False, 20), (300, 300, True, 3), (257, 700, False, 2), (1024, 64, False, 4)])
+def test_flash_attn_variants_agree_bitwise(Sq, Sk, causal, H):
+    """Round 4 forms of the D = 64 attention kernel -- 256-query workgroups (8 waves sharing every K / V tile), the XCD-aware
+    (head, query block) order, O staged through LDS -- change neither the arithmetic nor its order: every combination gives the
+    bits of the round-3 form (emu_gemm_tune: bit 6 straight order, bit 7 direct O stores, bits 12-13 = 1 / 2: always 4 / 8 waves),
+    and all of them the reference."""
+    from emu_amd._lib import lib
+    ops = _ops()
+    B, D = 2, 64
+    q, k, v = rnd(B, Sq, H, D, seed=161), rnd(B, Sk, H, D, seed=162), rnd(B, Sk, H, D, seed=163)
+    scale = D ** -0.5
+    outs = []
+    try:
+        for tune in (64 | 128 | 4096, 4096, 8192, 8192 | 64 | 128, 0):
+            lib().emu_gemm_tune(tune)
+            outs.append(ops.flash_attn(q.cuda(), k.cuda(), v.cuda(), causal, scale).cpu())
+    finally:
+        lib().emu_gemm_tune(0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    close(outs[0], ref_attention(q, k, v, causal, scale), atol=2e-2, what=f"flash variants {Sq}x{Sk}")
+
+
 def test_flash_attn_left_padding_and_strided_qkv():
     ops = _ops()
     B, S, H, D = 2, 150, 2, 128
