@@ -61,6 +61,7 @@ class UNetCfgC(C.Structure):
 _PROTOS = {
     "emu_version": (i32, []),
     "emu_gemm_trace": (None, [vp]),
+    "emu_gemm_trace_nth": (None, [lng]),
     "emu_gemm_trace_built": (i32, []),
     "emu_profile_launches": (i32, [i32]),
     "emu_profile_launches_read": (i32, [vp, i32]),

@@ -110,6 +110,7 @@ void emu_set_splitk_scratch(void* ptr, size_t bytes) { emu_gemm_set_splitk_scrat
 void emu_gemm_force_config(int cfg) { emu_gemm_force_config_set(cfg); }
 void emu_gemm_tune(int mask) { emu_gemm_tune_set(mask); }
 void emu_gemm_trace(void* buf) { emu_gemm_trace_set(reinterpret_cast<unsigned long long*>(buf)); }
+void emu_gemm_trace_nth(long n) { emu_gemm_trace_select(n); }
 int emu_gemm_trace_built(void) {
 #ifdef EMU_TRACE
     return 1;

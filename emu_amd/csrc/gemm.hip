@@ -277,7 +277,12 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
     using Stage = EpiStage<T::BMv, GLU ? T::BNv / 2 : T::BNv, T::THREADS>;
     bool staged = a.stage && nsl == 1 && n0 + T::BNv <= a.N && (FX & FX_CROSS) == 0;
-    if constexpr ((FX & FX_VT) != 0) staged = staged && n0 + T::BNv <= a.vt_col0;
+    bool vt_tile = false;                              // a whole tile of V columns: transposed staging
+    if constexpr ((FX & FX_VT) != 0) {
+        vt_tile = staged && a.stage_vt && n0 >= a.vt_col0;
+        staged = staged && (n0 + T::BNv <= a.vt_col0 || vt_tile);
+    }
+    using StageT = EpiStageT<T::BMv, T::BNv, T::THREADS>;
     char* stage = smem + STAGE_OFF;
     if (staged || T::KG > 1) __syncthreads();          // every wave is done with the ring, every tail DMA has landed
     if constexpr (EPI == EPI_RESID && STAGE_BEHIND) {
@@ -471,6 +476,12 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
                         if constexpr (GLU) {
                             const u32x2 ov = quad_value<EPI, FX>(a, v, rows[j], qin[g]);
                             *reinterpret_cast<uint32_t*>(stage + Stage::off(row, col >> 1)) = ov.x;
+                        } else if ((FX & FX_VT) != 0 && vt_tile) {
+                            const u32x2 ov = quad_value<EPI, FX>(a, v, rows[j], qin[g]);
+                            *reinterpret_cast<bf16_t*>(stage + StageT::off(col, row)) = (bf16_t)(ov.x & 0xffffu);
+                            *reinterpret_cast<bf16_t*>(stage + StageT::off(col + 1, row)) = (bf16_t)(ov.x >> 16);
+                            *reinterpret_cast<bf16_t*>(stage + StageT::off(col + 2, row)) = (bf16_t)(ov.y & 0xffffu);
+                            *reinterpret_cast<bf16_t*>(stage + StageT::off(col + 3, row)) = (bf16_t)(ov.y >> 16);
                         } else {
                             u32x2* cell = reinterpret_cast<u32x2*>(stage + Stage::off(row, col));
                             if constexpr (EPI == EPI_RESID) qin[g].res = *cell;
@@ -482,7 +493,8 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
             }
         }
         __syncthreads();
-        Stage::store(stage, a.C, a.ldc, m0, GLU ? n0 >> 1 : n0, a.M);
+        if ((FX & FX_VT) != 0 && vt_tile) StageT::store(stage, a, m0, n0);
+        else Stage::store(stage, a.C, a.ldc, m0, GLU ? n0 >> 1 : n0, a.M);
     } else {
 #pragma unroll
     for (int i = 0; i < T::NF; ++i) {
@@ -569,6 +581,7 @@ using CfgK = TileCfg<2, 2, 2, 1, 3, 2>;  // 128(n) x 64(m), 2 k-groups x 4 waves
 float* g_splitk_scratch = nullptr;
 size_t g_splitk_floats = 0;
 unsigned long long* g_trace = nullptr;   // emu_gemm_trace_set
+long g_trace_sel = -1, g_trace_count = 0; // emu_gemm_trace_select: only the sel-th GEMM launch since then is traced (-1: all)
 int g_force_cfg = 0;                     // emu_gemm_force_config: tests / benches pin one tile configuration
 int g_tune = 0;                          // emu_gemm_tune: A/B switches of single dispatch decisions (tools/unet_ab.py)
 
@@ -579,8 +592,9 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     GemmArgs b = a;
     b.full_tiles = full_tiles < 0 ? tiles : full_tiles;
     b.ksplit = ksplit;
-    b.trace = g_trace;
+    b.trace = emu_gemm_trace_get();
     b.stage = stage_ok(b) && !(g_tune & 8);
+    b.stage_vt = b.stage && stage_vt_ok(b, T::BMv, T::BNv) && !(g_tune & (1 << 14));
     // XCD-aware 2-D tile blocks (unsplit launches whose tile count splits evenly over the 8 XCDs): block b runs on XCD b % 8 and
     // xcd_order hands every XCD a run of tiles / 8 logical indices; a run of the column-major order covers (nearly) all rows of A
     // when tiles_m is large (2048 x 1280 on 128 x 64 tiles: 32 x 10 tiles, 40 per XCD = all 32 row tiles x 2 weight tiles = 5.2 +
@@ -789,7 +803,13 @@ void emu_gemm_set_splitk_scratch(float* ptr, size_t floats) { g_splitk_scratch =
 void emu_gemm_force_config_set(int cfg) { g_force_cfg = cfg & 255; }
 void emu_gemm_tune_set(int mask) { g_tune = mask; }
 void emu_gemm_trace_set(unsigned long long* buf) { g_trace = buf; }
-unsigned long long* emu_gemm_trace_get() { return g_trace; }
+void emu_gemm_trace_select(long n) { g_trace_sel = n; g_trace_count = 0; }
+// the buffer of THIS launch (every GEMM launch asks once): all launches, or only the selected one
+unsigned long long* emu_gemm_trace_get() {
+    if (!g_trace) return nullptr;
+    if (g_trace_sel < 0) return g_trace;
+    return g_trace_count++ == g_trace_sel ? g_trace : nullptr;
+}
 int emu_gemm_tune_get() { return g_tune; }
 
 int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {

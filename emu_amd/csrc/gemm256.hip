@@ -370,7 +370,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
     using Stage = EpiStage<256, GLU ? 128 : 256, 512>;
     bool staged = a.stage && nsl == 1 && n0 + 256 <= a.N;
-    if constexpr ((FX & FX_VT) != 0) staged = staged && n0 + 256 <= a.vt_col0;
+    bool vt_tile = false;                              // a whole tile of V columns: transposed staging (gemm_tile.h::EpiStageT)
+    if constexpr ((FX & FX_VT) != 0) {
+        vt_tile = staged && a.stage_vt && n0 >= a.vt_col0;
+        staged = staged && (n0 + 256 <= a.vt_col0 || vt_tile);
+    }
+    using StageT = EpiStageT<256, 256, 512>;
     if (staged) {
         __syncthreads();                               // both wave groups are out of the loop
         if constexpr (EPI == EPI_RESID) Stage::load(smem, a.res, a.ldres, m0, n0, a.M);
@@ -430,6 +435,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                         if constexpr (GLU) {
                             const u32x2 ov = quad_value<EPI, FX>(a, v, fx, qin[i][g]);
                             *reinterpret_cast<uint32_t*>(smem + Stage::off(row, col >> 1)) = ov.x;
+                        } else if ((FX & FX_VT) != 0 && vt_tile) {
+                            const u32x2 ov = quad_value<EPI, FX>(a, v, fx, qin[i][g]);
+                            *reinterpret_cast<bf16_t*>(smem + StageT::off(col, row)) = (bf16_t)(ov.x & 0xffffu);
+                            *reinterpret_cast<bf16_t*>(smem + StageT::off(col + 1, row)) = (bf16_t)(ov.x >> 16);
+                            *reinterpret_cast<bf16_t*>(smem + StageT::off(col + 2, row)) = (bf16_t)(ov.y & 0xffffu);
+                            *reinterpret_cast<bf16_t*>(smem + StageT::off(col + 3, row)) = (bf16_t)(ov.y >> 16);
                         } else {
                             u32x2* cell = reinterpret_cast<u32x2*>(smem + Stage::off(row, col));
                             if constexpr (EPI == EPI_RESID) qin[i][g].res = *cell;
@@ -440,7 +451,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        Stage::store(smem, a.C, a.ldc, m0, GLU ? n0 >> 1 : n0, a.M);
+        if ((FX & FX_VT) != 0 && vt_tile) StageT::store(smem, a, m0, n0);
+        else Stage::store(smem, a.C, a.ldc, m0, GLU ? n0 >> 1 : n0, a.M);
     } else {
     // Sub-tile x (64 columns) at a time: its column-only operands (bias / fused-LayerNorm vectors) are fetched once for both row
     // blocks y, a row block's residual / per-batch bias for all of its 8 quads before its first store (gemm_tile.h::QuadIn).
@@ -567,6 +579,7 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.ksplit = ksplit;
     b.trace = emu_gemm_trace_get();
     b.stage = stage_ok(b) && !(emu_gemm_tune_get() & 8);
+    b.stage_vt = b.stage && stage_vt_ok(b, 256, 256) && !(emu_gemm_tune_get() & (1 << 14));
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
     if (fx) {                                           // gemm256_ok: bf16 plain GEMM; launch_gemm: an instantiated (epi, mask) pair

@@ -310,6 +310,39 @@ struct EpiStage {
         }
     }
 };
+// The transposed twin for the V^T tiles of a fused qkv projection (GemmArgs::vt_out: output column n of row m = b * vt_s + s lands
+// at vt_out[(b * (N - vt_col0) + n - vt_col0) * vt_spad + s], key-contiguous): the tile sits in LDS as [n][m], every lane drops its
+// 4 values as 2-byte writes (32 lanes = 32 consecutive m of one n: 64 contiguous bytes), and it leaves as 16-byte stores of 8
+// consecutive keys -- against 64 two-byte global stores per lane straight from the accumulators (traced: those tiles' epilogue
+// 6.7-10 us where the others take 3-4).  Needs whole tiles inside one batch element (vt_s % BMv == 0).
+template <int BMv, int BNv, int THREADS>
+struct EpiStageT {
+    static constexpr int ROWB = BMv * 2, SLOTS = ROWB / 16, KEYM = SLOTS >= 16 ? 15 : SLOTS - 1;
+    static constexpr int ROUNDS = (BNv * SLOTS) / THREADS;
+    static_assert((BNv * SLOTS) % THREADS == 0 && (SLOTS & (SLOTS - 1)) == 0, "tile splits into whole rounds of 16-byte pieces");
+    // byte offset of (column n of the tile, row r of the tile)
+    __device__ static __forceinline__ int off(int n, int r) {
+        const int slot = r >> 3;
+        return n * ROWB + (((slot & ~KEYM) | ((slot ^ n) & KEYM)) << 4) + ((r & 7) << 1);
+    }
+    __device__ static __forceinline__ void store(const char* lds, const GemmArgs& a, int m0, int n0) {
+        const int tid = threadIdx.x;
+        const int b = m0 / a.vt_s, s0 = m0 - b * a.vt_s;
+        bf16_t* base = a.vt_out + ((size_t)b * (a.N - a.vt_col0) + (n0 - a.vt_col0)) * a.vt_spad + s0;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int idx = r * THREADS + tid, n = idx / SLOTS, ps = idx % SLOTS;
+            const int ls = (ps & ~KEYM) | ((ps ^ n) & KEYM);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lds + idx * 16);
+            if (m0 + ls * 8 < a.M && n0 + n < a.N) *reinterpret_cast<u32x4*>(base + (size_t)n * a.vt_spad + ls * 8) = v;
+        }
+    }
+};
+// may the V^T tiles of this launch take the transposed staging? (host side)
+inline bool stage_vt_ok(const GemmArgs& a, int bm, int bn) {
+    return a.vt_out && a.vt_s % bm == 0 && (a.vt_col0 % bn) == 0 && !(a.vt_spad & 7) && !((uintptr_t)a.vt_out & 15) && a.M % bm == 0;
+}
+
 // host side: may this launch take the staged epilogue?  16-byte alignment of C (and the residual) rows; the kernels add the
 // per-tile conditions (tile inside N, whole-K tile, no V^T columns, no remainder-row accumulator)
 inline bool stage_ok(const GemmArgs& a) {

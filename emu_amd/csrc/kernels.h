@@ -96,6 +96,7 @@ struct GemmArgs {
     float cross_scale = 0.f;
     int sup_m = 0, sup_n = 0;   // set by launch_gemm (lock-step tiles, unsplit launches): every XCD owns one sup_m x sup_n block of
                             // tiles instead of a run of the column-major order (fewer distinct A + W rows per L2); 0 = off
+    int stage_vt = 0;       // set by launch_gemm: whole V^T tiles leave through the transposed staging (gemm_tile.h::EpiStageT)
     int stage = 0;          // set by launch_gemm: the staged (LDS-transposed, 16-byte coalesced) epilogue may be taken (gemm_tile.h)
     // ---- per-workgroup timeline (tools/gemm_trace.py; written only by a library built with -DEMU_TRACE): 8 x u64 per workgroup
     unsigned long long* trace = nullptr;
@@ -104,6 +105,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s);
 // tools hook: where the next GEMM launches of a -DEMU_TRACE build write their per-workgroup timelines (nullptr = off)
 void emu_gemm_trace_set(unsigned long long* buf);
 unsigned long long* emu_gemm_trace_get();
+void emu_gemm_trace_select(long n);     // trace only the n-th GEMM launch from now on (-1: every launch)
 // fp8 x fp8 -> bf16 on the block-scaled MFMA (256x256 ping-pong tile only): K % 128 == 0, a.a_scale / a.w_scale set
 int launch_gemm_fp8(const GemmArgs& a, hipStream_t s);
 // the 256x256 ping-pong tile (gemm256.hip), dispatched by launch_gemm; tiles [0, full_tiles) whole-K, the rest in ksplit

@@ -74,7 +74,8 @@ void emu_gemm_force_config(int cfg);
  * layout (8 bytes per lane to 32 rows per instruction, as before round 4) instead of through the LDS-staged, row-contiguous
  * 16-byte form; bit 4: the lock-step tiles keep the column-major XCD runs instead of 2-D tile blocks per XCD; bit 5: no 128 x 128
  * tile for one-round problems; bit 6: the attention kernel deals its workgroups in launch order (query blocks of a head on 8
- * different XCDs); bit 7: it stores O straight from the accumulator layout; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
+ * different XCDs); bit 7: it stores O straight from the accumulator layout; bits 12-13: 1 / 2 = attention always on 4 / 8 waves;
+ * bit 14: V^T tiles of a fused qkv projection stored straight from the accumulators instead of through the transposed staging; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
 void emu_gemm_tune(int mask);
 
 /* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at
@@ -82,6 +83,7 @@ void emu_gemm_tune(int mask);
  * clock at entry / loop end, unused.  Written only by a library built with -DEMU_TRACE (`python -m emu_amd.build --trace` ->
  * libemu_hip_trace.so; emu_gemm_trace_built() says which one is loaded); NULL = off.  The production library ignores it. */
 void emu_gemm_trace(void* buf);
+void emu_gemm_trace_nth(long n);     /* trace only the n-th GEMM / conv launch from now on (a launch INSIDE a model's forward); -1: all */
 int emu_gemm_trace_built(void);
 
 /* Measurement hook (bench.py roofline leg): HIP-event timing of every M<=8 weight-streaming GEMV launched while

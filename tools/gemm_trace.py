@@ -36,7 +36,10 @@ def main():
     ap.add_argument("--shapes", default="unet")
     ap.add_argument("--cfgs", default="0")
     ap.add_argument("--dump", default="")
+    ap.add_argument("--only", default="", help="substring of the case name")
     ap.add_argument("--tune", type=int, default=0, help="emu_gemm_tune mask (8 = staged epilogue off)")
+    ap.add_argument("--fx", default="", help="ln: LayerNorm folded into the GEMM (consumer side); lnvt: + V^T store of the last third of "
+                    "the columns (the UNet's qkv projection); stats: row statistics out (producer side)")
     a = ap.parse_args()
     L = lib()
     L.emu_gemm_tune(a.tune)
@@ -48,12 +51,26 @@ def main():
     shapes = sum((SHAPES[k] for k in (SHAPES if a.shapes == "all" else a.shapes.split(","))), [])
     g = torch.Generator(device=dev).manual_seed(0)
     for name, M, N, K, epi in shapes:
+        if a.only and a.only not in name:
+            continue
         x = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).to(torch.bfloat16)
         bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16) if epi in (1, 4, 5) else None
         res = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16) if epi == 1 else None
         out = torch.empty(M, N // 2 if epi in (2, 5) else N, device=dev, dtype=torch.bfloat16)
         fn = lambda: ops.linear(x, w, bias=bias, res=res, epi=epi, out=out)
+        if a.fx:
+            st = torch.randn(K // 128, M, 2, device=dev, generator=g).abs() + 1.0
+            cvec, dvec = torch.randn(N, device=dev, generator=g), torch.randn(N, device=dev, generator=g)
+            if a.fx == "stats":
+                so = torch.zeros(N // 128, M, 2, device=dev)
+                fn = lambda: ops.linear_fused(x, w, bias=bias, res=res, epi=epi, out=out, stats_out=so)
+            elif a.fx == "ln":
+                fn = lambda: ops.linear_fused(x, w, epi=epi, out=out, ln=(cvec, dvec, st, 1e-5))
+            elif a.fx == "lnvt":
+                S_ = M // 2
+                vt = torch.zeros(2, N // 3, S_, device=dev, dtype=torch.bfloat16)
+                fn = lambda: ops.linear_fused(x, w, epi=epi, out=out, ln=(cvec, dvec, st, 1e-5), vt=(vt, 2 * N // 3, S_))
         for c in a.cfgs.split(","):
             L.emu_gemm_force_config(0 if c == "0" else ord(c))
             L.emu_gemm_trace(None)
