@@ -88,6 +88,7 @@ _PROTOS = {
     "emu_linear_fp8_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "emu_layernorm_q8_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "emu_softmax_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_embed_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_scatter_rows_bf16": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -121,6 +122,8 @@ _PROTOS = {
     "emu_vit_destroy": (None, [vp]),
     "emu_vit_set_stem": (i32, [vp, vp, vp, vp, vp]),
     "emu_vit_set_block": (i32, [vp, i32] + [vp] * 12),
+    "emu_vit_set_block_fp8": (i32, [vp, i32] + [vp] * 8),
+    "emu_vit_use_fp8": (i32, [vp, i32]),
     "emu_vit_workspace_bytes": (sz, [vp, i32]),
     "emu_vit_forward": (i32, [vp, vp, i32, i32, vp, vp, sz, vp]),
     "emu_groupnorm_ws_bytes": (sz, [i32, i32, i32]),
@@ -131,6 +134,7 @@ _PROTOS = {
     "emu_unet_set_weight": (i32, [vp, C.c_char_p, vp]),
     "emu_unet_finalize": (i32, [vp]),
     "emu_unet_set_fusion": (i32, [vp, i32]),
+    "emu_unet_use_fp8": (i32, [vp, i32]),
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
     "emu_regress_advance_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),

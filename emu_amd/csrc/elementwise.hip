@@ -271,6 +271,66 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
         *reinterpret_cast<uint2*>(dst + vi * 8) = make_uint2((unsigned)lo, (unsigned)hi);
     }
 }
+
+// layernorm_kernel + quant_fp8_rows_kernel in one pass over a row of <= 2048 columns (one 16-byte vector per thread, the row
+// stays in registers): y = bf16(res + bf16(LN(x))) as layernorm_kernel writes it (optional: y may be null), and the per-row
+// e4m3 quantisation of exactly those bf16 values (scale = amax / 448, 1 for a zero row) -- bit-identical to the two launches.
+// The W8A8 modes of the ViT / UNet blocks (emu_vit_use_fp8, emu_unet_use_fp8): the LayerNorm in front of a GEMM already holds
+// the whole row, so its output leaves as the GEMM's fp8 operand without a quantise launch.
+__global__ __launch_bounds__(256) void layernorm_q8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           const bf16_t* __restrict__ b, const bf16_t* res, bf16_t* y,
+                                                           uint8_t* __restrict__ q, float* __restrict__ scale, int cols, float eps) {
+    __shared__ float scratch[4];
+    const size_t roff = (size_t)blockIdx.x * cols;
+    const int vi = threadIdx.x;
+    const bool on = vi < (cols >> 3);
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (on) unpack8(ld16(x + roff + vi * 8), f);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j];
+    const float mean = block_sum<4>(s, scratch) / (float)cols;
+    float v = 0.f;
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; v += d * d; }
+    }
+    const float rstd = rsqrtf(block_sum<4>(v, scratch) / (float)cols + eps);
+    float amax = 0.f;
+    if (on) {
+        float g[8], bb[8];
+        unpack8(ld16(w + vi * 8), g);
+        unpack8(ld16(b + vi * 8), bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * g[j] + bb[j];
+        if (res) {
+            float r[8];
+            unpack8(ld16(res + roff + vi * 8), r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = r[j] + bfround(f[j]);
+        }
+        const auto yb = pack8(f);
+        if (y) st16(y + roff + vi * 8, yb);
+        unpack8(yb, f);                                  // the bf16 values the quantiser sees
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+    amax = wave_max(amax);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (threadIdx.x == 0) scale[blockIdx.x] = sc;
+    if (on) {
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] / sc, f[1] / sc, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] / sc, f[3] / sc, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] / sc, f[5] / sc, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] / sc, f[7] / sc, hi, true);
+        *reinterpret_cast<uint2*>(q + roff + vi * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
 }  // namespace
 
 int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s) {
@@ -290,6 +350,13 @@ int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf
                      int rows, int cols, float eps, hipStream_t s) {
     if (rows < 1 || (cols & 7)) return -22;
     hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, s, x, w, b, res, y, cols, eps);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+int launch_layernorm_q8(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* res, bf16_t* y, uint8_t* q, float* scale,
+                        int rows, int cols, float eps, hipStream_t s) {
+    if (rows < 1 || (cols & 7) || cols > 2048 || !q || !scale) return -22;
+    hipLaunchKernelGGL(layernorm_q8_kernel, dim3(rows), dim3(256), 0, s, x, w, b, res, y, q, scale, cols, eps);
     EMU_CHECK_LAUNCH();
     return 0;
 }

@@ -301,6 +301,12 @@ int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* 
                        float eps, emu_stream_t s) {
     return launch_layernorm(B(x), B(w), B(b), B(res), B(y), rows, cols, eps, S(s));
 }
+int emu_layernorm_q8_bf16(const void* x, const void* w, const void* b, const void* res, void* y, void* q, float* scale, int rows,
+                          int cols, float eps, emu_stream_t s) {
+    if (!x || !w || !b || !q || !scale) return -22;
+    return launch_layernorm_q8(B(x), B(w), B(b), B(res), reinterpret_cast<bf16_t*>(y), reinterpret_cast<uint8_t*>(q), scale, rows, cols,
+                               eps, S(s));
+}
 int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s) {
     return launch_softmax_rows(B(x), B(bias), rows, cols, ld, ld_bias, scale, S(s));
 }
@@ -649,11 +655,19 @@ struct emu_vit {
     const bf16_t *wpatch = nullptr, *bpatch = nullptr, *cls = nullptr, *pos = nullptr;
     struct Block { const bf16_t *wqkv, *bqkv, *wproj, *bproj, *ln1w, *ln1b, *fc1w, *fc1b, *fc2w, *fc2b, *ln2w, *ln2b; };
     std::vector<Block> blocks;
+    // optional fp8 (e4m3, one fp32 scale per output row) copies of the four matrices of every block: emu_vit_use_fp8 runs the
+    // blocks' GEMMs W8A8 on the block-scaled MFMA, the activation rows quantised per row ahead of every GEMM
+    struct Block8 { const uint8_t *wqkv = nullptr, *wproj = nullptr, *fc1w = nullptr, *fc2w = nullptr;
+                    const float *sqkv = nullptr, *sproj = nullptr, *sfc1 = nullptr, *sfc2 = nullptr; };
+    std::vector<Block8> blocks8;
+    bool fp8 = false;
 };
 
 namespace {
 constexpr int VIT_DP = 128;      // padded head dim
-struct VitWs { bf16_t *patches, *pemb, *qkv, *vt, *attn, *tmp, *h1; float* splitk; size_t splitk_floats; size_t total; };
+struct VitWs { bf16_t *patches, *pemb, *qkv, *vt, *attn, *tmp, *h1; float* splitk; size_t splitk_floats;
+               uint8_t* x8; float* xs;           // fp8 mode: the current GEMM's activation rows as e4m3 bytes + per-row scales
+               size_t total; };
 VitWs vit_ws(const emu_vit* m, int Bn, void* base) {
     const emu_vit_cfg& c = m->cfg;
     const int g = c.image_size / c.patch_size, T = g * g, N = T + 1;
@@ -672,6 +686,9 @@ VitWs vit_ws(const emu_vit* m, int Bn, void* base) {
     w.h1 = (bf16_t*)take(M * (size_t)c.mlp_hidden * 2);
     w.splitk_floats = EMU_SPLITK_SCRATCH_FLOATS;          // K-slices of fc2 (63 tiles of 256x128) and of fc1's tail round
     w.splitk = (float*)take(w.splitk_floats * sizeof(float));
+    const size_t kmax = std::max<size_t>(std::max<size_t>(c.width, (size_t)c.heads * VIT_DP), c.mlp_hidden);
+    w.x8 = (uint8_t*)take(m->blocks8.empty() ? 0 : M * kmax);
+    w.xs = (float*)take(m->blocks8.empty() ? 0 : M * sizeof(float));
     w.total = off;
     return w;
 }
@@ -704,6 +721,28 @@ int emu_vit_set_block(emu_vit* m, int layer, const void* wqkv, const void* bqkv,
     m->blocks[layer] = {B(wqkv), B(bqkv), B(wproj), B(bproj), B(ln1w), B(ln1b), B(fc1w), B(fc1b), B(fc2w), B(fc2b), B(ln2w), B(ln2b)};
     return 0;
 }
+int emu_vit_set_block_fp8(emu_vit* m, int layer, const void* wqkv8, const float* sqkv, const void* wproj8, const float* sproj,
+                          const void* fc1w8, const float* sfc1, const void* fc2w8, const float* sfc2) {
+    if (!m || layer < 0 || layer >= m->cfg.layers) return -22;
+    if (!wqkv8 || !sqkv || !wproj8 || !sproj || !fc1w8 || !sfc1 || !fc2w8 || !sfc2) return -22;
+    const emu_vit_cfg& c = m->cfg;
+    if ((c.width & 127) || (c.mlp_hidden & 127))
+        return fail(m->ctx, -22, "emu_vit_set_block_fp8: width and mlp_hidden must be multiples of 128 (k tiles of the fp8 MFMA)");
+    if (m->blocks8.size() != (size_t)c.layers) m->blocks8.assign(c.layers, emu_vit::Block8{});
+    auto U = [](const void* p) { return reinterpret_cast<const uint8_t*>(p); };
+    m->blocks8[layer] = {U(wqkv8), U(wproj8), U(fc1w8), U(fc2w8), sqkv, sproj, sfc1, sfc2};
+    return 0;
+}
+int emu_vit_use_fp8(emu_vit* m, int enable) {
+    if (!m) return -22;
+    if (enable) {
+        if (m->blocks8.size() != (size_t)m->cfg.layers) return fail(m->ctx, -22, "emu_vit_use_fp8: fp8 block weights not set");
+        for (const auto& b : m->blocks8)
+            if (!b.wqkv) return fail(m->ctx, -22, "emu_vit_use_fp8: fp8 block weights not set");
+    }
+    m->fp8 = enable != 0;
+    return 0;
+}
 size_t emu_vit_workspace_bytes(const emu_vit* m, int Bn) { return m ? vit_ws(m, Bn, nullptr).total : 0; }
 
 // blocks [l0, l1) in place on tokens x [B * N, C]
@@ -714,15 +753,35 @@ static int vit_blocks(emu_vit* m, bf16_t* x, int Bn, int l0, int l1, const VitWs
     const int QK = Hh * VIT_DP, F = c.mlp_hidden;
     const int npad = (N + 63) / 64 * 64;
     const float scale = 1.0f / sqrtf((float)c.head_width);
+    // one GEMM of a block: bf16, or (emu_vit_use_fp8) the activation rows quantised per row + the fp8 x fp8 GEMM
+    // (quantised = true: the LayerNorm in front of this GEMM has left the rows in w.x8 / w.xs already: launch_layernorm_q8)
+    auto lin = [&](const bf16_t* A, const bf16_t* W, const uint8_t* W8, const float* ws8, const bf16_t* bias, const bf16_t* res,
+                   bf16_t* Cc, int N_, int K_, int ldres, int epi, bool quantised = false) -> int {
+        if (!W8)
+            return linear(A, W, bias, res, nullptr, Cc, M, N_, K_, K_, K_, ldres, N_, 0.f, epi, s, nullptr, w.splitk, w.splitk_floats);
+        if (!quantised) {
+            const int st = launch_quant_fp8_rows(A, K_, w.x8, K_, w.xs, M, K_, s);
+            if (st) return st;
+        }
+        GemmArgs ga{reinterpret_cast<const bf16_t*>(w.x8), reinterpret_cast<const bf16_t*>(W8), bias, res, Cc, M, N_, K_, K_, K_, ldres, N_,
+                    epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+        ga.a_scale = w.xs; ga.w_scale = ws8;
+        ga.partial = w.splitk; ga.partial_floats = w.splitk_floats;
+        return launch_gemm_fp8(ga, s);
+    };
+    const bool q8 = m->fp8 && C <= 2048;                 // LayerNorm rows leave as fp8 operands (launch_layernorm_q8)
+    bool x8_valid = false;                               // post-norm: w.x8 / w.xs hold the quantised rows of x
     for (int l = l0; l < l1; ++l) {
         const emu_vit::Block& Bk = m->blocks[l];
         if (!Bk.wqkv) return fail(cx, -22, "emu_vit_forward: block weights not set");
+        const emu_vit::Block8 B8 = m->fp8 ? m->blocks8[l] : emu_vit::Block8{};
         const bf16_t* ain = x;                           // attention input
         if (c.prenorm) {
-            TRY(cx, launch_layernorm(x, Bk.ln1w, Bk.ln1b, nullptr, w.tmp, M, C, c.ln_eps, s));
+            if (q8) TRY(cx, launch_layernorm_q8(x, Bk.ln1w, Bk.ln1b, nullptr, nullptr, w.x8, w.xs, M, C, c.ln_eps, s));
+            else TRY(cx, launch_layernorm(x, Bk.ln1w, Bk.ln1b, nullptr, w.tmp, M, C, c.ln_eps, s));
             ain = w.tmp;
         }
-        TRY(cx, linear(ain, Bk.wqkv, Bk.bqkv, nullptr, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
+        TRY(cx, lin(ain, Bk.wqkv, B8.wqkv, B8.sqkv, Bk.bqkv, nullptr, w.qkv, 3 * QK, C, 0, EPI_NONE, q8 && (c.prenorm || x8_valid)));
         TransposeVArgs tv{w.qkv + 2 * QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK, w.vt, Bn, Hh, N, VIT_DP, npad};
         TRY(cx, launch_transpose_v(tv, s));
         FlashArgs f{w.qkv, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
@@ -732,16 +791,20 @@ static int vit_blocks(emu_vit* m, bf16_t* x, int Bn, int l0, int l1, const VitWs
         TRY(cx, launch_flash_attn(f, s));
         if (c.prenorm) {
             // x = x + proj(attn);  x = x + fc2(gelu(fc1(LN2(x))))
-            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, x, nullptr, x, M, C, QK, QK, QK, C, C, 0.f, EPI_RESID, s, nullptr, w.splitk, w.splitk_floats));
-            TRY(cx, launch_layernorm(x, Bk.ln2w, Bk.ln2b, nullptr, w.tmp, M, C, c.ln_eps, s));
-            TRY(cx, linear(w.tmp, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s, nullptr, w.splitk, w.splitk_floats));
-            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, x, nullptr, x, M, C, F, F, F, C, C, 0.f, EPI_RESID, s, nullptr, w.splitk, w.splitk_floats));
+            TRY(cx, lin(w.attn, Bk.wproj, B8.wproj, B8.sproj, Bk.bproj, x, x, C, QK, C, EPI_RESID));
+            if (q8) TRY(cx, launch_layernorm_q8(x, Bk.ln2w, Bk.ln2b, nullptr, nullptr, w.x8, w.xs, M, C, c.ln_eps, s));
+            else TRY(cx, launch_layernorm(x, Bk.ln2w, Bk.ln2b, nullptr, w.tmp, M, C, c.ln_eps, s));
+            TRY(cx, lin(w.tmp, Bk.fc1w, B8.fc1w, B8.sfc1, Bk.fc1b, nullptr, w.h1, F, C, 0, EPI_GELU, q8));
+            TRY(cx, lin(w.h1, Bk.fc2w, B8.fc2w, B8.sfc2, Bk.fc2b, x, x, C, F, C, EPI_RESID));
         } else {
-            TRY(cx, linear(w.attn, Bk.wproj, Bk.bproj, nullptr, nullptr, w.tmp, M, C, QK, QK, QK, 0, C, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
-            TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
-            TRY(cx, linear(x, Bk.fc1w, Bk.fc1b, nullptr, nullptr, w.h1, M, F, C, C, C, 0, F, 0.f, EPI_GELU, s, nullptr, w.splitk, w.splitk_floats));
-            TRY(cx, linear(w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, w.tmp, M, C, F, F, F, 0, C, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
-            TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+            TRY(cx, lin(w.attn, Bk.wproj, B8.wproj, B8.sproj, Bk.bproj, nullptr, w.tmp, C, QK, 0, EPI_NONE));
+            if (q8) TRY(cx, launch_layernorm_q8(w.tmp, Bk.ln1w, Bk.ln1b, x, x, w.x8, w.xs, M, C, c.ln_eps, s));
+            else TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
+            TRY(cx, lin(x, Bk.fc1w, B8.fc1w, B8.sfc1, Bk.fc1b, nullptr, w.h1, F, C, 0, EPI_GELU, q8));
+            TRY(cx, lin(w.h1, Bk.fc2w, B8.fc2w, B8.sfc2, Bk.fc2b, nullptr, w.tmp, C, F, 0, EPI_NONE));
+            if (q8) TRY(cx, launch_layernorm_q8(w.tmp, Bk.ln2w, Bk.ln2b, x, x, w.x8, w.xs, M, C, c.ln_eps, s));   // the next block's qkv rows
+            else TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+            x8_valid = q8;
         }
     }
     return 0;

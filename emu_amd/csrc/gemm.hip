@@ -51,8 +51,15 @@ struct TileCfg {
     __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 };
 
-template <int EPI, bool CONV, class T, int FX = 0>
+// F8 (launch_gemm_fp8): both operands are OCP fp8 e4m3 bytes.  A k tile is still 128 bytes per LDS row -- now 128 elements --
+// so staging, swizzle and ring are untouched; a k-step is 64 elements (32 bytes per lane: chunks 4 st + 2 hi, + 1) on the
+// block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 rate: the same MFMA time per k tile for
+// twice the K, half the LDS-DMA bytes per FLOP -- the resource that bounds these tiles), and the per-row scales of the two
+// operands (a_scale[m] * w_scale[n]) multiply the fp32 sums ahead of the epilogue.  Plain GEMM, no fused-LayerNorm features.
+template <int EPI, bool CONV, class T, int FX = 0, bool F8 = false>
 __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
+    static_assert(!F8 || (!CONV && FX == 0), "fp8 operands: plain GEMM only");
+    constexpr int KSH = F8 ? 1 : 0;                     // element offsets -> 2-byte units of the bf16_t pointers below
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
     // row-statistics exchange between the two waves of a 128-column slot: behind the k-group sums where those exist (the ring is
@@ -120,13 +127,13 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     for (int i = 0; i < T::NLW; ++i) {
         const int r = (i * NW + wave) * 8 + (lane >> 3);
         int gn = n0 + r; gn = gn < a.N ? gn : a.N - 1;
-        gW[i] = a.W + (size_t)gn * a.ldw + ck;
+        gW[i] = a.W + (((size_t)gn * a.ldw) >> KSH) + ck;
     }
 #pragma unroll
     for (int i = 0; i < T::NLA; ++i) {
         const int r = (i * NW + wave) * 8 + (lane >> 3);
         int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
-        gA[i] = a.A + (size_t)gm * a.lda + ck;
+        gA[i] = a.A + (((size_t)gm * a.lda) >> KSH) + ck;
         if constexpr (CONV) {
             const int hw = a.conv.Hout * a.conv.Wout;
             pb[i] = gm / hw;
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
     }
     // split-K: this workgroup owns K-tiles [kt0, kt0 + nk) of slice ks
-    const int nk_all = (a.K + BK - 1) / BK;
+    const int Kb = a.K >> KSH;                          // K in 2-byte units: k tiles of 128 bytes per row
+    const int nk_all = (Kb + BK - 1) / BK;
     const int kt0 = (int)((long)ks * nk_all / nsl);
     const int nk = (int)((long)(ks + 1) * nk_all / nsl) - kt0;
     auto issue = [&](int kt, int stage) {
@@ -191,13 +199,13 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
                     glds16(ok ? a.A + off : zero, base + T::W_BYTES + i * NW * 1024);
                 }
             }
-        } else if (k0 + BK <= a.K) {
+        } else if (k0 + BK <= Kb) {
 #pragma unroll
             for (int i = 0; i < T::NLW; ++i) glds16(gW[i] + k0, base + i * NW * 1024);
 #pragma unroll
             for (int i = 0; i < T::NLA; ++i) glds16(gA[i] + k0, base + T::W_BYTES + i * NW * 1024);
         } else {                                       // ragged last k tile (K % 64 != 0): chunks beyond K read zeros
-            const bool in = (k0 + ck) < a.K;
+            const bool in = (k0 + ck) < Kb;
 #pragma unroll
             for (int i = 0; i < T::NLW; ++i) glds16(in ? gW[i] + k0 : zero, base + i * NW * 1024);
 #pragma unroll
@@ -241,6 +249,44 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         issue(kt + T::NSTG - 1, (kt + T::NSTG - 1) % T::NSTG);
         const char* sW = smem + (kt % T::NSTG) * T::ST_BYTES;
         const char* sA = sW + T::W_BYTES;
+        if constexpr (F8) {
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            typedef int v8i_t __attribute__((ext_vector_type(8)));
+            auto op = [](const bf16x8_t& lo, const bf16x8_t& up) {
+                return __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, up), 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            bf16x8_t wf8[2][T::NF][2], af8[2][T::MF][2];
+            auto frags8 = [&](int st, int buf) {           // k-step st = elements 64 st .. + 63: 32 bytes per lane
+                const int ch = st * 4 + hi * 2;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int i = 0; i < T::NF; ++i)
+                        wf8[buf][i][p] = *reinterpret_cast<const bf16x8_t*>(sW + T::off((wn * T::NF + i) * 32 + l31, ch + p));
+#pragma unroll
+                    for (int j = 0; j < T::MF; ++j)
+                        af8[buf][j][p] = *reinterpret_cast<const bf16x8_t*>(sA + T::off((wm * T::MF + j) * 32 + l31, ch + p));
+                }
+            };
+            constexpr int KSTEPS8 = 2 / T::KG;
+            const int st0 = kg * KSTEPS8;
+            frags8(st0, 0);
+#pragma unroll
+            for (int st = 0; st < KSTEPS8; ++st) {
+                if (st < KSTEPS8 - 1) frags8(st0 + st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < T::MF; ++j) {
+                    const v8i_t bq = op(af8[st & 1][j][0], af8[st & 1][j][1]);
+#pragma unroll
+                    for (int i = 0; i < T::NF; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op(wf8[st & 1][i][0], wf8[st & 1][i][1]), bq, acc[i][j],
+                                                                                   0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
         // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are in flight under the MFMAs of kk
         bf16x8_t wf[2][T::NF], af[2][T::MF];
         auto frags = [&](int kk, int buf) {
@@ -323,6 +369,24 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
     }
 
+    if constexpr (F8) {
+        if (nsl == 1 && kg == 0) {                     // K-sliced: splitk_reduce_kernel scales the summed slices
+#pragma unroll
+            for (int j = 0; j < T::MF; ++j) {
+                const int m = m0 + (wm * T::MF + j) * 32 + l31;
+                const float sa = a.a_scale[m < a.M ? m : a.M - 1];
+#pragma unroll
+                for (int i = 0; i < T::NF; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int n = n0 + (wn * T::NF + i) * 32 + 8 * g + 4 * hi + e;
+                            acc[i][j][4 * g + e] *= sa * a.w_scale[n < a.N ? n : a.N - 1];
+                        }
+            }
+        }
+    }
     static_assert(T::NF == 2, "a wave's columns of one row are half a 128-column row-statistics slot");
     RowFx rowfx[T::MF];
     if constexpr ((FX & FX_LN) != 0) {
@@ -586,7 +650,7 @@ int g_force_cfg = 0;                     // emu_gemm_force_config: tests / bench
 int g_tune = 0;                          // emu_gemm_tune: A/B switches of single dispatch decisions (tools/unet_ab.py)
 
 // full_tiles whole-K workgroups followed by (tiles - full_tiles) * ksplit slice workgroups, one launch (+ the reduce)
-template <int EPI, bool CONV, class T>
+template <int EPI, bool CONV, class T, bool F8 = false>
 void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int ksplit = 1) {
     const int tiles = ((a.M + T::BMv - 1) / T::BMv) * ((a.N + T::BNv - 1) / T::BNv);
     GemmArgs b = a;
@@ -611,6 +675,12 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     }
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
+    if constexpr (F8) {                                 // launch_gemm_fp8: no fused-LayerNorm features
+        hipLaunchKernelGGL((gemm2_kernel<EPI, false, T, 0, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
+        if (tail > 0)
+            hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+        return;
+    }
     if (fx) {                                           // launch_gemm has checked gemm_fx_ok(epi, fx)
         if constexpr (!CONV) {
             gemm_fx_dispatch<EPI>(fx, [&](auto m) {
@@ -628,6 +698,8 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
 }
 
 inline int tiles_of(const GemmArgs& a, int bn, int bm) { return ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); }
+// k tiles (128 bytes per operand row) of a problem: 64 bf16 or 128 fp8 elements each
+inline int ktiles_of(const GemmArgs& a) { return a.a_scale ? a.K / 128 : a.K / BK; }
 
 // K-slices for a problem of `tiles` tiles (fewer than the 256 CUs) so that every CU gets about one workgroup; 0 = do
 // not split.  Needs N % 4 == 0 and a non-GLU epilogue (slices are raw fp32 quads), >= min_k k tiles per slice, and a
@@ -637,7 +709,7 @@ int pick_ksplit(const GemmArgs& a, int tiles, int tile_elems, int min_k) {
     if (EPI == EPI_SWIGLU || EPI == EPI_GEGLU || (a.N & 3) || !a.partial) return 0;
     int ksplit = 256 / tiles;
     if (ksplit > 8) ksplit = 8;
-    const int nk = a.K / BK;
+    const int nk = ktiles_of(a);
     while (ksplit > 1 && nk / ksplit < min_k) --ksplit;
     if (ksplit < 2 || (size_t)tiles * ksplit * tile_elems > a.partial_floats) return 0;
     return ksplit;
@@ -651,8 +723,9 @@ int pick_ksplit(const GemmArgs& a, int tiles, int tile_elems, int min_k) {
 // S=1544 down 3 slices (+13 %), S=770 gate/up none (420 tiles: 2 rounds either way), S=1544 gate/up 2-3 slices (+3 %).
 struct PpPlan { bool use; int full_tiles, ksplit; double us; };
 inline PpPlan plan_pp(const GemmArgs& a) {
-    const int tp = gemm256_tiles(a), nk = a.K / BK, CU = 256;
-    const double t_tile = 256.0 * 256.0 * a.K * 2.0 / 5.4e6;           // us: one CU at ~55 % of its share of the MFMA peak
+    const int tp = gemm256_tiles(a), nk = ktiles_of(a), CU = 256;
+    // us: one CU at ~55 % of its share of the MFMA peak (fp8 operands: twice the rate at a somewhat lower fraction)
+    const double t_tile = 256.0 * 256.0 * a.K * 2.0 / 5.4e6 * (a.a_scale ? 0.6 : 1.0);
     const int rem = tp % CU, full = tp - rem;
     PpPlan best{true, tp, 1, (double)((tp + CU - 1) / CU) * t_tile};
     if (rem == 0 || (a.N & 3) || !a.partial) return best;
@@ -673,7 +746,7 @@ inline PpPlan plan_pp(const GemmArgs& a) {
 inline PpPlan pick_pp(const GemmArgs& a) {
     PpPlan no{false, 0, 1, 0.0};
     if (!gemm256_ok(a) || a.M < 192) return no;
-    const int tp = gemm256_tiles(a), nk = a.K / BK, CU = 256;
+    const int tp = gemm256_tiles(a), nk = ktiles_of(a), CU = 256;
     const PpPlan p = plan_pp(a);
     if (tp >= 180) {
         if (nk < 8) return no;
@@ -704,6 +777,34 @@ inline int plan_hybrid(const GemmArgs& a, bool forced) {
     const int n1 = r * CU / tm;
     if (n1 < 1 || n1 >= tn || tm * n1 * 10 < r * CU * 9) return 0;
     return n1;
+}
+
+// The lock-step tile of a problem the 256x256 ping-pong tile does not take ('S' = K-sliced 256 x 128), bf16 and fp8 alike
+// (the rules count tiles and k tiles of 128 bytes per row).
+template <int EPI, bool CONV>
+int pick_lockstep(const GemmArgs& a) {
+    const bool k64 = a.a_scale ? (a.K & 127) == 0 : (a.K & 63) == 0;
+    const int tc = tiles_of(a, 256, 128);
+    // (>= 24 k tiles per slice: with fewer the reduce launch costs more than the slices save -- the ViT's proj at 16 per
+    // slice ran 284 TFLOP/s sliced, 381 on the 128 x 64 tile; profiles/r03_gemm_ilv_ab.log)
+    if (k64 && tc < 256 && pick_ksplit<EPI>(a, tc, 256 * 128, 24)) return 'S';
+    // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so the largest problems take the
+    // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
+    // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
+    // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
+    // Round 4, with the staged epilogue (its tail was 6.5-9 us on the 128 x 128 tile, now 3): one to one and a half rounds of
+    // 128 x 128 tiles (the UNet's 8192 x 640 outputs: 320 tiles; the 2048-column remainder of the GEGLU: 256) beat the 128 x 64
+    // and 256 x 128 tiles by 10-15 % also with COLD weights (profiles/r04_gemm_ab_staged_unet_cold_weights.log); below 200
+    // tiles (2048 x 1280: 160 tiles, one workgroup per CU and a two-stage ring) the 128 x 128 tile wins by 15 % on weights
+    // that sit in the cache and loses in the model, where every launch finds them in HBM (same-box kernel stats: 24.7 vs 22.3
+    // us); not for ragged M (the ViT's 1025 rows: a ninth row of tiles for one row)
+    if (!CONV && tiles_of(a, 128, 128) >= 200 && tiles_of(a, 128, 128) < 400 &&
+             ((a.M + 127) / 128) * 128 <= a.M + a.M / 16 && !(g_tune & 32)) return 'B';
+    if (tc >= 1024) return 'C';
+    if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) return 'C';   // in situ (UNet step): 256x128 29.4, 128x128 29.4, 256x256 29.8 ms
+    if (!CONV && tc >= 180 && tc < 400) return 'C';           // ~one 256x128 tile per CU: ViT qkv
+    if (!CONV && tiles_of(a, 128, 128) >= 400) return 'B';
+    return 'K';
 }
 
 template <int EPI, bool CONV>
@@ -754,27 +855,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // with fewer tiles than CUs are cut into K-slices so they fill the CUs once: fp32 slice tiles land in a
         // scratch, a second launch sums them in order and applies the epilogue.  (Slicing only the tail round of a
         // multi-round problem measured flat: a thin last round simply runs faster.)
-        const int tc = tiles_of(a, 256, 128);
-        // (>= 24 k tiles per slice: with fewer the reduce launch costs more than the slices save -- the ViT's proj at 16 per
-        // slice ran 284 TFLOP/s sliced, 381 on the 128 x 64 tile; profiles/r03_gemm_ilv_ab.log)
-        if (k64 && tc < 256 && pick_ksplit<EPI>(a, tc, 256 * 128, 24)) cfg = 'S';
-        // 128x128 tiles are L1/TA-bandwidth-bound (64 FLOP/B needs ~64 B/clk/CU), so the largest problems take the
-        // 256(n) x 128(m) tile; mid-size GEMMs 128x128 with two workgroups per CU; few-tile / long-K problems (UNet 32x32
-        // level, implicit-GEMM convs, skinny ViT fc2) take 128 x 64 tiles with two k-groups of waves (intra-workgroup
-        // split-K) and two workgroups per CU.  Thresholds from tools/kbench.py sweeps (profiles/r01_gemm_tilecfg_*).
-        // Round 4, with the staged epilogue (its tail was 6.5-9 us on the 128 x 128 tile, now 3): one to one and a half rounds of
-        // 128 x 128 tiles (the UNet's 8192 x 640 outputs: 320 tiles; the 2048-column remainder of the GEGLU: 256) beat the 128 x 64
-        // and 256 x 128 tiles by 10-15 % also with COLD weights (profiles/r04_gemm_ab_staged_unet_cold_weights.log); below 200
-        // tiles (2048 x 1280: 160 tiles, one workgroup per CU and a two-stage ring) the 128 x 128 tile wins by 15 % on weights
-        // that sit in the cache and loses in the model, where every launch finds them in HBM (same-box kernel stats: 24.7 vs 22.3
-        // us); not for ragged M (the ViT's 1025 rows: a ninth row of tiles for one row)
-        else if (!CONV && tiles_of(a, 128, 128) >= 200 && tiles_of(a, 128, 128) < 400 &&
-                 ((a.M + 127) / 128) * 128 <= a.M + a.M / 16 && !(g_tune & 32)) cfg = 'B';
-        else if (tc >= 1024) cfg = 'C';
-        else if ((EPI == EPI_GEGLU || EPI == EPI_SWIGLU) && tc >= 512) cfg = 'C';   // in situ (UNet step): 256x128 29.4, 128x128 29.4, 256x256 29.8 ms
-        else if (!CONV && tc >= 180 && tc < 400) cfg = 'C';           // ~one 256x128 tile per CU: ViT qkv
-        else if (!CONV && tiles_of(a, 128, 128) >= 400) cfg = 'B';
-        else cfg = 'K';
+        cfg = pick_lockstep<EPI, CONV>(a);
     }
     switch (cfg) {
         case 'Q': return launch_gemm256(a, s, -1, 1);  // 256x256 ping-pong, never K-sliced (A/B)
@@ -812,14 +893,63 @@ unsigned long long* emu_gemm_trace_get() {
 }
 int emu_gemm_tune_get() { return g_tune; }
 
-int launch_gemm_fp8(const GemmArgs& a0, hipStream_t s) {
+// fp8 x fp8 -> bf16: the 256x256 ping-pong tile where the bf16 rules would take it, else the lock-step tiles' fp8 form
+template <int EPI>
+static int launch_fp8_v2(const GemmArgs& a, hipStream_t s) {
+    int cfg = g_force_cfg;
+    if (cfg == 'H') cfg = 0;
+    if ((cfg == 'P' || cfg == 'Q') && !gemm256_ok(a)) cfg = 0;
+    if (!cfg) {
+        const PpPlan pp = pick_pp(a);
+        if (pp.use) return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
+        cfg = pick_lockstep<EPI, false>(a);
+        // with half the LDS-DMA bytes per FLOP the 128 x 128 tile (two workgroups per CU) beats the 256 x 128 tile wherever the
+        // bf16 rules pick the latter (profiles/r04_fp8_gemm_time_*.log: UNet qkv 17.7 vs 18.6 us, GEGLU 50.8 vs 53.2, ViT qkv 17.5 vs 20.1)
+        if (cfg == 'C') cfg = 'B';
+    }
+    switch (cfg) {
+        case 'Q': return launch_gemm256(a, s, -1, 1);
+        case 'P': {
+            const PpPlan pp = plan_pp(a);
+            return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
+        }
+        case 'S': {
+            const int tc = tiles_of(a, 256, 128);
+            const int ksplit = tc < 256 ? pick_ksplit<EPI>(a, tc, 256 * 128, g_force_cfg ? 4 : 24) : 0;
+            if (ksplit) launch_cfg<EPI, false, CfgC, true>(a, s, 0, ksplit);
+            else launch_cfg<EPI, false, CfgC, true>(a, s);
+            break;
+        }
+        case 'C': launch_cfg<EPI, false, CfgC, true>(a, s); break;
+        case 'K': launch_cfg<EPI, false, CfgK, true>(a, s); break;
+        default:  launch_cfg<EPI, false, CfgB, true>(a, s); break;
+    }
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
+
+static int launch_gemm_fp8_impl(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
-    if (a.M < 1 || a.N < 1 || !a.a_scale || !a.w_scale || (a.lda & 15) || (a.ldw & 15) || a.conv.mode != CONV_NONE) return -22;
+    if (a.M < 1 || a.N < 1 || !a.a_scale || !a.w_scale || (a.K & 127) || (a.lda & 15) || (a.ldw & 15) || a.conv.mode != CONV_NONE) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
-    if (!gemm256_ok(a)) return -22;
+    if (gemm_fx(a) || a.bias2) return -22;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
-    const PpPlan pp = plan_pp(a);
-    return pp.ksplit > 1 ? launch_gemm256(a, s, pp.full_tiles, pp.ksplit) : launch_gemm256(a, s, -1, 1);
+    a.slice_rr = (g_tune >> 1) & 1;
+    switch (a.epi) {
+        case EPI_NONE:   return launch_fp8_v2<EPI_NONE>(a, s);
+        case EPI_RESID:  return launch_fp8_v2<EPI_RESID>(a, s);
+        case EPI_SWIGLU: return launch_fp8_v2<EPI_SWIGLU>(a, s);
+        case EPI_GELU:   return launch_fp8_v2<EPI_GELU>(a, s);
+        case EPI_GEGLU:  return launch_fp8_v2<EPI_GEGLU>(a, s);
+        default: return -22;
+    }
+}
+int launch_gemm_fp8(const GemmArgs& a, hipStream_t s) {
+    if (!emu_prof_on()) return launch_gemm_fp8_impl(a, s);
+    emu_prof_begin(s);
+    const int st = launch_gemm_fp8_impl(a, s);
+    emu_prof_end(s, "gemm_fp8", a.M, a.N, a.K, a.epi, 2.0 * a.M * a.N * a.K);
+    return st;
 }
 
 static int launch_gemm_impl(const GemmArgs& a, hipStream_t s);

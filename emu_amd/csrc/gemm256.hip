@@ -31,7 +31,7 @@
 // Ragged M ("extension"): prompts are 256*j + a few rows (770 = 3*256 + 2 text+image tokens, the ViT's 1025 = 4*256 + cls),
 // and a fourth / fifth row of tiles for 2 rows would cost a quarter of the GEMM.  When 0 < M mod 256 <= 32 the last row
 // of tiles carries the remainder itself: one more 1 KiB piece per wave per k tile (unit QX, 64 LDS rows), one more
-// accumulator per wave (its wc-th weight fragment x the remainder rows) and 4 more MFMAs per k tile (+12.5 %).  The
+// accumulator per wave (its wc-th weight fragment x the remainder rows) and 4 more MFMAs per k tile (+12.5 %; fp8 operands: 2).  The
 // remainder fragments are read in the middle of phase B's MFMA segment into the registers of the weight half that
 // the wave has finished with (the half order depends on wc), so the extension costs 16 registers, not 32.  QX of tile
 // t+1 is staged first in B(t)'s group, waited for in A(t+1) and read in B(t+1).  Plain GEMM only (conv M is a
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const int b = blockIdx.x;
     int ext_rows;
     constexpr uint32_t ESZ = F8 ? 1u : 2u;                          // bytes per element
-    const int tiles_m = pp_tiles_m(a.M, !CONV && !F8, ext_rows);
+    const int tiles_m = pp_tiles_m(a.M, !CONV, ext_rows);
     auto xcd_order = [](int i, int n) {                              // i-th block of n -> its place in the logical order
         const int xcd = i & 7, q8 = n >> 3, r8 = n & 7;
         return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (i >> 3);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
     // this workgroup also owns rows m0 + 256 .. M - 1 (never with the fused epilogues: gemm256_ok refuses that combination)
-    const bool ext = !CONV && !F8 && FX == 0 && ext_rows > 0 && tm == tiles_m - 1;
+    const bool ext = !CONV && FX == 0 && ext_rows > 0 && tm == tiles_m - 1;
 
     // ---- LDS-DMA sources.  Instruction i (0, 1) of a unit fills LDS rows r = i*64 + srow, srow = wave*8 + lane/8, slot
     // lane%8 <- global chunk slot ^ ((r >> 1) & 7).  P unit s: row r holds weight row n0 + (r >> 6)*128 + s*64 + (r & 63);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     auto stage_x = [&](auto bc, int tau) {
         constexpr int BF = decltype(bc)::value;
         if constexpr (!CONV)
-            dma(rA, vQ, ((kt0 + tau) << 7) + (256 - 32 * (wave >> 2)) * a.lda * 2, smem + 2 * BUFB + BF * QXB + wave * 1024);
+            dma(rA, vQ, ((kt0 + tau) << 7) + (256 - 32 * (wave >> 2)) * a.lda * (int)ESZ, smem + 2 * BUFB + BF * QXB + wave * 1024);
     };
 
     // ---- fragment reads: lane (l31, hi) reads row base + l31, chunk (2*kk + hi) ^ swizzle(row), swizzle = (l31 >> 1) & 7
@@ -278,8 +278,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     };
     auto mma_x = [&](auto xc, auto ic) {               // remainder rows x this wave's wc-th weight fragment
         constexpr int X = decltype(xc)::value, I = decltype(ic)::value;
+        if constexpr (!F8) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pg[X][I][kk], qxf[kk], accx, 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pg[X][I][kk], qxf[kk], accx, 0, 0, 0);
+        } else {
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            auto op = [](const bf16x8_t& lo, const bf16x8_t& hi_) {
+                return __builtin_shufflevector(__builtin_bit_cast(v4i_t, lo), __builtin_bit_cast(v4i_t, hi_), 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                accx = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(op(pg[X][I][2 * st], pg[X][I][2 * st + 1]), op(qxf[2 * st], qxf[2 * st + 1]),
+                                                                      accx, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
     };
 
     auto tile = [&](auto bc, int t) {
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 template <int EPI, int FX = 0>
 __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
     int ext_rows;
-    const int tiles_m = pp_tiles_m(a.M, a.conv.mode == CONV_NONE && !a.a_scale, ext_rows);
+    const int tiles_m = pp_tiles_m(a.M, a.conv.mode == CONV_NONE, ext_rows);
     const int wg = a.full_tiles + blockIdx.x;
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
@@ -600,7 +611,7 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
 
 int gemm256_tiles(const GemmArgs& a) {
     int ext_rows;
-    return pp_tiles_m(a.M, a.conv.mode == CONV_NONE && !a.a_scale, ext_rows) * ((a.N + 255) / 256);
+    return pp_tiles_m(a.M, a.conv.mode == CONV_NONE, ext_rows) * ((a.N + 255) / 256);
 }
 
 // operand extents the 32-bit descriptor offsets can address, k tiles of 64

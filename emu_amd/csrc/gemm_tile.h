@@ -385,6 +385,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
                 const f32x4_t t = *reinterpret_cast<const f32x4_t*>(base + (size_t)ks * (BMv * BNv) + (size_t)lm * BNv + lq * 4);
                 v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
             }
+            if (a.a_scale) {                           // fp8 operands: the per-row scales of both multiply the summed slices
+                const float sa = a.a_scale[m];
+                for (int e = 0; e < 4; ++e) v[e] *= sa * a.w_scale[nb + e < a.N ? nb + e : a.N - 1];
+            }
             QuadIn qi;
             quad_load_cols<EPI, FX>(a, nb, qi);
             quad_load_row<EPI>(a, m, nb, qi);

@@ -135,6 +135,9 @@ int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int co
 // y = (res ? res : 0) + LayerNorm(x) * w + b       (ViT post-norm residual, eva_vit.py:298-300)
 int launch_layernorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* res, bf16_t* y,
                      int rows, int cols, float eps, hipStream_t s);
+// the same + per-row e4m3 quantisation of the bf16 result in one pass (cols <= 2048; y may be null): q [rows, cols] bytes, scale [rows]
+int launch_layernorm_q8(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* res, bf16_t* y, uint8_t* q, float* scale,
+                        int rows, int cols, float eps, hipStream_t s);
 int launch_embed_gather(const int32_t* ids, const bf16_t* table, bf16_t* out, int n_tok, int hidden, int vocab, hipStream_t s);
 // out[dst_rows[i], :] = src[i, :]
 int launch_scatter_rows(const bf16_t* src, const int32_t* dst_rows, bf16_t* out, int n_rows, int hidden, hipStream_t s);

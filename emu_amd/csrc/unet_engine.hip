@@ -39,9 +39,15 @@ struct LnW {                        // a LayerNorm folded into its consumer GEMM
     const float *c = nullptr, *d = nullptr;
     bool ok() const { return w && c && d; }
 };
+struct W8 {                         // optional e4m3 copy of a packed matrix: bytes [N, K] + one fp32 scale per output row
+    const uint8_t* q = nullptr;
+    const float* s = nullptr;
+    bool ok() const { return q && s; }
+};
 struct TBlock {
     const bf16_t *ln1g, *ln1b, *qkv, *o1w, *o1b, *ln2g, *ln2b, *q2, *kv2, *o2w, *o2b, *ln3g, *ln3b, *ggw, *ggb, *ffw, *ffb;
     LnW qkv_ln, q2_ln, gg_ln;       // optional packed tensors of the fused-LayerNorm path
+    W8 qkv8, o1_8, q2_8, o2_8, gg8, ff8;   // emu_unet_use_fp8: the six matrices of the block as fp8 operands
     size_t ctx_off;                 // element offset of this block's {K|V rows, Vt} in the context cache
 };
 struct Transformer {
@@ -63,6 +69,7 @@ struct emu_unet {
     int fusion = 0;                     // bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv epilogue,
                                         // bit 2: cross-attention inside the attn2 to_q epilogue
     int fusion_avail = 0;               // what the registered tensors allow (set by emu_unet_finalize)
+    bool fp8 = false;                   // emu_unet_use_fp8: the transformer blocks' GEMMs W8A8 (takes precedence over `fusion`)
     // resolved structure
     const bf16_t *conv_in_w, *conv_in_b, *te1w, *te1b, *te2w, *te2b, *ae1w, *ae1b, *ae2w, *ae2b, *tpw, *tpb;
     const bf16_t *cno_g, *cno_b, *cout_w, *cout_b;
@@ -141,6 +148,8 @@ struct Ws {
     bf16_t *colin, *hA, *hB, *cat, *gn, *t1, *sc, *tokA, *tokB, *ln, *qkv, *vt, *att, *q2, *ff;
     bf16_t* skip[12];
     bf16_t *temb_in, *e1, *emb, *semb, *temb_all, *add1;
+    uint8_t* x8;            // emu_unet_use_fp8: the current GEMM's activation rows as e4m3 bytes ...
+    float* xs;              // ... and their per-row scales
     float* lnstats;         // per-row partial (sum, sum of squares) of the transformer stream, one pair per 128-column slot
     float* gnws;
     float* splitk;          // fp32 K-slices of the split-K GEMMs / convs of the lowest-resolution level
@@ -190,6 +199,8 @@ Ws plan_ws(const emu_unet* u, int H, int W, void* base) {
     w.temb_in = (bf16_t*)take(Bn * c.ch[0]); w.e1 = (bf16_t*)take(Bn * c.temb_dim); w.emb = (bf16_t*)take(Bn * c.temb_dim);
     w.semb = (bf16_t*)take(Bn * c.temb_dim); w.temb_all = (bf16_t*)take((size_t)Bn * u->temb_total);
     w.add1 = (bf16_t*)take(Bn * c.temb_dim);
+    w.x8 = (uint8_t*)take(u->fp8 ? max_ff : 0, 1);
+    w.xs = (float*)take(u->fp8 ? max_tok : 0, 4);       // (>= rows of any transformer level)
     w.lnstats = (float*)take(max_st, 4);
     w.gnws = (float*)take(gn_ws_floats(Bn, 2 * c.ch[2] > c.ch[1] + c.ch[0] ? 2 * c.ch[2] : c.ch[1] + c.ch[0], (int)hw[0]), 4);
     w.splitk_floats = EMU_SPLITK_SCRATCH_FLOATS;
@@ -233,6 +244,16 @@ int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, con
     return launch_gemm(g, s);
 }
 
+// epi(fp8 rows in w.x8 / w.xs  x  fp8 weights): launch_gemm_fp8 (emu_linear_fp8_bf16's kernels)
+int gemm8(emu_unet* u, const Ws& w, const W8& W, const bf16_t* bias, const bf16_t* res, bf16_t* C, int M, int N, int K, int ldres,
+          int ldc, int epi, hipStream_t s) {
+    GemmArgs g{reinterpret_cast<const bf16_t*>(w.x8), reinterpret_cast<const bf16_t*>(W.q), bias, res, C, M, N, K, K, K, ldres, ldc, epi,
+               NOCONV, nullptr, 0, 0};
+    g.a_scale = w.xs; g.w_scale = W.s;
+    g.partial = u->splitk; g.partial_floats = u->splitk_floats;
+    return launch_gemm_fp8(g, s);
+}
+
 int conv3(emu_unet* u, const bf16_t* x, const bf16_t* Wt, const bf16_t* bias, const bf16_t* bias2, int ldb2, const bf16_t* res,
           bf16_t* y, int Bn, int Hin, int Win, int Cin, int Cout, int mode, hipStream_t s) {
     int Ho = Hin, Wo = Win;
@@ -267,9 +288,15 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     // stream (proj_in, attn1 / attn2 out-projection, ff-out) emits per-row partial sums from its epilogue, the consumer (qkv,
     // attn2 q, GEGLU) multiplies the un-normalised rows by W * gamma and corrects with mean / rstd in its epilogue -- and the qkv
     // projection writes V^T itself.  M <= 8 (toy latents) stays on the unfused GEMV path.
-    const bool fln = (u->fusion & 1) && M > 8 && (C & 127) == 0;     // statistics slots are 128 columns wide
-    const bool fvt = (u->fusion & 2) && M > 8 && HW == hwpad;
-    const bool fca = (u->fusion & 4) && M > 8 && HW == hwpad && n <= 64;     // rows of one tile within one batch element
+    // W8A8 mode (emu_unet_use_fp8; not a reference feature): the six GEMMs of a block take fp8 operands.  The three LayerNorms
+    // run as launches again -- they hold whole rows, so their output leaves as the consumer's fp8 operand with its per-row scale
+    // for free (launch_layernorm_q8) -- the attention outputs and the GEGLU product are quantised by a launch of their own
+    // (their rows are spread over the workgroups of the producing kernel), V^T and the cross-attention are the separate launches
+    // of the unfused sequence.  proj_in / proj_out, the convs and everything outside the transformer blocks stay bf16.
+    const bool f8 = u->fp8 && M > 8 && (C & 127) == 0 && C <= 2048;
+    const bool fln = !f8 && (u->fusion & 1) && M > 8 && (C & 127) == 0;     // statistics slots are 128 columns wide
+    const bool fvt = !f8 && (u->fusion & 2) && M > 8 && HW == hwpad;
+    const bool fca = !f8 && (u->fusion & 4) && M > 8 && HW == hwpad && n <= 64;     // rows of one tile within one batch element
     float* st = w.lnstats;
     UTRY(launch_groupnorm(x, t.gng, t.gnb, w.gn, w.gnws, Bn, HW, C, u->cfg.groups, 1e-6f, 0, s));
     { Fx fx; fx.stats_out = fln ? st : nullptr;
@@ -277,6 +304,32 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     bf16_t *a = w.tokA, *b = w.tokB;
     for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
         const TBlock& tb = t.blocks[bi];
+        if (f8) {
+            UTRY(launch_layernorm_q8(a, tb.ln1g, tb.ln1b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));
+            UTRY(gemm8(u, w, tb.qkv8, nullptr, nullptr, w.qkv, M, 3 * C, C, 0, 3 * C, EPI_NONE, s));
+            { TransposeVArgs tv{w.qkv + 2 * C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt, Bn, t.heads, HW, D, hwpad};
+              UTRY(launch_transpose_v(tv, s)); }
+            { FlashArgs f{w.qkv, (long)HW * 3 * C, (long)D, (long)3 * C, w.qkv + C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt,
+                          w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, HW, hwpad, D, 0, scale};
+              UTRY(launch_flash_attn(f, s)); }
+            UTRY(launch_quant_fp8_rows(w.att, C, w.x8, C, w.xs, M, C, s));
+            UTRY(gemm8(u, w, tb.o1_8, tb.o1b, a, b, M, C, C, C, C, EPI_RESID, s));
+            UTRY(launch_layernorm_q8(b, tb.ln2g, tb.ln2b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));
+            UTRY(gemm8(u, w, tb.q2_8, nullptr, nullptr, w.q2, M, C, C, 0, C, EPI_NONE, s));
+            { const bf16_t* kv = u->ctx_cache + tb.ctx_off;
+              const bf16_t* vt = kv + (size_t)Bn * n * 2 * C;
+              FlashArgs f{w.q2, (long)HW * C, (long)D, (long)C, kv, (long)n * 2 * C, (long)D, (long)2 * C, vt,
+                          w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, n, npad, D, 0, scale};
+              UTRY(launch_flash_attn(f, s)); }
+            UTRY(launch_quant_fp8_rows(w.att, C, w.x8, C, w.xs, M, C, s));
+            UTRY(gemm8(u, w, tb.o2_8, tb.o2b, b, a, M, C, C, C, C, EPI_RESID, s));
+            UTRY(launch_layernorm_q8(a, tb.ln3g, tb.ln3b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));
+            UTRY(gemm8(u, w, tb.gg8, tb.ggb, nullptr, w.ff, M, 8 * C, C, 0, 4 * C, EPI_GEGLU, s));
+            UTRY(launch_quant_fp8_rows(w.ff, 4 * C, w.x8, 4 * C, w.xs, M, 4 * C, s));
+            UTRY(gemm8(u, w, tb.ff8, tb.ffb, a, b, M, C, 4 * C, C, C, EPI_RESID, s));
+            std::swap(a, b);
+            continue;
+        }
         // self attention
         const bf16_t* lnx = a;
         if (!fln) { UTRY(launch_layernorm(a, tb.ln1g, tb.ln1b, nullptr, w.ln, M, C, 1e-5f, s)); lnx = w.ln; }
@@ -359,7 +412,40 @@ void emu_unet_destroy(emu_unet* u) { delete u; }
 int emu_unet_set_weight(emu_unet* u, const char* name, const void* ptr) {
     if (!u || !name || !ptr) return -22;
     u->w[name] = B16(ptr);
-    u->finalized = false;
+    const std::string nm(name);
+    const bool f8name = (nm.size() > 4 && nm.compare(nm.size() - 4, 4, ".fp8") == 0) || (nm.size() > 5 && nm.compare(nm.size() - 5, 5, ".fp8s") == 0);
+    if (!f8name) u->finalized = false;                  // (fp8 copies are resolved by emu_unet_use_fp8, not by finalize)
+    return 0;
+}
+
+// W8A8 mode of the transformer blocks: every block's six packed matrices must have been registered a second time as
+// "<name>.fp8" (e4m3 bytes of emu_quantize_fp8_rows) and "<name>.fp8s" (fp32 row scales) with emu_unet_set_weight.
+// Changes emu_unet_workspace_bytes; invalidates captured graphs of the step (the caller's business).
+int emu_unet_use_fp8(emu_unet* u, int enable) {
+    if (!u || !u->finalized) return -22;
+    if (!enable) { u->fp8 = false; return 0; }
+    bool ok = true;
+    auto w8 = [&](const std::string& base) {
+        W8 r;
+        r.q = reinterpret_cast<const uint8_t*>(find(u, base + ".fp8", true, &ok));
+        r.s = reinterpret_cast<const float*>(find(u, base + ".fp8s", true, &ok));
+        return r;
+    };
+    auto resolve = [&](Transformer& t) {
+        for (int k = 0; k < t.depth; ++k) {
+            const std::string b = t.name + "transformer_blocks." + std::to_string(k) + ".";
+            TBlock& tb = t.blocks[k];
+            tb.qkv8 = w8(b + "attn1.qkv.w"); tb.o1_8 = w8(b + "attn1.out.w"); tb.q2_8 = w8(b + "attn2.q.w");
+            tb.o2_8 = w8(b + "attn2.out.w"); tb.gg8 = w8(b + "ff.geglu.w"); tb.ff8 = w8(b + "ff.out.w");
+        }
+    };
+    for (int i = 0; i < 3; ++i) {
+        for (auto& t : u->down_tr[i]) resolve(t);
+        for (auto& t : u->up_tr[i]) resolve(t);
+    }
+    resolve(u->mid_tr);
+    if (!ok) return emu_ctx_fail(u->ctx, -2, u->err.c_str());
+    u->fp8 = true;
     return 0;
 }
 
@@ -428,6 +514,7 @@ int emu_unet_finalize(emu_unet* u) {
     u->temb_total = toff;
     if (!ok) return emu_ctx_fail(u->ctx, -2, u->err.c_str());
     u->fusion = u->fusion_avail;
+    u->fp8 = false;                                    // the blocks were re-resolved: emu_unet_use_fp8 again
     u->finalized = true;
     return 0;
 }

@@ -171,6 +171,20 @@ def layernorm(x, w, b, eps: float, res=None, out=None):
     return out
 
 
+def layernorm_q8(x, w, b, eps: float, res=None, want_y: bool = True):
+    """``layernorm`` + per-row e4m3 quantisation of its bf16 result in one launch (see emu_layernorm_q8_bf16):
+    returns (y or None, bytes uint8 [rows, cols], scale fp32 [rows])."""
+    _req(x, "x")
+    assert x.is_contiguous()
+    rows, cols = x.shape
+    y = torch.empty_like(x) if want_y else None
+    q = torch.empty(rows, cols, device=x.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib().emu_layernorm_q8_bf16(_p(x), _p(w), _p(b), _p(res), _p(y), _p(q), _p(sc), rows, cols, float(eps), stream(x)),
+          "emu_layernorm_q8_bf16")
+    return y, q, sc
+
+
 def embed_gather(ids, table, out=None):
     _req(ids, "ids", torch.int32); _req(table, "table")
     n = ids.numel()

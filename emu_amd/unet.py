@@ -205,6 +205,32 @@ class UNetEngine:
             check(r, "emu_unet_set_fusion", self.ctx.handle)
         return r
 
+    FP8_MATRICES = ("attn1.qkv.w", "attn1.out.w", "attn2.q.w", "attn2.out.w", "ff.geglu.w", "ff.out.w")
+
+    def quantize_fp8(self) -> None:
+        """Per-row-scaled e4m3fn copies of the six packed matrices of every transformer block (the bf16 set stays resident).
+        Not a reference feature (the reference is bf16 end to end); off unless ``use_fp8``."""
+        if not self.ready:
+            raise RuntimeError("quantize_fp8: load the weights first")
+        if getattr(self, "_fp8_done", False):
+            return
+        from . import ops
+        for name in [k for k in self._keep if ".transformer_blocks." in k and k.endswith(self.FP8_MATRICES)]:
+            q, sc = ops.quantize_fp8_rows(self._keep[name])
+            self._keep[name + ".fp8"], self._keep[name + ".fp8s"] = q, sc
+            check(lib().emu_unet_set_weight(self.handle, (name + ".fp8").encode(), q.data_ptr()), "emu_unet_set_weight")
+            check(lib().emu_unet_set_weight(self.handle, (name + ".fp8s").encode(), sc.data_ptr()), "emu_unet_set_weight")
+        self._fp8_done = True
+
+    def use_fp8(self, enable: bool = True) -> None:
+        """Run the transformer blocks' GEMMs W8A8 on the block-scaled fp8 MFMA (see emu_unet_use_fp8); invalidates a captured
+        hipGraph of the step."""
+        if enable:
+            self.quantize_fp8()
+        self._graph = None
+        check(lib().emu_unet_use_fp8(self.handle, 1 if enable else 0), "emu_unet_use_fp8", self.ctx.handle)
+        self.fp8 = bool(enable)
+
     @staticmethod
     def _conv(w: torch.Tensor) -> torch.Tensor:
         return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)             # [Cout, (ky, kx, ci)]

@@ -135,6 +135,36 @@ class VitEngine:
 
     __call__ = forward
 
+    # ------------------------------------------------------------------ optional W8A8 mode (BASELINE configs[4]: fp8 MFMA)
+    def quantize_fp8(self) -> None:
+        """Per-row-scaled e4m3fn copies of the four packed matrices of every block (the bf16 set stays resident: +4.3 GB for
+        EVA-CLIP-4B).  Not a reference feature (the reference is bf16 end to end); off unless ``use_fp8``."""
+        if not self.ready:
+            raise RuntimeError("quantize_fp8: load all weights first")
+        if getattr(self, "_fp8", None):
+            return
+        self._fp8 = {}
+        for i in range(self.cfg.layers):
+            a = []
+            for k in ("wqkv", "wproj", "fc1w", "fc2w"):
+                q, sc = ops.quantize_fp8_rows(self._keep[f"{i}.{k}"])
+                self._fp8[f"{i}.{k}"] = (q, sc)
+                a += [q.data_ptr(), sc.data_ptr()]
+            check(lib().emu_vit_set_block_fp8(self.handle, i, *a), "emu_vit_set_block_fp8", self.ctx.handle)
+
+    def use_fp8(self, enable: bool = True) -> None:
+        """Run the blocks' GEMMs W8A8 on the block-scaled fp8 MFMA (activation rows quantised per row ahead of every GEMM);
+        LayerNorm, attention and the patch embedding stay bf16."""
+        if enable:
+            self.quantize_fp8()
+        check(lib().emu_vit_use_fp8(self.handle, 1 if enable else 0), "emu_vit_use_fp8", self.ctx.handle)
+        self.fp8 = bool(enable)
+
+    def fp8_dequantized(self, key: str) -> torch.Tensor:
+        """fp32 value of a registered fp8 matrix, e.g. ``"3.fc1w"`` (tests: the checker runs on the exact weights the GEMMs use)."""
+        q, sc = self._fp8[key]
+        return q.view(torch.float8_e4m3fn).to(torch.float32) * sc[:, None]
+
     @torch.no_grad()
     def run_blocks(self, tokens: torch.Tensor, l0: int, l1: int) -> torch.Tensor:
         """Parity hook (include/emu_hip.h: emu_vit_blocks): blocks [l0, l1) on a COPY of tokens [B, 1+g*g, C] bf16."""

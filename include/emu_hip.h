@@ -168,6 +168,11 @@ int emu_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int cols, 
 /* nn.LayerNorm + post-norm residual (eva_vit.py:298-300): y = (res ? res + : ) bf16(LN(x) * w + b) */
 int emu_layernorm_bf16(const void* x, const void* w, const void* b, const void* res, void* y, int rows,
                        int cols, float eps, emu_stream_t s);
+/* The same in one pass with the per-row e4m3 quantisation of the bf16 result (emu_quantize_fp8_rows' definition: scale = amax / 448,
+ * 1 for a zero row), bit-identical to the two launches: q [rows, cols] bytes, scale [rows]; y may be null; cols <= 2048.  The
+ * LayerNorm in front of a GEMM of the W8A8 modes (emu_vit_use_fp8, emu_unet_use_fp8) hands over the GEMM's fp8 operand itself. */
+int emu_layernorm_q8_bf16(const void* x, const void* w, const void* b, const void* res, void* y, void* q, float* scale, int rows,
+                          int cols, float eps, emu_stream_t s);
 /* in-place row softmax x = bf16(softmax(x * scale [+ bias])) over [rows, cols] (row stride ld): materialised-score
  * attention for the VAE mid block (AutoencoderKL attention, 1 head of 512; Emu2/emu/diffusion.py:216) and, with the additive
  * bf16 bias [rows, cols] (relative-position bias + causal mask), T5Attention of Emu1's CausalFormer
@@ -330,6 +335,14 @@ int emu_vit_set_stem(emu_vit* m, const void* wpatch, const void* bpatch, const v
 int emu_vit_set_block(emu_vit* m, int layer, const void* wqkv, const void* bqkv, const void* wproj,
                       const void* bproj, const void* ln1w, const void* ln1b, const void* fc1w, const void* fc1b,
                       const void* fc2w, const void* fc2b, const void* ln2w, const void* ln2b);
+/* Optional W8A8 mode of the encoder blocks (not a reference feature -- the reference runs bf16 end to end; BASELINE.json
+ * configs[4] names an fp8 MFMA path): e4m3 copies of the four matrices of a block (emu_quantize_fp8_rows of the PACKED bf16
+ * matrices registered with emu_vit_set_block: bytes [N, K] + one fp32 scale per output row).  With emu_vit_use_fp8(m, 1) every
+ * GEMM of a block quantises its activation rows (per-row e4m3) and runs on emu_linear_fp8_bf16's kernels; LayerNorm, attention
+ * and the stem stay bf16.  width and mlp_hidden must be multiples of 128.  Registering changes emu_vit_workspace_bytes. */
+int emu_vit_set_block_fp8(emu_vit* m, int layer, const void* wqkv8, const float* sqkv, const void* wproj8, const float* sproj,
+                          const void* fc1w8, const float* sfc1, const void* fc2w8, const float* sfc2);
+int emu_vit_use_fp8(emu_vit* m, int enable);
 size_t emu_vit_workspace_bytes(const emu_vit* m, int B);
 /* image NCHW (fp32 or bf16) -> tokens [B, 1+g*g, C] bf16 (raw block output incl. cls, eva_vit.py:433-445) */
 int emu_vit_forward(emu_vit* m, const void* image, int image_is_f32, int B, void* out_tokens, void* workspace,
@@ -376,6 +389,14 @@ int emu_unet_finalize(emu_unet* u);                       /* -2 + emu_last_error
  * over the (<= 64) prompt tokens runs inside the attn2.to_q projection's epilogue (no q tensor, no attention launch).  0 = the
  * unfused launch sequence (A/B timing, parity of fused vs unfused).  Returns the mask in effect. */
 int emu_unet_set_fusion(emu_unet* u, int mask);
+/* Optional W8A8 mode of the transformer blocks (not a reference feature; BASELINE.json configs[4] names an fp8 MFMA path).
+ * Register every block's six packed matrices (attn1.qkv.w, attn1.out.w, attn2.q.w, attn2.out.w, ff.geglu.w, ff.out.w) a second
+ * time with emu_unet_set_weight as "<name>.fp8" (the e4m3 bytes of emu_quantize_fp8_rows) and "<name>.fp8s" (fp32 row
+ * scales), then emu_unet_use_fp8(u, 1): the blocks' GEMMs run on emu_linear_fp8_bf16's kernels, the three LayerNorms of a
+ * block emit the consumer's fp8 rows themselves, the attention outputs and the GEGLU product are quantised per row by a launch
+ * of their own; convs, GroupNorm, proj_in / proj_out, attention and the scheduler stay bf16.  Takes precedence over
+ * emu_unet_set_fusion; changes emu_unet_workspace_bytes; returns -2 when a copy is missing. */
+int emu_unet_use_fp8(emu_unet* u, int enable);
 int emu_unet_temb_total(const emu_unet* u);               /* rows of temb_proj_all (sum of resnet out channels) */
 size_t emu_unet_workspace_bytes(const emu_unet* u, int H, int W);
 size_t emu_unet_context_bytes(const emu_unet* u, int n_ctx);
