@@ -553,7 +553,6 @@ def main():
         sync(); t = time.perf_counter()
         hidden, kstart, next_pos = lm.prefill(x.view(1, S, -1), mask, s_max)
         sync(); prefill_ms = (time.perf_counter() - t) * 1e3
-        hidden_bf16 = hidden.clone()                       # the fp8 leg reports its distance from these rows
         # second timing of each (first call includes lazy code-object loads)
         sync(); t = time.perf_counter(); m.encode_image(img); sync(); vit_ms2 = (time.perf_counter() - t) * 1e3
         sync(); t = time.perf_counter(); hidden, kstart, next_pos = lm.prefill(x.view(1, S, -1), mask, s_max); sync()
@@ -645,8 +644,7 @@ def main():
             # prefill on the fp8 weight set: activations quantised per row ahead of every GEMM, block-scaled fp8 MFMA
             with torch.no_grad():
                 lm.use_fp8(True, prefill=True)
-                h8, _, _ = lm.prefill(x.view(1, S, -1), mask, s_max)
-                pf8_err = float((h8.float() - hidden_bf16.float()).norm() / hidden_bf16.float().norm())
+                lm.prefill(x.view(1, S, -1), mask, s_max)
                 sync(); t = time.perf_counter()
                 lm.prefill(x.view(1, S, -1), mask, s_max)
                 sync(); pf8 = time.perf_counter() - t
@@ -701,7 +699,7 @@ def main():
                    "weight_bytes_per_token_per_gpu": lm.weight_bytes_per_token(),
                    "gemv_achieved_GBps": wb.value / (ms.value * 1e-3) / 1e9, "gemv_frac_of_hbm_peak": wb.value / (ms.value * 1e-3) / HBM_PEAK,
                    "gemv_ms_per_token": ms.value / n_prof, "tokens_identical_to_bf16_prefix": agree,
-                   "prefill_ms": pf8 * 1e3, "prefill_rel_l2_vs_bf16_hidden": pf8_err, "vit_encode_fp8": vit8, "prefill_note": "S=%d prefill with W8A8 GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4 "
+                   "prefill_ms": pf8 * 1e3, "vit_encode_fp8": vit8, "prefill_note": "S=%d prefill with W8A8 GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4 "
                    "(per-row e4m3 scales on weights and activations), attention / norms / KV bf16" % S,
                    "note": "extra leg, not the headline metric (which stays bf16 like the reference)"}
         except Exception as e:

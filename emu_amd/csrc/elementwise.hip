@@ -240,17 +240,38 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ 
 }
 
 // per-row symmetric fp8 (OCP e4m3fn) quantisation of a packed bf16 weight: scale = amax / 448, q = rne_fp8(w / scale)
+// NV > 0: the row (K <= 2048 * NV elements) stays in registers between the amax pass and the conversion (one read of the row:
+// the activation rows of the W8A8 GEMMs -- 1025 x 15360 after the ViT's GELU, 2048 x 5120 after the UNet's GEGLU -- are
+// quantised on the critical path); NV = 0: any K, two passes (weight matrices at load time).  Same values either way.
+template <int NV>
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __restrict__ w, int ldw, uint8_t* __restrict__ q,
                                                              int ldq, float* __restrict__ scale, int K) {
     __shared__ float scratch[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     const bf16_t* src = w + (size_t)n * ldw;
+    const int nv = K >> 3;
     float amax = 0.f;
-    for (int vi = tid; vi < (K >> 3); vi += 256) {
-        float f[8];
-        unpack8(ld16(src + vi * 8), f);
+    u32x4 keep[NV > 0 ? NV : 1];
+    if constexpr (NV > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+        for (int i = 0; i < NV; ++i) {
+            const int vi = tid + i * 256;
+            keep[i] = vi < nv ? ld16(src + vi * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float f[8];
+            unpack8(keep[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+        }
+    } else {
+        for (int vi = tid; vi < nv; vi += 256) {
+            float f[8];
+            unpack8(ld16(src + vi * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+        }
     }
     amax = wave_max(amax);
     __syncthreads();
@@ -260,15 +281,24 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
     const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
     if (tid == 0) scale[n] = sc;
     uint8_t* dst = q + (size_t)n * ldq;
-    for (int vi = tid; vi < (K >> 3); vi += 256) {
+    auto put = [&](int vi, const u32x4& v) {
         float f[8];
-        unpack8(ld16(src + vi * 8), f);
+        unpack8(v, f);
         int lo = 0, hi = 0;
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] / sc, f[1] / sc, lo, false);
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] / sc, f[3] / sc, lo, true);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] / sc, f[5] / sc, hi, false);
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] / sc, f[7] / sc, hi, true);
         *reinterpret_cast<uint2*>(dst + vi * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    };
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = tid + i * 256;
+            if (vi < nv) put(vi, keep[i]);
+        }
+    } else {
+        for (int vi = tid; vi < nv; vi += 256) put(vi, ld16(src + vi * 8));
     }
 }
 
@@ -402,7 +432,10 @@ int launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16_t* 
 }
 int launch_quant_fp8_rows(const bf16_t* w, int ldw, uint8_t* q, int ldq, float* scale, int N, int K, hipStream_t s) {
     if (N < 1 || K < 8 || (K & 7) || (ldw & 7) || (ldq & 7)) return -22;
-    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, s, w, ldw, q, ldq, scale, K);
+    if (K <= 2048) hipLaunchKernelGGL(quant_fp8_rows_kernel<1>, dim3(N), dim3(256), 0, s, w, ldw, q, ldq, scale, K);
+    else if (K <= 8192) hipLaunchKernelGGL(quant_fp8_rows_kernel<4>, dim3(N), dim3(256), 0, s, w, ldw, q, ldq, scale, K);
+    else if (K <= 16384) hipLaunchKernelGGL(quant_fp8_rows_kernel<8>, dim3(N), dim3(256), 0, s, w, ldw, q, ldq, scale, K);
+    else hipLaunchKernelGGL(quant_fp8_rows_kernel<0>, dim3(N), dim3(256), 0, s, w, ldw, q, ldq, scale, K);
     EMU_CHECK_LAUNCH();
     return 0;
 }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Same-run A/B of the UNet denoise step under different launch-fusion masks (emu_unet_set_fusion): one engine, one set of
 weights, the variants alternated inside one process (box-to-box variance of the MFMA-bound legs is ~12 %, so only same-run
-comparisons are evidence).  A variant is a fusion mask, optionally followed by "t<N>" = emu_gemm_tune(N) (e.g. "3t1").
+comparisons are evidence).  A variant is a fusion mask, optionally followed by "t<N>" = emu_gemm_tune(N) (e.g. "3t1"), or
+"fp8" = the transformer blocks W8A8 (emu_unet_use_fp8).
 Usage: python tools/unet_ab.py [steps] [variant,variant,...] [rounds]"""
 import os, sys, time
 import torch
@@ -23,10 +24,16 @@ best = {}
 with torch.no_grad():
     for r in range(rounds):
         for m in masks:
-            fm, _, tn = m.partition("t")
             from emu_amd._lib import lib
-            lib().emu_gemm_tune(int(tn or 0))
-            got = eng.set_fusion(int(fm))
+            if m == "fp8":
+                lib().emu_gemm_tune(0)
+                eng.use_fp8(True)
+                got = "fp8"
+            else:
+                eng.use_fp8(False) if getattr(eng, "fp8", False) else None
+                fm, _, tn = m.partition("t")
+                lib().emu_gemm_tune(int(tn or 0))
+                got = eng.set_fusion(int(fm))
             eng.set_timesteps(50)
             eng.set_context(prompt, 1024, 1024)
             lat = lat0.clone()
