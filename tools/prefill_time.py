@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Time the LLaMA-33B prefill alone (synthetic weights of the true shape): python tools/prefill_time.py [S] [reps]"""
+"""Time the LLaMA-33B prefill alone (synthetic weights of the true shape): python tools/prefill_time.py [S] [reps] [--graph]
+(--graph: the same call replayed from a hipGraph: what the eager launches of ~900 kernels cost beyond their kernel time)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,20 +8,30 @@ from emu_amd import synth
 from emu_amd.conf.emu_conf import LlamaCfg
 from emu_amd.llama import EmuHipContext, LlamaEngine
 
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 770
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+graph = "--graph" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--graph"]
+S = int(argv[0]) if len(argv) > 0 else 770
+reps = int(argv[1]) if len(argv) > 1 else 5
 dev = torch.device("cuda", 0)
 l = LlamaCfg()
 V = 32274
 eng = LlamaEngine(l, V, EmuHipContext(dev))
 eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device=dev, dtype=torch.bfloat16))
 x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
-mask = torch.ones(1, S, dtype=torch.long)
+mask = torch.ones(1, S, dtype=torch.long, device=dev)
 ts = []
 with torch.no_grad():
+    cap = eng.kv_capacity(S + 64)
+    run = lambda: eng.prefill(x, mask, cap)
+    if graph:
+        run(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = eng.prefill(x, mask, cap)
+        run = g.replay
     for i in range(reps + 2):
         torch.cuda.synchronize(); t = time.perf_counter()
-        eng.prefill(x, mask, eng.kv_capacity(S + 64))
+        run()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t) * 1e3)
-print(f"prefill S={S}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [{os.environ.get('EMU_TMP_FORCE', '')}]", flush=True)
+print(f"prefill S={S}{' (hipGraph replay)' if graph else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [{os.environ.get('EMU_TMP_FORCE', '')}]", flush=True)

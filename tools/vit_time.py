@@ -9,7 +9,8 @@ from emu_amd.llama import EmuHipContext
 from emu_amd.vit import VitEngine
 
 fp8 = "--fp8" in sys.argv
-args = [x for x in sys.argv[1:] if x != "--fp8"]
+graph = "--graph" in sys.argv                    # replay the encode from a hipGraph (what VitEngine.forward does for repeated shapes)
+args = [x for x in sys.argv[1:] if x not in ("--fp8", "--graph")]
 reps = int(args[0]) if args else 8
 dev = torch.device("cuda", 0)
 v = CLIPVisionCfg(n_query=256, v_query=64)
@@ -20,9 +21,16 @@ if fp8:
     eng.use_fp8(True)
 ts = []
 with torch.no_grad():
+    run = lambda: eng.forward(img)
+    if graph:
+        eng.forward(img); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = eng.forward(img)
+        run = g.replay
     for i in range(reps + 2):
         torch.cuda.synchronize(); t = time.perf_counter()
-        eng.forward(img)
+        run()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t) * 1e3)
-print(f"vit encode{' (W8A8 blocks)' if fp8 else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [{os.environ.get('EMU_TMP_FORCE', '')}]", flush=True)
+print(f"vit encode{' (W8A8 blocks)' if fp8 else ''}{' (hipGraph replay)' if graph else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [{os.environ.get('EMU_TMP_FORCE', '')}]", flush=True)
