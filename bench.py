@@ -776,16 +776,17 @@ def main():
         traffic_src = f"no PMC pass available ({type(e).__name__})"
 
     prefill_traffic, prefill_traffic_src = None, "no PMC pass over the GEMM sources committed"
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_prefill_gemm_pmc_traffic.json")))
+    for rnd in ("r04", "r03"):                               # the newest committed pass whose kernel sources are these
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_prefill_gemm_pmc_traffic.json")))
+        except Exception:
+            continue
         if pm.get("source_sha256") == gemm_source_hash():
             prefill_traffic = float(pm["traffic_over_algorithmic"]) * prefill_gemm_bytes(lcfg, S)
-            prefill_traffic_src = ("profiles/r03_prefill_gemm_pmc_traffic.json (same kernel sources, sha256 checked): traffic / algorithmic GEMM bytes = "
-                                   f"{float(pm['traffic_over_algorithmic']):.3f}")
-        else:
-            prefill_traffic_src = "profiles/r03_prefill_gemm_pmc_traffic.json is STALE (other kernel sources): traffic not reported"
-    except Exception:
-        pass
+            prefill_traffic_src = (f"profiles/{rnd}_prefill_gemm_pmc_traffic.json (same kernel sources, sha256 checked): traffic / algorithmic GEMM "
+                                   f"bytes = {float(pm['traffic_over_algorithmic']):.3f}")
+            break
+        prefill_traffic_src = f"profiles/{rnd}_prefill_gemm_pmc_traffic.json is STALE (other kernel sources): traffic not reported"
     if rank == 0:
         prefill_flops = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
                                                    + 2 * S * S * lcfg.hidden_size)
