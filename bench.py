@@ -663,8 +663,9 @@ def main():
                         m.visual.use_fp8(False)
                     sync(); t = time.perf_counter(); m.visual(img); sync()
                     vit8["bf16_ms_same_call"] = (time.perf_counter() - t) * 1e3
-                    vit8["note"] = ("64 EVA-CLIP-4B blocks with W8A8 GEMMs (per-row e4m3 on weights and activation rows, quantise "
-                                    "launch ahead of every GEMM), LayerNorm / attention / stem bf16; random-init weights: the distance "
+                    vit8["note"] = ("64 EVA-CLIP-4B blocks with W8A8 GEMMs (per-row e4m3 on weights and activation rows: the LayerNorms emit "
+                                    "their rows as fp8, the attention output and the GELU product are quantised by a launch each), "
+                                    "LayerNorm / attention / stem arithmetic bf16; random-init weights: the distance "
                                     "is what per-row e4m3 costs on unstructured matrices, not a quality claim")
             out8 = torch.zeros(total + 1, 1, device=dev, dtype=torch.int32)
             out8[0] = cur
