@@ -55,10 +55,12 @@ struct TileCfg {
 // so staging, swizzle and ring are untouched; a k-step is 64 elements (32 bytes per lane: chunks 4 st + 2 hi, + 1) on the
 // block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 rate: the same MFMA time per k tile for
 // twice the K, half the LDS-DMA bytes per FLOP -- the resource that bounds these tiles), and the per-row scales of the two
-// operands (a_scale[m] * w_scale[n]) multiply the fp32 sums ahead of the epilogue.  Plain GEMM, no fused-LayerNorm features.
+// operands (a_scale[m] * w_scale[n]) multiply the fp32 sums ahead of the epilogue.  Plain GEMM; of the fused epilogues the two that
+// only look at the finished sums -- V^T stores and the cross-attention -- are available, the LayerNorm fold is not (it needs the
+// un-normalised rows as the operand, and those quantise badly).
 template <int EPI, bool CONV, class T, int FX = 0, bool F8 = false>
 __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmArgs a) {
-    static_assert(!F8 || (!CONV && FX == 0), "fp8 operands: plain GEMM only");
+    static_assert(!F8 || (!CONV && (FX & (FX_LN | FX_STATS)) == 0), "fp8 operands: plain GEMM, V^T / cross-attention epilogues only");
     constexpr int KSH = F8 ? 1 : 0;                     // element offsets -> 2-byte units of the bf16_t pointers below
     constexpr int NW = T::WN * T::WM * T::KG;           // waves per workgroup
     constexpr int RED_BYTES = T::KG > 1 ? T::WN * T::WM * T::NF * T::MF * 16 * 64 * 4 : 0;
@@ -675,7 +677,19 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
     }
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
-    if constexpr (F8) {                                 // launch_gemm_fp8: no fused-LayerNorm features
+    if constexpr (F8) {                                 // launch_gemm_fp8: V^T / cross-attention epilogues only (EPI_NONE, unsliced)
+        if constexpr (EPI == EPI_NONE) {
+            if (fx == FX_VT && tail == 0) {
+                hipLaunchKernelGGL((gemm2_kernel<EPI, false, T, FX_VT, true>), dim3(b.full_tiles), dim3(T::THREADS), 0, s, b);
+                return;
+            }
+            if constexpr (T::MF == 1 && T::NF == 2 && T::KG == 2) {
+                if (fx == FX_CROSS && tail == 0) {
+                    hipLaunchKernelGGL((gemm2_kernel<EPI, false, T, FX_CROSS, true>), dim3(b.full_tiles), dim3(T::THREADS), 0, s, b);
+                    return;
+                }
+            }
+        }
         hipLaunchKernelGGL((gemm2_kernel<EPI, false, T, 0, true>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
         if (tail > 0)
             hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
@@ -896,6 +910,22 @@ int emu_gemm_tune_get() { return g_tune; }
 // fp8 x fp8 -> bf16: the 256x256 ping-pong tile where the bf16 rules would take it, else the lock-step tiles' fp8 form
 template <int EPI>
 static int launch_fp8_v2(const GemmArgs& a, hipStream_t s) {
+    if (a.cross_k) {                                   // the cross-attention epilogue lives on the 128 x 64 tile
+        if constexpr (EPI == EPI_NONE) { launch_cfg<EPI, false, CfgK, true>(a, s); EMU_CHECK_LAUNCH(); return 0; }
+        return -22;
+    }
+    if (a.vt_out) {                                    // V^T epilogue: the lock-step tiles, unsliced
+        if constexpr (EPI == EPI_NONE) {
+            int c = g_force_cfg ? g_force_cfg : pick_lockstep<EPI, false>(a);
+            if (c == 'C' && !g_force_cfg) c = 'B';
+            if (c == 'K') launch_cfg<EPI, false, CfgK, true>(a, s);
+            else if (c == 'C') launch_cfg<EPI, false, CfgC, true>(a, s);
+            else launch_cfg<EPI, false, CfgB, true>(a, s);
+            EMU_CHECK_LAUNCH();
+            return 0;
+        }
+        return -22;
+    }
     int cfg = g_force_cfg;
     if (cfg == 'H') cfg = 0;
     if ((cfg == 'P' || cfg == 'Q') && !gemm256_ok(a)) cfg = 0;
@@ -932,7 +962,13 @@ static int launch_gemm_fp8_impl(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     if (a.M < 1 || a.N < 1 || !a.a_scale || !a.w_scale || (a.K & 127) || (a.lda & 15) || (a.ldw & 15) || a.conv.mode != CONV_NONE) return -22;
     if ((a.epi == EPI_SWIGLU || a.epi == EPI_GEGLU) && ((a.N & 1) || (a.ldc & 1))) return -22;
-    if (gemm_fx(a) || a.bias2) return -22;
+    const int fx = gemm_fx(a);
+    if ((fx != 0 && fx != FX_VT && fx != FX_CROSS) || a.bias2) return -22;
+    if (a.vt_out && (a.epi != EPI_NONE || (a.vt_col0 & 63) || ((a.N - a.vt_col0) & 63) || a.vt_col0 < 0 || a.vt_col0 >= a.N || a.vt_s < 1 ||
+                     a.M % a.vt_s || a.vt_spad < a.vt_s || (a.ldc & 3))) return -22;
+    if (a.cross_k && (!a.cross_vt || a.epi != EPI_NONE || a.bias || (a.N & 63) || (a.ldc & 3) || a.cross_n < 1 || a.cross_n > 64 ||
+                      a.cross_npad < 64 || a.cross_rows < 64 || (a.cross_rows & 63) || a.M % a.cross_rows || (a.cross_ldk & 3) ||
+                      (a.cross_npad & 3))) return -22;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
     a.slice_rr = (g_tune >> 1) & 1;
     switch (a.epi) {

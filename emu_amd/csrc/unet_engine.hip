@@ -69,7 +69,7 @@ struct emu_unet {
     int fusion = 0;                     // bit 0: LayerNorm folded into the consumer GEMMs, bit 1: V^T from the qkv epilogue,
                                         // bit 2: cross-attention inside the attn2 to_q epilogue
     int fusion_avail = 0;               // what the registered tensors allow (set by emu_unet_finalize)
-    bool fp8 = false;                   // emu_unet_use_fp8: the transformer blocks' GEMMs W8A8 (takes precedence over `fusion`)
+    bool fp8 = false;                   // emu_unet_use_fp8: the transformer blocks' GEMMs W8A8 (fusion bit 0 has no fp8 form)
     // resolved structure
     const bf16_t *conv_in_w, *conv_in_b, *te1w, *te1b, *te2w, *te2b, *ae1w, *ae1b, *ae2w, *ae2b, *tpw, *tpb;
     const bf16_t *cno_g, *cno_b, *cout_w, *cout_b;
@@ -245,12 +245,18 @@ int gemm(emu_unet* u, const bf16_t* A, const bf16_t* Wt, const bf16_t* bias, con
 }
 
 // epi(fp8 rows in w.x8 / w.xs  x  fp8 weights): launch_gemm_fp8 (emu_linear_fp8_bf16's kernels)
+// (of the fused epilogues the V^T stores and the cross-attention are available with fp8 operands: Fx::vt / Fx::cross_*)
 int gemm8(emu_unet* u, const Ws& w, const W8& W, const bf16_t* bias, const bf16_t* res, bf16_t* C, int M, int N, int K, int ldres,
-          int ldc, int epi, hipStream_t s) {
+          int ldc, int epi, hipStream_t s, const Fx* fx = nullptr) {
     GemmArgs g{reinterpret_cast<const bf16_t*>(w.x8), reinterpret_cast<const bf16_t*>(W.q), bias, res, C, M, N, K, K, K, ldres, ldc, epi,
                NOCONV, nullptr, 0, 0};
     g.a_scale = w.xs; g.w_scale = W.s;
     g.partial = u->splitk; g.partial_floats = u->splitk_floats;
+    if (fx) {
+        g.vt_out = fx->vt; g.vt_col0 = fx->vt_col0; g.vt_s = fx->vt_s; g.vt_spad = fx->vt_spad;
+        g.cross_k = fx->cross_k; g.cross_vt = fx->cross_vt; g.cross_ldk = fx->cross_ldk; g.cross_n = fx->cross_n;
+        g.cross_npad = fx->cross_npad; g.cross_rows = fx->cross_rows; g.cross_scale = fx->cross_scale;
+    }
     return launch_gemm_fp8(g, s);
 }
 
@@ -291,9 +297,12 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     // W8A8 mode (emu_unet_use_fp8; not a reference feature): the six GEMMs of a block take fp8 operands.  The three LayerNorms
     // run as launches again -- they hold whole rows, so their output leaves as the consumer's fp8 operand with its per-row scale
     // for free (launch_layernorm_q8) -- the attention outputs and the GEGLU product are quantised by a launch of their own
-    // (their rows are spread over the workgroups of the producing kernel), V^T and the cross-attention are the separate launches
-    // of the unfused sequence.  proj_in / proj_out, the convs and everything outside the transformer blocks stay bf16.
+    // (their rows are spread over the workgroups of the producing kernel); the V^T stores of the qkv projection and the
+    // cross-attention inside the to_q epilogue (fusion bits 1, 2) work on finished sums and stay available.  proj_in / proj_out,
+    // the convs and everything outside the transformer blocks stay bf16.
     const bool f8 = u->fp8 && M > 8 && (C & 127) == 0 && C <= 2048;
+    const bool fvt8 = f8 && (u->fusion & 2) && HW == hwpad;
+    const bool fca8 = f8 && (u->fusion & 4) && HW == hwpad && n <= 64;
     const bool fln = !f8 && (u->fusion & 1) && M > 8 && (C & 127) == 0;     // statistics slots are 128 columns wide
     const bool fvt = !f8 && (u->fusion & 2) && M > 8 && HW == hwpad;
     const bool fca = !f8 && (u->fusion & 4) && M > 8 && HW == hwpad && n <= 64;     // rows of one tile within one batch element
@@ -306,21 +315,32 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
         const TBlock& tb = t.blocks[bi];
         if (f8) {
             UTRY(launch_layernorm_q8(a, tb.ln1g, tb.ln1b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));
-            UTRY(gemm8(u, w, tb.qkv8, nullptr, nullptr, w.qkv, M, 3 * C, C, 0, 3 * C, EPI_NONE, s));
-            { TransposeVArgs tv{w.qkv + 2 * C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt, Bn, t.heads, HW, D, hwpad};
-              UTRY(launch_transpose_v(tv, s)); }
+            { Fx fx;
+              if (fvt8) { fx.vt = w.vt; fx.vt_col0 = 2 * C; fx.vt_s = HW; fx.vt_spad = hwpad; }
+              UTRY(gemm8(u, w, tb.qkv8, nullptr, nullptr, w.qkv, M, 3 * C, C, 0, 3 * C, EPI_NONE, s, fvt8 ? &fx : nullptr)); }
+            if (!fvt8) {
+                TransposeVArgs tv{w.qkv + 2 * C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt, Bn, t.heads, HW, D, hwpad};
+                UTRY(launch_transpose_v(tv, s));
+            }
             { FlashArgs f{w.qkv, (long)HW * 3 * C, (long)D, (long)3 * C, w.qkv + C, (long)HW * 3 * C, (long)D, (long)3 * C, w.vt,
                           w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, HW, hwpad, D, 0, scale};
               UTRY(launch_flash_attn(f, s)); }
             UTRY(launch_quant_fp8_rows(w.att, C, w.x8, C, w.xs, M, C, s));
             UTRY(gemm8(u, w, tb.o1_8, tb.o1b, a, b, M, C, C, C, C, EPI_RESID, s));
             UTRY(launch_layernorm_q8(b, tb.ln2g, tb.ln2b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));
-            UTRY(gemm8(u, w, tb.q2_8, nullptr, nullptr, w.q2, M, C, C, 0, C, EPI_NONE, s));
             { const bf16_t* kv = u->ctx_cache + tb.ctx_off;
               const bf16_t* vt = kv + (size_t)Bn * n * 2 * C;
-              FlashArgs f{w.q2, (long)HW * C, (long)D, (long)C, kv, (long)n * 2 * C, (long)D, (long)2 * C, vt,
-                          w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, n, npad, D, 0, scale};
-              UTRY(launch_flash_attn(f, s)); }
+              if (fca8) {                                // to_q + the 64-key attention in one launch: writes w.att directly
+                  Fx fx;
+                  fx.cross_k = kv; fx.cross_vt = vt; fx.cross_ldk = 2 * C; fx.cross_n = n; fx.cross_npad = npad; fx.cross_rows = HW;
+                  fx.cross_scale = scale;
+                  UTRY(gemm8(u, w, tb.q2_8, nullptr, nullptr, w.att, M, C, C, 0, C, EPI_NONE, s, &fx));
+              } else {
+                  UTRY(gemm8(u, w, tb.q2_8, nullptr, nullptr, w.q2, M, C, C, 0, C, EPI_NONE, s));
+                  FlashArgs f{w.q2, (long)HW * C, (long)D, (long)C, kv, (long)n * 2 * C, (long)D, (long)2 * C, vt,
+                              w.att, (long)HW * C, (long)D, (long)C, nullptr, Bn, t.heads, HW, n, npad, D, 0, scale};
+                  UTRY(launch_flash_attn(f, s));
+              } }
             UTRY(launch_quant_fp8_rows(w.att, C, w.x8, C, w.xs, M, C, s));
             UTRY(gemm8(u, w, tb.o2_8, tb.o2b, b, a, M, C, C, C, C, EPI_RESID, s));
             UTRY(launch_layernorm_q8(a, tb.ln3g, tb.ln3b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));

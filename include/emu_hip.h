@@ -394,8 +394,9 @@ int emu_unet_set_fusion(emu_unet* u, int mask);
  * time with emu_unet_set_weight as "<name>.fp8" (the e4m3 bytes of emu_quantize_fp8_rows) and "<name>.fp8s" (fp32 row
  * scales), then emu_unet_use_fp8(u, 1): the blocks' GEMMs run on emu_linear_fp8_bf16's kernels, the three LayerNorms of a
  * block emit the consumer's fp8 rows themselves, the attention outputs and the GEGLU product are quantised per row by a launch
- * of their own; convs, GroupNorm, proj_in / proj_out, attention and the scheduler stay bf16.  Takes precedence over
- * emu_unet_set_fusion; changes emu_unet_workspace_bytes; returns -2 when a copy is missing. */
+ * of their own; convs, GroupNorm, proj_in / proj_out, attention and the scheduler stay bf16.  Of emu_unet_set_fusion's bits the
+ * V^T stores (1) and the cross-attention epilogue (2) stay in effect -- they work on finished sums -- the LayerNorm fold (0) has
+ * no fp8 form.  Changes emu_unet_workspace_bytes; returns -2 when a copy is missing. */
 int emu_unet_use_fp8(emu_unet* u, int enable);
 int emu_unet_temb_total(const emu_unet* u);               /* rows of temb_proj_all (sum of resnet out channels) */
 size_t emu_unet_workspace_bytes(const emu_unet* u, int H, int W);

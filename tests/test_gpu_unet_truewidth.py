@@ -204,6 +204,31 @@ def test_true_width_fp8_transformer_blocks_track_bf16(true_unet):
     assert 1e-4 < e < 0.15, e
 
 
+def test_true_width_fp8_blocks_keep_the_vt_and_cross_attention_epilogues(true_unet):
+    """With fp8 operands the epilogues that only look at finished sums stay fused (fusion bits 1, 2; the LayerNorm fold, bit 0, has
+    no fp8 form): V^T out of the fp8 qkv projection is bit-identical to the separate transpose launch, the cross-attention inside
+    the fp8 to_q epilogue stays within 2.5e-2 of the two-launch sequence (the bf16 engine's own figure for that fusion)."""
+    eng, Wr, ocfg = true_unet
+    H = Wd = 32
+    g = torch.Generator().manual_seed(8)
+    prompt = torch.randn(2, 64, 1792, generator=g).to(BF16)
+    x = (torch.randn(1, 4, H, Wd, generator=g) * 13.0).to(BF16)
+    eng.set_timesteps(2)
+    eng.set_context(prompt.cuda(), 8 * H, 8 * Wd)
+    outs = {}
+    eng.use_fp8(True)
+    try:
+        for mask in (0, 2, 4, 7):
+            eng.set_fusion(mask)
+            outs[mask] = eng.forward(x, 0).clone()
+    finally:
+        eng.use_fp8(False)
+        eng.set_fusion(7)
+    assert torch.equal(outs[2], outs[0])
+    assert 0 < rel_err(outs[4], outs[0]) < 2.5e-2, rel_err(outs[4], outs[0])
+    assert rel_err(outs[7], outs[0]) < 2.5e-2
+
+
 @pytest.mark.parametrize("rows,cols,with_res", [(1025, 1792, True), (2048, 1280, False), (300, 640, False), (5, 2048, True)])
 def test_layernorm_q8_equals_layernorm_then_quantise(rows, cols, with_res):
     """launch_layernorm_q8 (the W8A8 modes' LayerNorm): bf16 output and fp8 rows + scales bit-identical to layernorm followed by

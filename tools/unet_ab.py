@@ -25,10 +25,10 @@ with torch.no_grad():
     for r in range(rounds):
         for m in masks:
             from emu_amd._lib import lib
-            if m == "fp8":
+            if m.startswith("fp8"):                      # "fp8" = W8A8 blocks with the V^T / cross-attention epilogues, "fp8m0" = without
                 lib().emu_gemm_tune(0)
                 eng.use_fp8(True)
-                got = "fp8"
+                got = "fp8 + fusion %d" % eng.set_fusion(int(m[4:]) if m[3:4] == "m" else 7)
             else:
                 eng.use_fp8(False) if getattr(eng, "fp8", False) else None
                 fm, _, tn = m.partition("t")
