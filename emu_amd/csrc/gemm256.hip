@@ -29,13 +29,17 @@
 // barrier per phase measured within +-5 %.
 //
 // Ragged M ("extension"): prompts are 256*j + a few rows (770 = 3*256 + 2 text+image tokens, the ViT's 1025 = 4*256 + cls),
-// and a fourth / fifth row of tiles for 2 rows would cost a quarter of the GEMM.  When 0 < M mod 256 <= 32 the last row
-// of tiles carries the remainder itself: one more 1 KiB piece per wave per k tile (unit QX, 64 LDS rows), one more
-// accumulator per wave (its wc-th weight fragment x the remainder rows) and 4 more MFMAs per k tile (+12.5 %; fp8 operands: 2).  The
-// remainder fragments are read in the middle of phase B's MFMA segment into the registers of the weight half that
-// the wave has finished with (the half order depends on wc), so the extension costs 16 registers, not 32.  QX of tile
-// t+1 is staged first in B(t)'s group, waited for in A(t+1) and read in B(t+1).  Plain GEMM only (conv M is a
-// multiple of 256 on this path).
+// and a fourth / fifth row of tiles for 2 rows would cost a quarter of the GEMM.  When 0 < M mod 256 <= 16 the last row
+// of tiles carries the remainder itself: one more 1 KiB piece per wave per k tile (unit QX, 64 LDS rows; 16 are read) and
+// the remainder rows x this wave's wc-th 32 weight rows on FOUR v_mfma_f32_16x16x32_bf16 per k tile (two 16-row halves x two
+// 32-wide k-steps: 64 MFMA cycles against the main tile's 1024, +6.25 %; rounds 2-3 used 32x32x16 on the weight fragments that
+// were in registers anyway: +12.5 %, and M = 770 ran 7-10 % behind M = 768).  The 16-row fragments are a different lane layout
+// from the 32-row ones, so the weight rows are read a second time (4 ds_read_b128) -- in phase A, the only phase in which the
+// P units of the tile are readable (in phase B they are being overwritten with tile t+2) -- together with the remainder rows
+// (2 reads), and the four MFMAs close phase A's segment.  QX of tile t+2 rides in B(t)'s stage group with P0, P1, Q0 of that
+// tile (two phases in flight like every unit; waited for in B(t+1), read in A(t+2), its buffer last read in A(t)).  fp8
+// operands keep the 32x32x64 form on the register-resident fragments (2 more MFMAs per k tile), in phase A as well.  Plain
+// GEMM only (conv M is a multiple of 256 on this path).
 // LDS: 2 k tiles x 64 KiB + 2 x 8 KiB = 144 KiB, one workgroup per CU.
 //
 // Replaces the same reference calls as gemm.hip (torch Linear / Conv2d on the ViT, LLaMA-prefill and UNet paths).
@@ -64,7 +68,7 @@ __device__ __forceinline__ void bar() {
 // rows of tiles and remainder rows carried by the last one (0 = none / a ragged last tile instead)
 __host__ __device__ inline int pp_tiles_m(int M, bool allow_ext, int& ext_rows) {
     const int tm = M >> 8, r = M & 255;
-    ext_rows = (allow_ext && tm >= 1 && r > 0 && r <= 32) ? r : 0;
+    ext_rows = (allow_ext && tm >= 1 && r > 0 && r <= 16) ? r : 0;
     return ext_rows ? tm : (M + 255) >> 8;
 }
 
@@ -204,31 +208,48 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     };
 
     // ---- fragment reads: lane (l31, hi) reads row base + l31, chunk (2*kk + hi) ^ swizzle(row), swizzle = (l31 >> 1) & 7
-    int lp[4];                                      // P units: wave row wr owns LDS rows wr*64 .. +63
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        // bf16: k step kk (16 wide) = chunk 2*kk + hi.  fp8: k step kk >> 1 (64 wide) = 32 bytes per lane = chunks
-        // 4*(kk >> 1) + 2*hi + (kk & 1): pieces 2s, 2s+1 of a fragment form one MFMA operand
-        const int chunk = F8 ? ((kk >> 1) << 2) | (hi << 1) | (kk & 1) : (kk << 1) | hi;
-        lp[kk] = l31 * 128 + ((chunk ^ ((l31 >> 1) & 7)) << 4) + wr * 8192;
-    }
+    // bf16: k step kk (16 wide) = chunk 2*kk + hi.  fp8: k step kk >> 1 (64 wide) = 32 bytes per lane = chunks
+    // 4*(kk >> 1) + 2*hi + (kk & 1): pieces 2s, 2s+1 of a fragment form one MFMA operand.  The chunk index enters the byte
+    // offset through an XOR (the swizzle), so the offset of k step kk is the offset of k step 0 with bits 4..6 flipped: ONE
+    // loop-invariant lane offset (P units: wave row wr owns LDS rows wr*64 .. +63) and three v_xor per phase instead of four
+    // registers (the kernel lives at the 256-VGPR edge; round 4's 16x16 remainder-row fragments needed the room)
+    const int lp0 = l31 * 128 + ((((F8 ? hi << 1 : hi)) ^ ((l31 >> 1) & 7)) << 4) + wr * 8192;
+    auto lpk = [](int base, int kk) { return base ^ (F8 ? (((kk >> 1) << 6) | ((kk & 1) << 4)) : (kk << 5)); };
     bf16x8_t pg[2][2][4], q0f[4], q1f[4], qxf[4];   // [P sub-tile][n fragment][k step]
-    auto read_p = [&](bf16x8_t (&d)[2][4], const char* ub) {
+    auto read_p = [&](bf16x8_t (&d)[2][4], const char* ub, int base) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) d[i][kk] = *reinterpret_cast<const bf16x8_t*>(ub + i * 4096 + lp[kk]);
+            for (int kk = 0; kk < 4; ++kk) d[i][kk] = *reinterpret_cast<const bf16x8_t*>(ub + i * 4096 + lpk(base, kk));
     };
     // Q units: wave column wc owns LDS rows wc*32 .. +31; QX: rows 0 .. 31.  Same lane offsets as P, moved by a
-    // wave-uniform distance that is kept out of loop-invariant registers (the kernel lives at the 256-VGPR edge).
-    auto read_q = [&](bf16x8_t (&q)[4], const char* ub, int dist) {
+    // wave-uniform distance that is kept out of loop-invariant registers.
+    auto read_q = [&](bf16x8_t (&q)[4], const char* ub, int dist, int base) {
         asm volatile("" : "+s"(dist));
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) q[kk] = *reinterpret_cast<const bf16x8_t*>(ub + (lp[kk] + dist));
+        for (int kk = 0; kk < 4; ++kk) q[kk] = *reinterpret_cast<const bf16x8_t*>(ub + (lpk(base, kk) + dist));
     };
     const int dq = wc * 4096 - wr * 8192, dx = -wr * 8192;
+    // remainder rows on 16x16x32 MFMAs (bf16): lane (l15, q4) reads LDS row base + l15, chunk (4 s + q4) ^ swizzle(row); the
+    // swizzle (row >> 1) & 7 of rows R0 + 16 h + l15 (R0 a multiple of 32) is (l15 >> 1) & 7 for both halves h, and k-step s = 1 is
+    // the same offset with bit 6 flipped: one lane offset serves the wave's weight rows (P unit wc >> 1, rows wr*64 + (wc&1)*32 ..)
+    // and, moved by a wave-uniform distance, the remainder rows (QX rows 0 .. 15)
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int lx0 = (wr * 64 + (wc & 1) * 32 + l15) * 128 + ((q4 ^ ((l15 >> 1) & 7)) << 4);
+    bf16x8_t ax[2][2], bx[2];                        // [16-row half][k-step], [k-step]
+    auto read_x16 = [&](const char* pu, const char* qx) {
+        int d0 = 0, d1 = 2048;
+        asm volatile("" : "+s"(d0), "+s"(d1));
+        ax[0][0] = *reinterpret_cast<const bf16x8_t*>(pu + (lx0 + d0));
+        ax[0][1] = *reinterpret_cast<const bf16x8_t*>(pu + ((lx0 ^ 64) + d0));
+        ax[1][0] = *reinterpret_cast<const bf16x8_t*>(pu + (lx0 + d1));
+        ax[1][1] = *reinterpret_cast<const bf16x8_t*>(pu + ((lx0 ^ 64) + d1));
+        bx[0] = *reinterpret_cast<const bf16x8_t*>(qx + lx0);
+        bx[1] = *reinterpret_cast<const bf16x8_t*>(qx + (lx0 ^ 64));
+    };
 
-    f32x16_t acc[2][2][2], accx;                    // [P sub-tile][Q sub-tile][n fragment]; remainder rows
+    f32x16_t acc[2][2][2], accx;                    // [P sub-tile][Q sub-tile][n fragment]; remainder rows (fp8 operands)
+    f32x4_t accx16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // remainder rows x the wave's wc-th weight rows, 16-row halves (bf16)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         accx[r] = 0.f;
@@ -297,38 +318,55 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         constexpr int BF = decltype(bc)::value;
         const char* sb = smem + BF * BUFB;
         // ---- phase A
-        read_q(q0f, sb + U_Q0 * UNIT, dq);
-        read_p(pg[0], sb + U_P0 * UNIT);
-        read_p(pg[1], sb + U_P1 * UNIT);
-        if (t + 1 < nk) { stage(IC<U_Q1>{}, IC<BF ^ 1>{}, t + 1); wait_vmcnt<8>(); } else wait_vmcnt<0>();
+        int lb = lp0;
+        asm volatile("" : "+v"(lb));                   // (keeps the three derived offsets from being hoisted into registers)
+        read_q(q0f, sb + U_Q0 * UNIT, dq, lb);
+        read_p(pg[0], sb + U_P0 * UNIT, lb);
+        read_p(pg[1], sb + U_P1 * UNIT, lb);
+        if (ext) {                                     // the remainder rows of this tile (QX: staged two phases ago, waited for in B(t-1))
+            if constexpr (!F8) read_x16(sb + (wc >= 2 ? U_P1 : U_P0) * UNIT, smem + 2 * BUFB + BF * QXB - (wr * 64 + (wc & 1) * 32) * 128);
+            else read_q(qxf, smem + 2 * BUFB + BF * QXB, dx, lb);
+        }
+        if (t + 1 < nk) {
+            stage(IC<U_Q1>{}, IC<BF ^ 1>{}, t + 1);
+            if (ext) wait_vmcnt<9>(); else wait_vmcnt<8>();
+        } else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bar();
         __builtin_amdgcn_s_setprio(1);
         mma(0, q0f);
+        if (ext) {
+            if constexpr (!F8) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) accx16[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[h][s2], bx[s2], accx16[h], 0, 0, 0);
+            } else {
+                if (wc == 0) mma_x(IC<0>{}, IC<0>{});
+                else if (wc == 1) mma_x(IC<0>{}, IC<1>{});
+                else if (wc == 2) mma_x(IC<1>{}, IC<0>{});
+                else mma_x(IC<1>{}, IC<1>{});
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         bar();
         // ---- phase B
-        read_q(q1f, sb + U_Q1 * UNIT, dq);
-        if (ext) read_q(qxf, smem + 2 * BUFB + BF * QXB, dx);
-        if (ext && t + 1 < nk) stage_x(IC<BF ^ 1>{}, t + 1);
+        lb = lp0;
+        asm volatile("" : "+v"(lb));
+        read_q(q1f, sb + U_Q1 * UNIT, dq, lb);
         if (t + 2 < nk) {
+            if (ext) stage_x(IC<BF>{}, t + 2);
             stage(IC<U_P0>{}, IC<BF>{}, t + 2);
             stage(IC<U_P1>{}, IC<BF>{}, t + 2);
             stage(IC<U_Q0>{}, IC<BF>{}, t + 2);
             if (ext) wait_vmcnt<9>(); else wait_vmcnt<8>();
         } else if (t + 1 < nk) {
-            if (ext) wait_vmcnt<3>(); else wait_vmcnt<2>();
+            wait_vmcnt<2>();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bar();
         __builtin_amdgcn_s_setprio(1);
         mma(1, q1f);
-        if (ext) {
-            if (wc == 0) mma_x(IC<0>{}, IC<0>{});
-            else if (wc == 1) mma_x(IC<0>{}, IC<1>{});
-            else if (wc == 2) mma_x(IC<1>{}, IC<0>{});
-            else mma_x(IC<1>{}, IC<1>{});
-        }
         __builtin_amdgcn_s_setprio(0);
         bar();
     };
@@ -522,6 +560,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         }
     }
     if (ext) {
+        if constexpr (!F8) {
+            // 16x16 results: lane (l15, q4) holds remainder row l15, columns 16 h + 4 q4 .. + 3 of the wave's wc-th 32 weight rows
+            const int m = m0 + 256 + l15;
+            if (m < a.M) {
+                QuadIn qx[2];
+                if (nsl == 1) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int nb = n0 + wr * 128 + wc * 32 + 16 * h + 4 * q4;
+                        if (nb < a.N) { quad_load_cols<EPI, FX>(a, nb, qx[h]); quad_load_row<EPI>(a, m, nb, qx[h]); }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nb = n0 + wr * 128 + wc * 32 + 16 * h + 4 * q4;
+                    if (nb >= a.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = accx16[h][e];
+                    RowFx fx;                          // remainder rows never carry the fused-LayerNorm features (gemm256_ok)
+                    emit(m, nb, v, fx, qx[h]);
+                }
+            }
+        } else {
         const int m = m0 + 256 + l31;
         if (m < a.M) {
             QuadIn qx[4];
@@ -542,6 +604,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
                 RowFx fx;                              // remainder rows never carry the fused-LayerNorm features (gemm256_ok)
                 emit(m, nb, v, fx, qx[g]);
             }
+        }
         }
     }
 }
