@@ -377,6 +377,7 @@ struct emu_llama {
     int kv_batch = 0, s_max = 0;
     int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
     int l0 = 0, l1 = -1;                         // emu_llama_set_layer_range: layers [l0, l1) run (l1 < 0: all)
+    bool prefill_fusion = false;                 // emu_llama_set_prefill_fusion: RoPE + KV append + V^T in the qkv GEMM's epilogue
 };
 
 namespace {
@@ -464,6 +465,11 @@ int emu_llama_set_head_fp8(emu_llama* m, const void* lm_head8, const float* lm_s
     m->lm_head8 = reinterpret_cast<const uint8_t*>(lm_head8); m->lm_scale8 = lm_scale;
     return 0;
 }
+int emu_llama_set_prefill_fusion(emu_llama* m, int enable) {
+    if (!m) return -22;
+    m->prefill_fusion = enable != 0;
+    return 0;
+}
 int emu_llama_use_fp8(emu_llama* m, int enable) {
     if (!m) return -22;
     if (enable && m->layers8.size() != (size_t)m->cfg.layers)
@@ -522,6 +528,12 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     const int spad = (ctx + 63) / 64 * 64;
     bf16_t* hA = B(hidden);
     const int l_end = m->l1 < 0 ? c.layers : m->l1;
+    // Prefill of ONE batch element whose rows are the whole context in slot order (emu_llama_set_prefill_fusion: the caller
+    // promises slot[i] = i): the qkv projection rotates q / k, appends k / v to the cache and writes V^T itself
+    // (GemmArgs::rope_*), instead of the rope_kv and transpose_v launches.  The V^T buffer's pad columns [ctx, spad) are
+    // never written on that path: zeroed once per call (the attention kernel multiplies them by masked probabilities).
+    bool fuse_rope = m->prefill_fusion && Bn == 1 && T > 16 && T == ctx && D == 128 && !(HD & 255) && !m->fp8_prefill && m->kv_share_nb <= 1;
+    if (fuse_rope && hipMemsetAsync(w.vt, 0, (size_t)HD * spad * 2, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
     for (int l = m->l0; l < l_end; ++l) {
         const emu_llama::Layer& L = m->layers[l];
         if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
@@ -541,7 +553,21 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         } else {                                     // 2..16 rows: norm once, skinny MFMA stream; more: GEMM
             TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
             if (f8p) TRY(cx, linear_q8(w, w.xn, H, m->layers8[l].wqkv, m->layers8[l].sqkv, nullptr, w.qkv, M, 3 * HD, H, 0, 3 * HD, EPI_NONE, s));
-            else TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
+            else {
+                int st = -95;
+                if (fuse_rope) {
+                    GemmArgs g{w.xn, L.wqkv, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, EPI_NONE, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+                    g.partial = w.splitk; g.partial_floats = w.splitk_floats;
+                    g.rope_cos = m->cos; g.rope_sin = m->sin; g.rope_pos = pos; g.rope_slot = slot; g.rope_kc = kc; g.rope_vc = vc;
+                    g.rope_hl = Hl; g.rope_smax = m->s_max;
+                    g.vt_out = w.vt; g.vt_col0 = 2 * HD; g.vt_s = M; g.vt_spad = spad;
+                    st = launch_gemm(g, s);
+                    if (st != 0 && st != -95) return fail(cx, st, "emu_llama_forward: qkv projection with the RoPE epilogue");
+                    if (st == -95) fuse_rope = false;  // the 256x256 tile does not take this shape unsliced: unfused sequence
+                }
+                if (st == -95)
+                    TRY(cx, linear(w.xn, L.wqkv, nullptr, nullptr, nullptr, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, s, nullptr, w.splitk, w.splitk_floats));
+            }
         }
         if (T == 1) {
             // RoPE + KV append + attention in one launch; context = slot + 1 is read on the device (graph replay)
@@ -550,10 +576,12 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             TRY(cx, launch_decode_fused(a, s));
         } else {
             if (m->kv_share_nb > 1) return fail(cx, -22, "emu_llama_forward: shared-prefix KV rows serve single-token steps only");
-            { RopeKvArgs r{w.qkv, m->cos, m->sin, pos, slot, kc, vc, Bn, T, Hl, D, m->s_max};
-              TRY(cx, launch_rope_kv(r, s)); }
-            TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, w.vt, Bn, Hl, ctx, D, spad};
-            TRY(cx, launch_transpose_v(tv, s));
+            if (!fuse_rope) {
+                { RopeKvArgs r{w.qkv, m->cos, m->sin, pos, slot, kc, vc, Bn, T, Hl, D, m->s_max};
+                  TRY(cx, launch_rope_kv(r, s)); }
+                TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, w.vt, Bn, Hl, ctx, D, spad};
+                TRY(cx, launch_transpose_v(tv, s));
+            }
             FlashArgs f{w.qkv, (long)T * 3 * HD, (long)D, (long)3 * HD,
                         kc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D,
                         w.vt, w.attn, (long)T * HD, (long)D, (long)HD, kstart,

@@ -830,6 +830,16 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         if constexpr (EPI == EPI_NONE && !CONV) { launch_cfg<EPI, CONV, CfgK>(a, s); EMU_CHECK_LAUNCH(); return 0; }
         return -22;
     }
+    if (a.rope_cos) {
+        // only the 256x256 tile has this epilogue, and only whole-K tiles: -95 tells the caller to run the unfused sequence
+        // (qkv GEMM, rope_kv, transpose_v) instead -- thin prompts, K-sliced tail rounds
+        if constexpr (EPI == EPI_NONE && !CONV) {
+            const PpPlan pp = pick_pp(a);
+            if (!gemm256_ok(a) || !pp.use || pp.ksplit > 1) return -95;
+            return launch_gemm256(a, s, -1, 1);
+        }
+        return -22;
+    }
     int cfg = g_force_cfg;
     const bool k64 = (a.K & 63) == 0;
     if (cfg == 'S' && !k64) cfg = 0;
@@ -1005,6 +1015,14 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t s) {
     if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
     if (a.row_stats_out && ((a.N & 127) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
+    if (a.rope_cos) {                                  // RoPE + KV append + V^T epilogue of the LLaMA prefill's qkv projection
+        const int hd = a.rope_hl * 128;
+        if (!a.rope_sin || !a.rope_pos || !a.rope_slot || !a.rope_kc || !a.rope_vc || !a.vt_out || a.rope_hl < 1 || a.N != 3 * hd ||
+            (hd & 255) || a.vt_col0 != 2 * hd || a.vt_s != a.M || a.rope_smax < a.M || a.epi != EPI_NONE || a.bias || a.bias2 ||
+            a.ln_c || a.row_stats_out || a.cross_k || a.conv.mode != CONV_NONE || (a.ldc & 7) || ((uintptr_t)a.C & 15) ||
+            (a.vt_spad & 7) || ((uintptr_t)a.vt_out & 15) || a.vt_spad < a.M)
+            return -22;
+    }
     if (a.vt_out && (a.epi != EPI_NONE || a.conv.mode != CONV_NONE || (a.vt_col0 & 63) || ((a.N - a.vt_col0) & 63) || a.vt_col0 < 0 ||
                      a.vt_col0 >= a.N || a.vt_s < 1 || a.M % a.vt_s || a.vt_spad < a.vt_s || (a.ldc & 3))) return -22;
     if (a.cross_k && (!a.cross_vt || a.epi != EPI_NONE || a.conv.mode != CONV_NONE || a.bias || (a.N & 63) || (a.ldc & 3) || a.cross_n < 1 ||

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     const int tm = wg % tiles_m;
     const int n0 = (wg / tiles_m) << 8, m0 = tm << 8;
     // this workgroup also owns rows m0 + 256 .. M - 1 (never with the fused epilogues: gemm256_ok refuses that combination)
-    const bool ext = !CONV && FX == 0 && ext_rows > 0 && tm == tiles_m - 1;
+    const bool ext = !CONV && (FX == 0 || (FX & FX_ROPE) != 0) && ext_rows > 0 && tm == tiles_m - 1;
 
     // ---- LDS-DMA sources.  Instruction i (0, 1) of a unit fills LDS rows r = i*64 + srow, srow = wave*8 + lane/8, slot
     // lane%8 <- global chunk slot ^ ((r >> 1) & 7).  P unit s: row r holds weight row n0 + (r >> 6)*128 + s*64 + (r & 63);
@@ -415,6 +415,110 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
             store_quad<EPI, FX>(a, m, nb, v, fx, q);
         }
     };
+    // ---- LLaMA prefill qkv projection: RoPE + KV append + V^T out of the epilogue (GemmArgs::rope_*; replaces the rope_kv and
+    // transpose_v launches).  The tile -- 2 heads of q, k or v for 256 (+ remainder) rows of the one batch element -- is staged
+    // row-major in LDS first: a head's two rotation halves d, d + 64 are then 128 bytes apart in a row, whichever accumulator
+    // layout (main tile or 16x16 remainder rows) produced them; a lane rotates 8 + 8 elements of one row with rope_kv_kernel's
+    // arithmetic (every product and the sum rounded to bf16) and stores 16-byte pieces: q to C, k to the cache rows of its
+    // slot; v rows go to the cache as they are and then once more through the transposed staging to vt_out.
+    if constexpr ((FX & FX_ROPE) != 0) {
+        using StR = EpiStage<256, 256, 512>;
+        using StT = EpiStageT<256, 256, 512>;
+        const int HDc = a.rope_hl * 128, region = n0 / HDc;      // 0: q, 1: k, 2: v (3 * HDc % 256 == 0: launch_gemm checks)
+        __syncthreads();                               // both wave groups are out of the loop
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int row = wc * 64 + y * 32 + l31;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi;
+                        u32x2 ov;
+                        ov.x = packbf(acc[x][y][i][4 * g], acc[x][y][i][4 * g + 1]);
+                        ov.y = packbf(acc[x][y][i][4 * g + 2], acc[x][y][i][4 * g + 3]);
+                        *reinterpret_cast<u32x2*>(smem + StR::off(row, col)) = ov;
+                    }
+            }
+        if (ext) {                                     // remainder rows: LDS rows 256 .. 271 behind the tile
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x2 ov;
+                ov.x = packbf(accx16[h][0], accx16[h][1]);
+                ov.y = packbf(accx16[h][2], accx16[h][3]);
+                *reinterpret_cast<u32x2*>(smem + StR::off(256 + l15, wr * 128 + wc * 32 + 16 * h + 4 * q4)) = ov;
+            }
+        }
+        __syncthreads();
+        const int nrows = ext ? 272 : 256;
+        if (region < 2) {
+            const int head0 = (n0 - region * HDc) >> 7;
+            for (int idx = tid; idx < nrows * 16; idx += 512) {
+                const int row = idx >> 4, hh = (idx >> 3) & 1, c = idx & 7, m = m0 + row;
+                if (m >= a.M) continue;
+                float x1[8], x2[8], cs[8], sn[8], o1[8], o2[8];
+                unpack8(*reinterpret_cast<const u32x4*>(smem + StR::off(row, hh * 128 + c * 8)), x1);
+                unpack8(*reinterpret_cast<const u32x4*>(smem + StR::off(row, hh * 128 + 64 + c * 8)), x2);
+                const size_t po = (size_t)a.rope_pos[m] * 128 + c * 8;
+                unpack8(ld16(a.rope_cos + po), cs);
+                unpack8(ld16(a.rope_sin + po), sn);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    o1[j] = bfround(x1[j] * cs[j]) + bfround(-x2[j] * sn[j]);
+                    o2[j] = bfround(x2[j] * cs[j]) + bfround(x1[j] * sn[j]);
+                }
+                bf16_t* dst = region == 0 ? a.C + (size_t)m * a.ldc + n0 + hh * 128 + c * 8
+                                          : a.rope_kc + ((size_t)(head0 + hh) * a.rope_smax + a.rope_slot[m]) * 128 + c * 8;
+                st16(dst, pack8(o1));
+                st16(dst + 64, pack8(o2));
+            }
+        } else {
+            const int head0 = (n0 - 2 * HDc) >> 7;
+            for (int idx = tid; idx < nrows * 32; idx += 512) {
+                const int row = idx >> 5, ch = idx & 31, m = m0 + row;
+                if (m >= a.M) continue;
+                st16(a.rope_vc + ((size_t)(head0 + (ch >> 4)) * a.rope_smax + a.rope_slot[m]) * 128 + (ch & 15) * 8,
+                     *reinterpret_cast<const u32x4*>(smem + StR::off(row, ch * 8)));
+            }
+            __syncthreads();                           // the row-major tile has been read: the transposed one takes its place
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const int row = wc * 64 + y * 32 + l31;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = wr * 128 + x * 64 + i * 32 + 8 * g + 4 * hi;
+                            const uint32_t p0 = packbf(acc[x][y][i][4 * g], acc[x][y][i][4 * g + 1]);
+                            const uint32_t p1 = packbf(acc[x][y][i][4 * g + 2], acc[x][y][i][4 * g + 3]);
+                            *reinterpret_cast<bf16_t*>(smem + StT::off(col, row)) = (bf16_t)(p0 & 0xffffu);
+                            *reinterpret_cast<bf16_t*>(smem + StT::off(col + 1, row)) = (bf16_t)(p0 >> 16);
+                            *reinterpret_cast<bf16_t*>(smem + StT::off(col + 2, row)) = (bf16_t)(p1 & 0xffffu);
+                            *reinterpret_cast<bf16_t*>(smem + StT::off(col + 3, row)) = (bf16_t)(p1 >> 16);
+                        }
+                }
+            __syncthreads();
+            StT::store(smem, a, m0, n0);               // one batch element: b = 0, key index = row index (launch_gemm checks)
+            if (ext) {                                 // remainder rows: a few 2-byte stores per lane
+                const int m = m0 + 256 + l15;
+                if (m < a.M) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int n = n0 + wr * 128 + wc * 32 + 16 * h + 4 * q4 + e;
+                            const uint32_t pk = packbf(accx16[h][e], 0.f);
+                            a.vt_out[(size_t)(n - a.vt_col0) * a.vt_spad + m] = (bf16_t)(pk & 0xffffu);
+                        }
+                }
+            }
+        }
+        return;
+    }
     // Staged epilogue (gemm_tile.h::EpiStage): the 256 x 256 results leave through the (now dead) k-tile ring as whole rows
     constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
     using Stage = EpiStage<256, GLU ? 128 : 256, 512>;
@@ -656,6 +760,12 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.stage_vt = b.stage && stage_vt_ok(b, 256, 256) && !(emu_gemm_tune_get() & (1 << 14));
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
+    if (fx & FX_ROPE) {                                 // launch_gemm: EPI_NONE, unsliced, bf16 (launch_v2 checks the plan)
+        if constexpr (!CONV && !F8 && EPI == EPI_NONE) {
+            hipLaunchKernelGGL((gemm_pp_kernel<EPI_NONE, false, false, FX_ROPE | FX_VT>), dim3(b.full_tiles), dim3(512), 0, s, b);
+        }
+        return;
+    }
     if (fx) {                                           // gemm256_ok: bf16 plain GEMM; launch_gemm: an instantiated (epi, mask) pair
         if constexpr (!CONV && !F8) {
             gemm_fx_dispatch<EPI>(fx, [&](auto m) {
@@ -689,7 +799,7 @@ bool gemm256_ok(const GemmArgs& a) {
         if (a.a_scale || a.conv.mode != CONV_NONE) return false;
         int ext_rows;
         pp_tiles_m(a.M, a.conv.mode == CONV_NONE, ext_rows);
-        if (ext_rows) return false;
+        if (ext_rows && !a.rope_cos) return false;     // (the RoPE epilogue stages its remainder rows with the tile)
     }
     if (a.conv.mode != CONV_NONE && (a.conv.Hout > 2047 || a.conv.Wout > 2047 || a.M / (a.conv.Hout * a.conv.Wout) > 1023))
         return false;                                  // packed pixel coordinates of the gather

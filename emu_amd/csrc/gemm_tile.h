@@ -67,6 +67,7 @@ constexpr int FX_LN = 1;            // GemmArgs::ln_*: LayerNorm of A folded int
 constexpr int FX_STATS = 2;         // GemmArgs::row_stats_out: emit per-row partial sums of C
 constexpr int FX_VT = 4;            // GemmArgs::vt_out: V heads stored key-contiguous
 constexpr int FX_CROSS = 8;         // GemmArgs::cross_*: cross-attention over <= 64 cached keys in the epilogue (128 x 64 tile)
+constexpr int FX_ROPE = 16;         // GemmArgs::rope_*: RoPE + KV append (+ FX_VT) in the epilogue of the LLaMA prefill's qkv projection (256x256 tile)
 
 struct RowFx {
     float mean = 0.f, rstd = 1.f;
@@ -403,11 +404,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
 // what the UNet transformer blocks launch -- proj_in / to_q producers and consumers, the qkv projection (+ V^T), the residual
 // out-projections and ff-out as producers, the GEGLU projection as a consumer
 inline int gemm_fx(const GemmArgs& a) {
-    return (a.ln_c ? FX_LN : 0) | (a.row_stats_out ? FX_STATS : 0) | (a.vt_out ? FX_VT : 0) | (a.cross_k ? FX_CROSS : 0);
+    return (a.ln_c ? FX_LN : 0) | (a.row_stats_out ? FX_STATS : 0) | (a.vt_out ? FX_VT : 0) | (a.cross_k ? FX_CROSS : 0) | (a.rope_cos ? FX_ROPE : 0);
 }
 constexpr bool gemm_fx_ok(int epi, int fx) {
     return fx == 0 || (epi == EPI_NONE && (fx == FX_LN || fx == FX_STATS || fx == FX_VT || fx == (FX_LN | FX_VT) || fx == FX_CROSS ||
-                                           fx == (FX_LN | FX_CROSS))) ||
+                                           fx == (FX_LN | FX_CROSS) || fx == (FX_ROPE | FX_VT))) ||
            (epi == EPI_RESID && fx == FX_STATS) || (epi == EPI_GEGLU && fx == FX_LN);
 }
 // calls f(std::integral_constant<int, FX>) for the instantiated mask of this epilogue; false when the pair does not exist

@@ -100,6 +100,17 @@ struct GemmArgs {
     int stage = 0;          // set by launch_gemm: the staged (LDS-transposed, 16-byte coalesced) epilogue may be taken (gemm_tile.h)
     // ---- per-workgroup timeline (tools/gemm_trace.py; written only by a library built with -DEMU_TRACE): 8 x u64 per workgroup
     unsigned long long* trace = nullptr;
+    // ---- LLaMA prefill qkv projection with RoPE, KV append and V^T in the epilogue (256x256 tile only; N = 3 * rope_hl * 128,
+    // columns [q heads | k heads | v heads], ONE batch element whose rows sit at cache slots rope_slot[m] = m): q is rotated and
+    // stored to C, k is rotated and stored to rope_kc[head][slot][128], v goes to rope_vc[head][slot][128] and, key-contiguous, to
+    // vt_out (GemmArgs::vt_* as above, vt_col0 = 2 * rope_hl * 128).  Same arithmetic as rope_kv_kernel (attention.hip).
+    const bf16_t* rope_cos = nullptr;   // [max_pos, 128]
+    const bf16_t* rope_sin = nullptr;
+    const int32_t* rope_pos = nullptr;  // [M] rope position of every row
+    const int32_t* rope_slot = nullptr; // [M] cache slot of every row
+    bf16_t* rope_kc = nullptr;          // [rope_hl, rope_smax, 128] of this layer and batch element
+    bf16_t* rope_vc = nullptr;
+    int rope_hl = 0, rope_smax = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // tools hook: where the next GEMM launches of a -DEMU_TRACE build write their per-workgroup timelines (nullptr = off)

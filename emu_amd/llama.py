@@ -141,6 +141,10 @@ class LlamaEngine:
         h = C.c_void_p()
         check(lib().emu_llama_create(ctx.handle, C.byref(c), C.byref(h)), "emu_llama_create", ctx.handle)
         self.handle = h
+        # prefill() always hands the rows of a prompt over in slot order, which is what the fused RoPE / KV-append / V^T epilogue of
+        # the qkv projection needs to be told (include/emu_hip.h: emu_llama_set_prefill_fusion); set_prefill_fusion(False) = the
+        # three-launch sequence (A/B timing, parity tests)
+        self.set_prefill_fusion(True)
         self._keep: Dict[str, torch.Tensor] = {}          # packed weights (owned here, pointers held by the lib)
         self._pending: Dict[int, Dict[str, torch.Tensor]] = {}
         self.layers_loaded = set()          # indices of the packed layers (a reload must not count twice)
@@ -149,6 +153,10 @@ class LlamaEngine:
         self.kcache = self.vcache = None
         self.kv_batch = self.s_max = 0
         self._ws = None
+
+    def set_prefill_fusion(self, enable: bool) -> None:
+        check(lib().emu_llama_set_prefill_fusion(self.handle, 1 if enable else 0), "emu_llama_set_prefill_fusion", self.ctx.handle)
+        self.prefill_fusion = bool(enable)
 
     # ------------------------------------------------------------------ weights
     def _dev(self, t: torch.Tensor) -> torch.Tensor:

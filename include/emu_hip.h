@@ -257,6 +257,13 @@ int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots);
  * KV-cache plane of its own index.  The full-size tests feed ONE layer the fp32 oracle's input of that layer (a common input per
  * layer instead of 60 layers of accumulated bf16 rounding); production code never calls it. */
 int emu_llama_set_layer_range(emu_llama* m, int l0, int l1);
+
+/* Prefill fusion (off by default): a caller that sets it PROMISES that every emu_llama_forward call with T > 1 rows passes
+ * slot[i] = i (the rows of the one batch element are the whole context, in order -- what EmuModel's prefill does).  Then, for
+ * B = 1, T == ctx, head_dim 128 and heads_local * 128 a multiple of 256, the qkv projection applies RoPE to q and k, appends
+ * k / v to the cache and writes V^T for the attention kernel from its own epilogue (same arithmetic and rounding points as the
+ * three launches it replaces: bit-identical hidden states and caches); every other call runs the unfused sequence. */
+int emu_llama_set_prefill_fusion(emu_llama* m, int enable);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
 /* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
  * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).

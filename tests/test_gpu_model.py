@@ -413,6 +413,41 @@ def test_true_width_single_layer_decode_and_prefill():
     assert rel_err(step, want1[:, 0]) < 2e-2, rel_err(step, want1[:, 0])
 
 
+@pytest.mark.parametrize("S", [770, 1544, 600, 300])
+def test_true_width_prefill_rope_epilogue_bit_identical(S):
+    """Round 4: the qkv projection of a one-prompt prefill applies RoPE, appends k / v to the cache and writes V^T from its own
+    epilogue (emu_llama_set_prefill_fusion; 256x256 tile, with the 16x16 remainder rows of S = 770 / 1544 and the ragged last
+    tile of S = 600) instead of the rope_kv and transpose_v launches.  Same arithmetic, same rounding points: hidden states,
+    both caches and a cached decode step on top must be BIT-identical to the three-launch sequence.  S = 300 is a shape the big
+    tile would K-slice: the engine falls back to the unfused sequence by itself (same bits trivially; the call must not fail)."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import LlamaCfg
+    from emu_amd.llama import EmuHipContext, LlamaEngine
+    l = LlamaCfg(num_hidden_layers=2)
+    eng = LlamaEngine(l, 256, EmuHipContext(torch.device("cuda", 0)))
+    eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, 256), device="cuda", dtype=BF16))
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(1, S + 1, l.hidden_size, generator=g).to(BF16).cuda()
+    mask = torch.ones(1, S, dtype=torch.long)
+    s_max = eng.kv_capacity(S + 8)
+    outs = {}
+    for fused in (True, False, True):
+        eng.set_prefill_fusion(fused)
+        eng.alloc_kv(1, s_max)
+        eng.kcache.fill_(7.0); eng.vcache.fill_(7.0)                        # every slot the prefill owns must be written
+        hidden, kstart, pos = eng.prefill(x[:, :S].contiguous(), mask, s_max)
+        hidden = hidden.clone()
+        kc, vc = eng.kcache[:, :, :, :S].clone(), eng.vcache[:, :, :, :S].clone()
+        step = eng.decode_embeds(x[:, S].contiguous(), pos, S, kstart).clone()
+        outs.setdefault(fused, []).append((hidden, kc, vc, step))
+    eng.set_prefill_fusion(True)
+    a, b, c = outs[True][0], outs[False][0], outs[True][1]
+    for t in a:
+        assert bool(torch.isfinite(t.float()).all())
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u, w)
+
+
 def test_true_width_five_beam_step_against_oracle_and_single_rows():
     """The reference's default decoding mode at the decoder's true width: one LLaMA-33B-shaped layer, a 300-token prompt, 5 beams
     that share the prompt's cache row and feed five different tokens -- the step runs the 5-row LDS-DMA + MFMA weight streams
