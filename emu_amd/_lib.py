@@ -124,6 +124,7 @@ _PROTOS = {
     "emu_vit_set_block": (i32, [vp, i32] + [vp] * 12),
     "emu_vit_set_block_fp8": (i32, [vp, i32] + [vp] * 8),
     "emu_vit_use_fp8": (i32, [vp, i32]),
+    "emu_vit_set_fusion": (i32, [vp, i32]),
     "emu_vit_workspace_bytes": (sz, [vp, i32]),
     "emu_vit_forward": (i32, [vp, vp, i32, i32, vp, vp, sz, vp]),
     "emu_groupnorm_ws_bytes": (sz, [i32, i32, i32]),

@@ -689,6 +689,7 @@ struct emu_vit {
                     const float *sqkv = nullptr, *sproj = nullptr, *sfc1 = nullptr, *sfc2 = nullptr; };
     std::vector<Block8> blocks8;
     bool fp8 = false;
+    bool fuse_vt = true;                             // emu_vit_set_fusion bit 0: V^T out of the qkv projection's epilogue (one image)
 };
 
 namespace {
@@ -761,6 +762,11 @@ int emu_vit_set_block_fp8(emu_vit* m, int layer, const void* wqkv8, const float*
     m->blocks8[layer] = {U(wqkv8), U(wproj8), U(fc1w8), U(fc2w8), sqkv, sproj, sfc1, sfc2};
     return 0;
 }
+int emu_vit_set_fusion(emu_vit* m, int mask) {
+    if (!m) return -22;
+    m->fuse_vt = (mask & 1) != 0;
+    return 0;
+}
 int emu_vit_use_fp8(emu_vit* m, int enable) {
     if (!m) return -22;
     if (enable) {
@@ -809,9 +815,19 @@ static int vit_blocks(emu_vit* m, bf16_t* x, int Bn, int l0, int l1, const VitWs
             else TRY(cx, launch_layernorm(x, Bk.ln1w, Bk.ln1b, nullptr, w.tmp, M, C, c.ln_eps, s));
             ain = w.tmp;
         }
-        TRY(cx, lin(ain, Bk.wqkv, B8.wqkv, B8.sqkv, Bk.bqkv, nullptr, w.qkv, 3 * QK, C, 0, EPI_NONE, q8 && (c.prenorm || x8_valid)));
-        TransposeVArgs tv{w.qkv + 2 * QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK, w.vt, Bn, Hh, N, VIT_DP, npad};
-        TRY(cx, launch_transpose_v(tv, s));
+        // one image, bf16: the V heads leave the qkv projection key-contiguous (GemmArgs::vt_*, round 3's UNet epilogue; the
+        // transposed staging takes a single batch element's ragged last tile since round 4) -- no transpose launch
+        const bool fvt = m->fuse_vt && Bn == 1 && !B8.wqkv;
+        if (fvt) {
+            GemmArgs gq{ain, Bk.wqkv, Bk.bqkv, nullptr, w.qkv, M, 3 * QK, C, C, C, 0, 3 * QK, EPI_NONE, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+            gq.partial = w.splitk; gq.partial_floats = w.splitk_floats;
+            gq.vt_out = w.vt; gq.vt_col0 = 2 * QK; gq.vt_s = N; gq.vt_spad = npad;
+            TRY(cx, launch_gemm(gq, s));
+        } else {
+            TRY(cx, lin(ain, Bk.wqkv, B8.wqkv, B8.sqkv, Bk.bqkv, nullptr, w.qkv, 3 * QK, C, 0, EPI_NONE, q8 && (c.prenorm || x8_valid)));
+            TransposeVArgs tv{w.qkv + 2 * QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK, w.vt, Bn, Hh, N, VIT_DP, npad};
+            TRY(cx, launch_transpose_v(tv, s));
+        }
         FlashArgs f{w.qkv, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
                     w.qkv + QK, (long)N * 3 * QK, (long)VIT_DP, (long)3 * QK,
                     w.vt, w.attn, (long)N * QK, (long)VIT_DP, (long)QK, nullptr,

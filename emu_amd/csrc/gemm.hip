@@ -525,7 +525,9 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
 #pragma unroll
                 for (int j = 0; j < T::MF; ++j) {
                     const int row = (wm * T::MF + j) * 32 + l31, m = m0 + row;
-                    if (m >= a.M) continue;
+                    // (rows beyond M of a transposed V^T tile are staged too: copies of row M - 1, finite, landing in the pad keys of
+                    // the last 8-key group that StageT::store writes -- never whatever the dead k-tile ring held)
+                    if (m >= a.M && !((FX & FX_VT) != 0 && vt_tile)) continue;
                     if (a.bias2) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {

@@ -559,10 +559,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
                 const int row = wc * 64 + y * 32 + l31, m = m0 + row;
-                if (m >= a.M) continue;
+                if (m >= a.M && !((FX & FX_VT) != 0 && vt_tile)) continue;     // (see gemm.hip: pad keys of a V^T tile stay finite)
                 RowFx& fx = rowfx[y];
                 float sa = 1.f;
-                if constexpr (F8) sa = a.a_scale[m];
+                if constexpr (F8) sa = a.a_scale[m < a.M ? m : a.M - 1];
                 if (a.bias2) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)

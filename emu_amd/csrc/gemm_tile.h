@@ -315,7 +315,7 @@ struct EpiStage {
 // at vt_out[(b * (N - vt_col0) + n - vt_col0) * vt_spad + s], key-contiguous): the tile sits in LDS as [n][m], every lane drops its
 // 4 values as 2-byte writes (32 lanes = 32 consecutive m of one n: 64 contiguous bytes), and it leaves as 16-byte stores of 8
 // consecutive keys -- against 64 two-byte global stores per lane straight from the accumulators (traced: those tiles' epilogue
-// 6.7-10 us where the others take 3-4).  Needs whole tiles inside one batch element (vt_s % BMv == 0).
+// 6.7-10 us where the others take 3-4).  Needs whole tiles inside one batch element (vt_s % BMv == 0) or a single batch element.
 template <int BMv, int BNv, int THREADS>
 struct EpiStageT {
     static constexpr int ROWB = BMv * 2, SLOTS = ROWB / 16, KEYM = SLOTS >= 16 ? 15 : SLOTS - 1;
@@ -341,7 +341,10 @@ struct EpiStageT {
 };
 // may the V^T tiles of this launch take the transposed staging? (host side)
 inline bool stage_vt_ok(const GemmArgs& a, int bm, int bn) {
-    return a.vt_out && a.vt_s % bm == 0 && (a.vt_col0 % bn) == 0 && !(a.vt_spad & 7) && !((uintptr_t)a.vt_out & 15) && a.M % bm == 0;
+    // whole tiles inside one batch element -- or ONE batch element (vt_s == M: the ViT's 1025 tokens), whose ragged last tile
+    // writes a few pad keys (< 8, inside vt_spad) along with its last 8-key group
+    const bool one = a.vt_s == a.M && a.vt_spad >= (a.M + 7) / 8 * 8;
+    return a.vt_out && (one || (a.vt_s % bm == 0 && a.M % bm == 0)) && (a.vt_col0 % bn) == 0 && !(a.vt_spad & 7) && !((uintptr_t)a.vt_out & 15);
 }
 
 // host side: may this launch take the staged epilogue?  16-byte alignment of C (and the residual) rows; the kernels add the

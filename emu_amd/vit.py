@@ -152,6 +152,10 @@ class VitEngine:
                 a += [q.data_ptr(), sc.data_ptr()]
             check(lib().emu_vit_set_block_fp8(self.handle, i, *a), "emu_vit_set_block_fp8", self.ctx.handle)
 
+    def set_fusion(self, mask: int) -> None:
+        """Launch fusions of the blocks (bit 0: V^T from the qkv projection's epilogue for a single image); 0 = unfused."""
+        check(lib().emu_vit_set_fusion(self.handle, int(mask)), "emu_vit_set_fusion", self.ctx.handle)
+
     def use_fp8(self, enable: bool = True) -> None:
         """Run the blocks' GEMMs W8A8 on the block-scaled fp8 MFMA (activation rows quantised per row ahead of every GEMM);
         LayerNorm, attention and the patch embedding stay bf16."""

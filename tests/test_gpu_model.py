@@ -448,6 +448,35 @@ def test_true_width_prefill_rope_epilogue_bit_identical(S):
         assert torch.equal(u, v) and torch.equal(u, w)
 
 
+@pytest.mark.parametrize("image,postnorm,width,head_width", [(448, True, 1792, 112), (224, False, 1408, 88), (56, True, 256, 64)])
+def test_vit_vt_epilogue_bit_identical(image, postnorm, width, head_width):
+    """Round 4: with one image the V heads leave the encoder's qkv projection key-contiguous (the UNet's V^T epilogue, whose
+    transposed LDS staging now takes a single batch element's ragged last tile: 1025 / 257 / 17 tokens) instead of a transpose
+    launch.  Same values; the pad keys differ (copies of the last row instead of zeros) and meet masked probabilities only:
+    the encoder's tokens must be BIT-identical, for EVA-CLIP-4B (Emu2), EVA-CLIP-g (Emu1, pre-norm) and a small shape; two
+    images in one call take the transpose launch as before."""
+    from emu_amd import CLIPVisionCfg, synth
+    from emu_amd.llama import EmuHipContext
+    from emu_amd.vit import VitEngine
+    v = CLIPVisionCfg(layers=2, image_size=image, postnorm=postnorm, width=width, head_width=head_width,
+                      mlp_ratio=15360 / 1792 if width == 1792 else 4.0)
+    vit = VitEngine(v, EmuHipContext(torch.device("cuda", 0)))
+    vit.load_weights(synth.iter_synth(synth.vit_param_shapes(v), seed=5, device="cuda", dtype=BF16))
+    g = torch.Generator().manual_seed(image)
+    img = torch.randn(2, 3, image, image, generator=g).to(BF16).cuda()
+    fused = vit(img[:1]).clone()
+    both = vit(img).clone()
+    vit.set_fusion(0)
+    try:
+        plain = vit(img[:1]).clone()
+        both0 = vit(img).clone()
+    finally:
+        vit.set_fusion(1)
+    assert bool(torch.isfinite(fused.float()).all())
+    assert torch.equal(fused, plain)
+    assert torch.equal(both, both0)                      # (two images: another M, another tile dispatch -- not comparable bit for bit with one)
+
+
 def test_true_width_five_beam_step_against_oracle_and_single_rows():
     """The reference's default decoding mode at the decoder's true width: one LLaMA-33B-shaped layer, a 300-token prompt, 5 beams
     that share the prompt's cache row and feed five different tokens -- the step runs the 5-row LDS-DMA + MFMA weight streams
