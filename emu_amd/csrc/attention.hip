@@ -123,7 +123,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void flash_kernel(const F
     // XCD owns a run of consecutive (head, query block) pairs -- whole heads where the counts allow: K / V cross the fabric once.
     const int nq = (a.Sq + QB - 1) / QB, total = nq * a.H * a.B;
     int lin = blockIdx.x;
-    if (a.xcd_remap) {
+    if (a.heavy_first) {
+        // causal prefill: a query block's work grows with its index (2 .. 13 key tiles at S = 770), and a long block that starts
+        // late IS the kernel's tail.  Every XCD owns whole heads (H * B heads dealt 7,7,..,6,6 over the 8 XCDs; the grid is padded
+        // to 8 x ceil(heads / 8) x nq blocks, surplus blocks leave at once) and walks them query-block-major from the LAST block
+        // down: its 32 CUs start on the long blocks, the short ones fill in behind.  K / V of a head still stay in one L2.
+        const int xcd = lin & 7, j = lin >> 3, heads = a.H * a.B, hq = heads >> 3, hr = heads & 7;
+        const int mine = hq + (xcd < hr ? 1 : 0), first = xcd * hq + (xcd < hr ? xcd : hr);
+        if (j >= mine * nq) return;
+        lin = (first + j % mine) * nq + (nq - 1 - j / mine);
+    } else if (a.xcd_remap) {
         const int xcd = lin & 7, q8 = total >> 3, r8 = total & 7;
         lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
     }
@@ -421,7 +430,10 @@ int launch_flash_attn(const FlashArgs& a, hipStream_t s) {
     bool w8 = a.D == 64 && wg4 > 256 && wg4 <= 400 && a.Sq >= 256;
     if (((tune >> 12) & 3) == 1) w8 = false;
     if (((tune >> 12) & 3) == 2) w8 = a.D == 64;
-    const dim3 grid(w8 ? ((a.Sq + 255) / 256) * a.H * a.B : wg4), block(w8 ? 512 : 256);
+    // causal launches of more than one round's worth of unequal blocks: longest query blocks first (flash_kernel: heavy_first)
+    b.heavy_first = a.causal && !w8 && a.Sq >= 256 && wg4 > 256 && !(tune & (1 << 15));
+    const int nqb = (a.Sq + 127) / 128;
+    const dim3 grid(w8 ? ((a.Sq + 255) / 256) * a.H * a.B : (b.heavy_first ? 8 * ((a.H * a.B + 7) / 8) * nqb : wg4)), block(w8 ? 512 : 256);
     const bool prof = emu_prof_on();
     if (prof) emu_prof_begin(s);
     if (a.D == 128) hipLaunchKernelGGL((flash_kernel<128, 4>), grid, block, 0, s, b);

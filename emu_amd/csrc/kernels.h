@@ -192,6 +192,7 @@ struct FlashArgs {
     float scale;
     int xcd_remap = 1;                         // set by launch_flash_attn: XCD-aware (head, query block) order
     int stage_o = 0;                           // set by launch_flash_attn: O leaves through LDS as 16-byte row-contiguous stores
+    int heavy_first = 0;    // set by launch_flash_attn: causal prefill, XCDs walk their heads' query blocks from the longest down
 };
 int launch_flash_attn(const FlashArgs& a, hipStream_t s);
 

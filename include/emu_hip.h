@@ -75,7 +75,9 @@ void emu_gemm_force_config(int cfg);
  * 16-byte form; bit 4: the lock-step tiles keep the column-major XCD runs instead of 2-D tile blocks per XCD; bit 5: no 128 x 128
  * tile for one-round problems; bit 6: the attention kernel deals its workgroups in launch order (query blocks of a head on 8
  * different XCDs); bit 7: it stores O straight from the accumulator layout; bits 12-13: 1 / 2 = attention always on 4 / 8 waves;
- * bit 14: V^T tiles of a fused qkv projection stored straight from the accumulators instead of through the transposed staging; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
+ * bit 14: V^T tiles of a fused qkv projection stored straight from the accumulators instead of through the transposed staging; bit 15:
+ * causal attention launches keep the (head, query block) order instead of walking every XCD's heads from the longest query block
+ * down; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
 void emu_gemm_tune(int mask);
 
 /* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at

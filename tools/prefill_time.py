@@ -17,6 +17,9 @@ l = LlamaCfg()
 V = 32274
 eng = LlamaEngine(l, V, EmuHipContext(dev))
 eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device=dev, dtype=torch.bfloat16))
+if os.environ.get("EMU_TUNE"):                        # A/B switches of single dispatch decisions (include/emu_hip.h: emu_gemm_tune)
+    from emu_amd._lib import lib
+    lib().emu_gemm_tune(int(os.environ["EMU_TUNE"]))
 if os.environ.get("EMU_PREFILL_FUSION") == "0":      # A/B: the rope_kv + transpose_v launches instead of the qkv epilogue
     eng.set_prefill_fusion(False)
 x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
@@ -36,4 +39,4 @@ with torch.no_grad():
         run()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t) * 1e3)
-print(f"prefill S={S}{' (hipGraph replay)' if graph else ''}{'' if eng.prefill_fusion else ' (rope_kv + transpose_v launches)'}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [{os.environ.get('EMU_TMP_FORCE', '')}]", flush=True)
+print(f"prefill S={S}{' (hipGraph replay)' if graph else ''}{'' if eng.prefill_fusion else ' (rope_kv + transpose_v launches)'}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [tune {os.environ.get('EMU_TUNE', '0')}]", flush=True)
