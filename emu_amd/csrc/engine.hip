@@ -425,6 +425,21 @@ int linear_q8(const LlamaWs& w, const bf16_t* A, int lda, const uint8_t* W8, con
     g.partial = w.splitk; g.partial_floats = w.splitk_floats;
     return launch_gemm_fp8(g, s);
 }
+// C = epi(A W^T [+ res]) followed by xn = RMSNorm(C) * gain: one row-wise slice-sum launch where the 256x256 tile K-slices every
+// tile of the GEMM (GemmArgs::norm_*; launch_gemm answers -95 otherwise), else the GEMM and the rmsnorm launch apart.  Same bits.
+int linear_then_rmsnorm(const LlamaWs& w, const bf16_t* A, const bf16_t* W, const bf16_t* res, bf16_t* C, int M, int N, int K, int epi,
+                        const bf16_t* gain, bf16_t* xn, float eps, bool fuse, hipStream_t s) {
+    if (fuse && M > 16) {
+        GemmArgs g{A, W, nullptr, res, C, M, N, K, K, K, N, N, epi, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+        g.partial = w.splitk; g.partial_floats = w.splitk_floats;
+        g.norm_w = gain; g.norm_out = xn; g.norm_ld = N; g.norm_eps = eps;
+        const int st = launch_gemm(g, s);
+        if (st != -95) return st;
+    }
+    int st = linear(A, W, nullptr, res, nullptr, C, M, N, K, K, K, N, N, 0.f, epi, s, nullptr, w.splitk, w.splitk_floats);
+    if (st) return st;
+    return launch_rmsnorm(C, gain, xn, M, N, N, N, eps, s);
+}
 }  // namespace
 
 extern "C" {
@@ -534,6 +549,10 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     // never written on that path: zeroed once per call (the attention kernel multiplies them by masked probabilities).
     bool fuse_rope = m->prefill_fusion && Bn == 1 && T > 16 && T == ctx && D == 128 && !(HD & 255) && !m->fp8_prefill && m->kv_share_nb <= 1;
     if (fuse_rope && hipMemsetAsync(w.vt, 0, (size_t)HD * spad * 2, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
+    // (prefill fusion, no tensor parallelism: the K-slice sums of o_proj / down_proj apply the RMSNorm that follows them; for
+    // down_proj that is the NEXT layer's input norm, so a layer may find its normalised rows in w.xn already)
+    const bool fuse_norm = m->prefill_fusion && !tp && M > 16 && !m->fp8_prefill;
+    bool xn_ready = false;
     for (int l = m->l0; l < l_end; ++l) {
         const emu_llama::Layer& L = m->layers[l];
         if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
@@ -551,7 +570,8 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         } else if (M == 1) {
             TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, M, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
         } else {                                     // 2..16 rows: norm once, skinny MFMA stream; more: GEMM
-            TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
+            if (!xn_ready) TRY(cx, launch_rmsnorm(hA, L.ln1, w.xn, M, H, H, H, c.rms_eps, s));
+            xn_ready = false;
             if (f8p) TRY(cx, linear_q8(w, w.xn, H, m->layers8[l].wqkv, m->layers8[l].sqkv, nullptr, w.qkv, M, 3 * HD, H, 0, 3 * HD, EPI_NONE, s));
             else {
                 int st = -95;
@@ -590,6 +610,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         }
         if (f8) TRY(cx, linear(w.attn, B(L8.wo), nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, L8.so));
         else if (f8p) TRY(cx, linear_q8(w, w.attn, HD, m->layers8[l].wo, m->layers8[l].so, hA, w.hB, M, H, HD, H, H, epi_res, s));
+        else if (fuse_norm) TRY(cx, linear_then_rmsnorm(w, w.attn, L.wo, hA, w.hB, M, H, HD, epi_res, L.ln2, w.xn, c.rms_eps, true, s));
         else TRY(cx, linear(w.attn, L.wo, nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, nullptr, w.splitk, w.splitk_floats));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, w.hB, (size_t)M * H, s_));
         // ---- SwiGLU MLP
@@ -598,12 +619,16 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         } else if (M == 1) {
             TRY(cx, linear(w.hB, L.wgu, nullptr, nullptr, L.ln2, w.act, M, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s));
         } else {
-            TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
+            if (!fuse_norm) TRY(cx, launch_rmsnorm(w.hB, L.ln2, w.xn, M, H, H, H, c.rms_eps, s));
             if (f8p) TRY(cx, linear_q8(w, w.xn, H, m->layers8[l].wgu, m->layers8[l].sgu, nullptr, w.act, M, 2 * Fl, H, 0, Fl, EPI_SWIGLU, s));
             else TRY(cx, linear(w.xn, L.wgu, nullptr, nullptr, nullptr, w.act, M, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, s, nullptr, w.splitk, w.splitk_floats));
         }
         if (f8) TRY(cx, linear(w.act, B(L8.wdown), nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, L8.sdown));
         else if (f8p) TRY(cx, linear_q8(w, w.act, Fl, m->layers8[l].wdown, m->layers8[l].sdown, w.hB, hA, M, H, Fl, H, H, epi_res, s));
+        else if (fuse_norm && l + 1 < l_end && m->layers[l + 1].ln1) {
+            TRY(cx, linear_then_rmsnorm(w, w.act, L.wdown, w.hB, hA, M, H, Fl, epi_res, m->layers[l + 1].ln1, w.xn, c.rms_eps, true, s));
+            xn_ready = true;
+        }
         else TRY(cx, linear(w.act, L.wdown, nullptr, w.hB, nullptr, hA, M, H, Fl, Fl, Fl, H, H, 0.f, epi_res, s, nullptr, w.splitk, w.splitk_floats));
         if (tp) TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)M * H, s_));
     }

@@ -842,6 +842,19 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         }
         return -22;
     }
+    if (a.norm_w) {
+        // slice sum + the following RMSNorm in one row-wise launch: only where the 256x256 tile K-slices EVERY tile of the problem
+        // (fewer tiles than CUs: S = 770 o_proj / down_proj) and the row-major slices fit the scratch; -95 = run GEMM and rmsnorm apart
+        if constexpr ((EPI == EPI_NONE || EPI == EPI_RESID) && !CONV) {
+            const PpPlan pp = pick_pp(a);
+            if (!gemm256_ok(a) || !pp.use || pp.ksplit < 2 || pp.full_tiles != 0 || (a.N & 7) || a.N > 16384 ||
+                (size_t)pp.ksplit * a.M * a.N > a.partial_floats)
+                return -95;
+            a.slab_rows = 1;
+            return launch_gemm256(a, s, 0, pp.ksplit);
+        }
+        return -22;
+    }
     int cfg = g_force_cfg;
     const bool k64 = (a.K & 63) == 0;
     if (cfg == 'S' && !k64) cfg = 0;
@@ -1017,6 +1030,9 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t s) {
     if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
     if (a.row_stats_out && ((a.N & 127) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
+    if (a.norm_w && (!a.norm_out || (a.norm_ld & 7) || a.norm_ld < a.N || a.bias || a.bias2 || gemm_fx(a) || a.conv.mode != CONV_NONE ||
+                     (a.epi != EPI_NONE && a.epi != EPI_RESID) || (a.ldc & 7) || (a.epi == EPI_RESID && (a.ldres & 7))))
+        return -22;
     if (a.rope_cos) {                                  // RoPE + KV append + V^T epilogue of the LLaMA prefill's qkv projection
         const int hd = a.rope_hl * 128;
         if (!a.rope_sin || !a.rope_pos || !a.rope_slot || !a.rope_kc || !a.rope_vc || !a.vt_out || a.rope_hl < 1 || a.N != 3 * hd ||

@@ -111,6 +111,16 @@ struct GemmArgs {
     bf16_t* rope_kc = nullptr;          // [rope_hl, rope_smax, 128] of this layer and batch element
     bf16_t* rope_vc = nullptr;
     int rope_hl = 0, rope_smax = 0;
+    // ---- K-sliced GEMM whose slice sum also applies the RMSNorm that follows (LLaMA prefill: o_proj -> post-attention norm,
+    // down_proj -> the next layer's input norm; 256x256 tile with EVERY tile K-sliced): the fp32 slices are laid out row-major
+    // over the whole output (partial[(ks * M + m) * N + n], slab_rows = 1) and ONE workgroup per row sums them in slice order,
+    // applies the epilogue (C), and writes norm_out = bf16(norm_w * bf16(C * rsqrt(mean(C^2) + eps))) with rmsnorm_kernel's
+    // arithmetic -- the reduce launch and the rmsnorm launch in one, bit-identical to the pair.
+    const bf16_t* norm_w = nullptr;     // [N]
+    bf16_t* norm_out = nullptr;         // [M, norm_ld]
+    int norm_ld = 0;
+    float norm_eps = 0.f;
+    int slab_rows = 0;                  // set by launch_gemm
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // tools hook: where the next GEMM launches of a -DEMU_TRACE build write their per-workgroup timelines (nullptr = off)
