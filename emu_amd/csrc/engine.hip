@@ -715,6 +715,7 @@ struct emu_vit {
     std::vector<Block8> blocks8;
     bool fp8 = false;
     bool fuse_vt = true;                             // emu_vit_set_fusion bit 0: V^T out of the qkv projection's epilogue (one image)
+    bool fuse_norm = true;                           // bit 1: fc2's K-slice sum applies bias + LayerNorm + residual (post-norm blocks)
 };
 
 namespace {
@@ -790,6 +791,7 @@ int emu_vit_set_block_fp8(emu_vit* m, int layer, const void* wqkv8, const float*
 int emu_vit_set_fusion(emu_vit* m, int mask) {
     if (!m) return -22;
     m->fuse_vt = (mask & 1) != 0;
+    m->fuse_norm = (mask & 2) != 0;
     return 0;
 }
 int emu_vit_use_fp8(emu_vit* m, int enable) {
@@ -870,9 +872,21 @@ static int vit_blocks(emu_vit* m, bf16_t* x, int Bn, int l0, int l1, const VitWs
             if (q8) TRY(cx, launch_layernorm_q8(w.tmp, Bk.ln1w, Bk.ln1b, x, x, w.x8, w.xs, M, C, c.ln_eps, s));
             else TRY(cx, launch_layernorm(w.tmp, Bk.ln1w, Bk.ln1b, x, x, M, C, c.ln_eps, s));
             TRY(cx, lin(x, Bk.fc1w, B8.fc1w, B8.sfc1, Bk.fc1b, nullptr, w.h1, F, C, 0, EPI_GELU, q8));
-            TRY(cx, lin(w.h1, Bk.fc2w, B8.fc2w, B8.sfc2, Bk.fc2b, nullptr, w.tmp, C, F, 0, EPI_NONE));
-            if (q8) TRY(cx, launch_layernorm_q8(w.tmp, Bk.ln2w, Bk.ln2b, x, x, w.x8, w.xs, M, C, c.ln_eps, s));   // the next block's qkv rows
-            else TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+            // bf16: fc2 is a K-sliced GEMM (28 big tiles, K = 15360): its slice sum applies bias, LayerNorm and the residual add
+            // row-wise in the same launch (GemmArgs::norm_*; -95 = this shape is not sliced that way: the launches apart)
+            int st2 = -95;
+            if (m->fuse_norm && !B8.fc2w) {
+                GemmArgs gf{w.h1, Bk.fc2w, Bk.fc2b, nullptr, nullptr, M, C, F, F, F, 0, C, EPI_NONE, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+                gf.partial = w.splitk; gf.partial_floats = w.splitk_floats;
+                gf.norm_w = Bk.ln2w; gf.norm_b = Bk.ln2b; gf.norm_res = x; gf.norm_ldres = C; gf.norm_out = x; gf.norm_ld = C; gf.norm_eps = c.ln_eps;
+                st2 = launch_gemm(gf, s);
+                if (st2 != 0 && st2 != -95) return fail(cx, st2, "emu_vit_forward: fc2 with the LayerNorm slice sum");
+            }
+            if (st2 == -95) {
+                TRY(cx, lin(w.h1, Bk.fc2w, B8.fc2w, B8.sfc2, Bk.fc2b, nullptr, w.tmp, C, F, 0, EPI_NONE));
+                if (q8) TRY(cx, launch_layernorm_q8(w.tmp, Bk.ln2w, Bk.ln2b, x, x, w.x8, w.xs, M, C, c.ln_eps, s));   // the next block's qkv rows
+                else TRY(cx, launch_layernorm(w.tmp, Bk.ln2w, Bk.ln2b, x, x, M, C, c.ln_eps, s));
+            }
             x8_valid = q8;
         }
     }

@@ -593,8 +593,9 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
                 if (nsl > 1) {                         // raw fp32 slice tile; splitk_reduce_kernel applies the epilogue
-                    float* dst = a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * (T::BMv * T::BNv) +
-                                 (size_t)(m - m0) * T::BNv + (nb - n0);
+                    float* dst = a.slab_rows ? a.partial + ((size_t)ks * a.M + m) * a.N + nb     // row-major slices: rows_reduce_norm_kernel
+                                             : a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * (T::BMv * T::BNv) +
+                                                   (size_t)(m - m0) * T::BNv + (nb - n0);
                     *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
                 } else {
                     store_quad<EPI, FX>(a, m, nb, v, rows[j], qin[g]);
@@ -709,7 +710,8 @@ void launch_cfg(const GemmArgs& a, hipStream_t s, int full_tiles = -1, int kspli
         return;
     }
     hipLaunchKernelGGL((gemm2_kernel<EPI, CONV, T>), dim3(b.full_tiles + tail * ksplit), dim3(T::THREADS), 0, s, b);
-    if (tail > 0)
+    if (tail > 0 && b.slab_rows) launch_rows_reduce_norm(b, s);        // launch_v2: every tile sliced, slices row-major
+    else if (tail > 0)
         hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T::BMv, T::BNv>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }
 
@@ -846,12 +848,22 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
         // slice sum + the following RMSNorm in one row-wise launch: only where the 256x256 tile K-slices EVERY tile of the problem
         // (fewer tiles than CUs: S = 770 o_proj / down_proj) and the row-major slices fit the scratch; -95 = run GEMM and rmsnorm apart
         if constexpr ((EPI == EPI_NONE || EPI == EPI_RESID) && !CONV) {
+            if ((a.N & 7) || a.N > 16384) return -95;
             const PpPlan pp = pick_pp(a);
-            if (!gemm256_ok(a) || !pp.use || pp.ksplit < 2 || pp.full_tiles != 0 || (a.N & 7) || a.N > 16384 ||
-                (size_t)pp.ksplit * a.M * a.N > a.partial_floats)
-                return -95;
+            if (gemm256_ok(a) && pp.use) {
+                if (pp.ksplit < 2 || pp.full_tiles != 0 || (size_t)pp.ksplit * a.M * a.N > a.partial_floats) return -95;
+                a.slab_rows = 1;
+                return launch_gemm256(a, s, 0, pp.ksplit);
+            }
+            // the K-sliced 256 x 128 lock-step tile (ViT fc2): all of its tiles are slices
+            if (pick_lockstep<EPI, CONV>(a) != 'S') return -95;
+            const int tc = tiles_of(a, 256, 128);
+            const int ksplit = pick_ksplit<EPI>(a, tc, 256 * 128, 24);
+            if (ksplit < 2 || (size_t)ksplit * a.M * a.N > a.partial_floats) return -95;
             a.slab_rows = 1;
-            return launch_gemm256(a, s, 0, pp.ksplit);
+            launch_cfg<EPI, CONV, CfgC>(a, s, 0, ksplit);
+            EMU_CHECK_LAUNCH();
+            return 0;
         }
         return -22;
     }
@@ -1030,8 +1042,9 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t s) {
     if (a.ln_c && (!a.ln_d || !a.ln_stats || a.ln_slots < 1 || a.ln_slots > LN_MAX_SLOTS || a.bias || (a.N & 3) || (a.ldc & 3) || a.conv.mode != CONV_NONE)) return -22;
     if (a.row_stats_out && ((a.N & 127) || (a.ldc & 3) || (a.epi != EPI_NONE && a.epi != EPI_RESID) ||
                             (a.epi == EPI_RESID && (a.ldres & 3)))) return -22;
-    if (a.norm_w && (!a.norm_out || (a.norm_ld & 7) || a.norm_ld < a.N || a.bias || a.bias2 || gemm_fx(a) || a.conv.mode != CONV_NONE ||
-                     (a.epi != EPI_NONE && a.epi != EPI_RESID) || (a.ldc & 7) || (a.epi == EPI_RESID && (a.ldres & 7))))
+    if (a.norm_w && (!a.norm_out || (a.norm_ld & 7) || a.norm_ld < a.N || a.bias2 || gemm_fx(a) || a.conv.mode != CONV_NONE ||
+                     (a.epi != EPI_NONE && a.epi != EPI_RESID) || (a.C && (a.ldc & 7)) || (a.epi == EPI_RESID && (a.ldres & 7)) ||
+                     (!a.C && !a.norm_b) || (a.norm_res && (!a.norm_b || (a.norm_ldres & 7)))))
         return -22;
     if (a.rope_cos) {                                  // RoPE + KV append + V^T epilogue of the LLaMA prefill's qkv projection
         const int hd = a.rope_hl * 128;

@@ -751,57 +751,6 @@ __global__ __launch_bounds__(256) void pp_reduce_kernel(const GemmArgs a) {
     }
 }
 
-// Second launch of a run whose EVERY tile was K-sliced into row-major slices (GemmArgs::slab_rows): one workgroup per output
-// row sums the slices in slice order, applies the (bias-free) EPI_NONE / EPI_RESID epilogue with pp_reduce_kernel's rounding
-// points, keeps the row's bf16 values in registers and writes the RMSNorm of the row beside it -- rmsnorm_kernel's arithmetic
-// and summation order (thread t owns the 16-byte vectors t, t + 256, ...), so C and norm_out are bit-identical to the two
-// launches this replaces (LLaMA prefill: 120 reduce + 120 rmsnorm launches per S = 770 prefill).
-template <int NV>
-__global__ __launch_bounds__(256) void pp_rows_reduce_norm_kernel(const GemmArgs a) {
-    __shared__ float scratch[4];
-    const int m = blockIdx.x, nv = a.N >> 3, tid = threadIdx.x;
-    float f[NV][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = tid + i * 256;
-        if (vi < nv) {
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < a.ksplit; ++ks) {
-                const float* src = a.partial + ((size_t)ks * a.M + m) * a.N + vi * 8;
-                const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(src), t1 = *reinterpret_cast<const f32x4_t*>(src + 4);
-                v[0] += t0[0]; v[1] += t0[1]; v[2] += t0[2]; v[3] += t0[3];
-                v[4] += t1[0]; v[5] += t1[1]; v[6] += t1[2]; v[7] += t1[3];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = bfround(v[j]);
-            if (a.epi == EPI_RESID) {
-                float r[8];
-                unpack8(ld16(a.res + (size_t)m * a.ldres + vi * 8), r);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += r[j];
-            }
-            const u32x4 hv = pack8(v);
-            st16(a.C + (size_t)m * a.ldc + vi * 8, hv);
-            unpack8(hv, f[i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
-        }
-    }
-    const float rinv = rsqrtf(block_sum<4>(ss, scratch) / (float)a.N + a.norm_eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = tid + i * 256;
-        if (vi < nv) {
-            float g[8], o[8];
-            unpack8(ld16(a.norm_w + vi * 8), g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = g[j] * bfround(f[i][j] * rinv);
-            st16(a.norm_out + (size_t)m * a.norm_ld + vi * 8, pack8(o));
-        }
-    }
-}
-
 template <int EPI, bool CONV, bool F8 = false>
 void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     const int tiles = gemm256_tiles(a);
@@ -830,10 +779,8 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
         return;
     }
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
-    if (tail > 0 && b.slab_rows) {                      // launch_v2: every tile sliced, bf16, bias-free, N <= 16384
-        if (b.N <= 8192) hipLaunchKernelGGL((pp_rows_reduce_norm_kernel<4>), dim3(b.M), dim3(256), 0, s, b);
-        else hipLaunchKernelGGL((pp_rows_reduce_norm_kernel<8>), dim3(b.M), dim3(256), 0, s, b);
-    } else if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
+    if (tail > 0 && b.slab_rows) launch_rows_reduce_norm(b, s);     // launch_v2: every tile sliced, bf16, N <= 16384 (gemm_tile.h)
+    else if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }
 
 }  // namespace

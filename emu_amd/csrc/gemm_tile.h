@@ -403,6 +403,109 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs a) {
     }
 }
 
+// Second launch of a run whose EVERY tile was K-sliced into row-major slices (GemmArgs::slab_rows): one workgroup per output
+// row sums the slices in slice order, applies the EPI_NONE / EPI_RESID epilogue (bias, bf16 rounding, residual: the reduce
+// kernels' rounding points), keeps the row's bf16 values in registers and writes the norm of the row: RMSNorm with
+// rmsnorm_kernel's arithmetic (norm_b null), or LayerNorm (+ residual) with layernorm_kernel's -- same summation order (thread t
+// owns the 16-byte vectors t, t + 256, ...), so C and norm_out are bit-identical to the two launches this replaces (LLaMA
+// prefill: o_proj / down_proj + RMSNorm; ViT: fc2 + LayerNorm + residual).
+template <int NV>
+__global__ __launch_bounds__(256) void rows_reduce_norm_kernel(const GemmArgs a) {
+    __shared__ float scratch[4];
+    const int m = blockIdx.x, nv = a.N >> 3, tid = threadIdx.x;
+    float f[NV][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = tid + i * 256;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+        if (vi < nv) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const float* src = a.partial + ((size_t)ks * a.M + m) * a.N + vi * 8;
+                const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(src), t1 = *reinterpret_cast<const f32x4_t*>(src + 4);
+                v[0] += t0[0]; v[1] += t0[1]; v[2] += t0[2]; v[3] += t0[3];
+                v[4] += t1[0]; v[5] += t1[1]; v[6] += t1[2]; v[7] += t1[3];
+            }
+            if (a.bias) {
+                float bb[8];
+                unpack8(ld16(a.bias + vi * 8), bb);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += bb[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bfround(v[j]);
+            if (a.epi == EPI_RESID) {
+                float r[8];
+                unpack8(ld16(a.res + (size_t)m * a.ldres + vi * 8), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += r[j];
+            }
+            const u32x4 hv = pack8(v);
+            if (a.C) st16(a.C + (size_t)m * a.ldc + vi * 8, hv);
+            unpack8(hv, f[i]);
+            if (a.norm_b) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[i][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
+            }
+        }
+    }
+    if (!a.norm_b) {                                   // RMSNorm (rmsnorm_kernel)
+        const float rinv = rsqrtf(block_sum<4>(ss, scratch) / (float)a.N + a.norm_eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = tid + i * 256;
+            if (vi < nv) {
+                float g[8], o[8];
+                unpack8(ld16(a.norm_w + vi * 8), g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = g[j] * bfround(f[i][j] * rinv);
+                st16(a.norm_out + (size_t)m * a.norm_ld + vi * 8, pack8(o));
+            }
+        }
+        return;
+    }
+    // LayerNorm (+ residual) (layernorm_kernel)
+    const float mean = block_sum<4>(ss, scratch) / (float)a.N;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = tid + i * 256;
+        if (vi < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[i][j] - mean; var += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum<4>(var, scratch) / (float)a.N + a.norm_eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = tid + i * 256;
+        if (vi < nv) {
+            float g[8], bb[8], o[8];
+            unpack8(ld16(a.norm_w + vi * 8), g);
+            unpack8(ld16(a.norm_b + vi * 8), bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * g[j] + bb[j];
+            if (a.norm_res) {
+                float r[8];
+                unpack8(ld16(a.norm_res + (size_t)m * a.norm_ldres + vi * 8), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = r[j] + bfround(o[j]);
+            }
+            st16(a.norm_out + (size_t)m * a.norm_ld + vi * 8, pack8(o));
+        }
+    }
+}
+inline void launch_rows_reduce_norm(const GemmArgs& b, hipStream_t s) {
+    if (b.N <= 2048) hipLaunchKernelGGL((rows_reduce_norm_kernel<1>), dim3(b.M), dim3(256), 0, s, b);
+    else if (b.N <= 8192) hipLaunchKernelGGL((rows_reduce_norm_kernel<4>), dim3(b.M), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((rows_reduce_norm_kernel<8>), dim3(b.M), dim3(256), 0, s, b);
+}
+
 // the feature mask of a launch (host side: picks the FX instantiation), and the (epilogue, mask) pairs that are instantiated:
 // what the UNet transformer blocks launch -- proj_in / to_q producers and consumers, the qkv projection (+ V^T), the residual
 // out-projections and ff-out as producers, the GEGLU projection as a consumer

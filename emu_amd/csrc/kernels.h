@@ -115,8 +115,12 @@ struct GemmArgs {
     // down_proj -> the next layer's input norm; 256x256 tile with EVERY tile K-sliced): the fp32 slices are laid out row-major
     // over the whole output (partial[(ks * M + m) * N + n], slab_rows = 1) and ONE workgroup per row sums them in slice order,
     // applies the epilogue (C), and writes norm_out = bf16(norm_w * bf16(C * rsqrt(mean(C^2) + eps))) with rmsnorm_kernel's
-    // arithmetic -- the reduce launch and the rmsnorm launch in one, bit-identical to the pair.
+    // arithmetic -- the reduce launch and the rmsnorm launch in one, bit-identical to the pair.  The K-sliced 256 x 128 lock-step
+    // tile has the same form (ViT fc2 -> LayerNorm + residual).
     const bf16_t* norm_w = nullptr;     // [N]
+    const bf16_t* norm_b = nullptr;     // [N] or null.  Non-null: LayerNorm (layernorm_kernel's arithmetic) instead of RMSNorm, and
+    const bf16_t* norm_res = nullptr;   //   norm_out = bf16(norm_res + bf16(LN(C))) when norm_res is set (ViT post-norm block); C may be null then
+    int norm_ldres = 0;
     bf16_t* norm_out = nullptr;         // [M, norm_ld]
     int norm_ld = 0;
     float norm_eps = 0.f;

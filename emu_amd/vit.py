@@ -153,7 +153,8 @@ class VitEngine:
             check(lib().emu_vit_set_block_fp8(self.handle, i, *a), "emu_vit_set_block_fp8", self.ctx.handle)
 
     def set_fusion(self, mask: int) -> None:
-        """Launch fusions of the blocks (bit 0: V^T from the qkv projection's epilogue for a single image); 0 = unfused."""
+        """Launch fusions of the blocks (bit 0: V^T from the qkv projection's epilogue for a single image, bit 1: fc2's K-slice sum
+        applies bias + LayerNorm + residual); 0 = unfused.  All on by default."""
         check(lib().emu_vit_set_fusion(self.handle, int(mask)), "emu_vit_set_fusion", self.ctx.handle)
 
     def use_fp8(self, enable: bool = True) -> None:

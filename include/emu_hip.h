@@ -353,7 +353,9 @@ int emu_vit_set_block_fp8(emu_vit* m, int layer, const void* wqkv8, const float*
                           const void* fc1w8, const float* sfc1, const void* fc2w8, const float* sfc2);
 int emu_vit_use_fp8(emu_vit* m, int enable);
 /* Launch fusions of the encoder blocks (all on by default; 0 = the launch sequence of rounds 1-3, for A/B timing and parity):
- * bit 0: with one image the V heads leave the qkv projection key-contiguous (no transpose launch); bit-identical tokens. */
+ * bit 0: with one image the V heads leave the qkv projection key-contiguous (no transpose launch); bit 1: the K-slice sum of a
+ * post-norm block's fc2 applies bias, LayerNorm and the residual add row-wise in the same launch (no reduce + layernorm launches).
+ * Bit-identical tokens either way. */
 int emu_vit_set_fusion(emu_vit* m, int mask);
 size_t emu_vit_workspace_bytes(const emu_vit* m, int B);
 /* image NCHW (fp32 or bf16) -> tokens [B, 1+g*g, C] bf16 (raw block output incl. cls, eva_vit.py:433-445) */

@@ -454,7 +454,8 @@ def test_vit_vt_epilogue_bit_identical(image, postnorm, width, head_width):
     transposed LDS staging now takes a single batch element's ragged last tile: 1025 / 257 / 17 tokens) instead of a transpose
     launch.  Same values; the pad keys differ (copies of the last row instead of zeros) and meet masked probabilities only:
     the encoder's tokens must be BIT-identical, for EVA-CLIP-4B (Emu2), EVA-CLIP-g (Emu1, pre-norm) and a small shape; two
-    images in one call take the transpose launch as before."""
+    images in one call take the transpose launch as before.  The same switch covers the second fusion: fc2's K-slice sum applies
+    bias, LayerNorm and the residual add row-wise in one launch (post-norm blocks whose fc2 is K-sliced: the EVA-CLIP-4B shape)."""
     from emu_amd import CLIPVisionCfg, synth
     from emu_amd.llama import EmuHipContext
     from emu_amd.vit import VitEngine
@@ -471,7 +472,7 @@ def test_vit_vt_epilogue_bit_identical(image, postnorm, width, head_width):
         plain = vit(img[:1]).clone()
         both0 = vit(img).clone()
     finally:
-        vit.set_fusion(1)
+        vit.set_fusion(3)
     assert bool(torch.isfinite(fused.float()).all())
     assert torch.equal(fused, plain)
     assert torch.equal(both, both0)                      # (two images: another M, another tile dispatch -- not comparable bit for bit with one)

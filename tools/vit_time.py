@@ -19,8 +19,8 @@ eng.load_weights(synth.iter_synth(synth.vit_param_shapes(v), seed=0, device=dev,
 img = torch.randn(1, 3, v.image_size, v.image_size, device=dev)
 if fp8:
     eng.use_fp8(True)
-if os.environ.get("EMU_VIT_FUSION") == "0":          # A/B: the transpose launch instead of the V^T epilogue of the qkv projection
-    eng.set_fusion(0)
+if os.environ.get("EMU_VIT_FUSION"):                 # A/B: emu_vit_set_fusion mask (0 = the launch sequence of rounds 1-3, 3 = default)
+    eng.set_fusion(int(os.environ["EMU_VIT_FUSION"]))
 ts = []
 with torch.no_grad():
     run = lambda: eng.forward(img)
@@ -35,4 +35,4 @@ with torch.no_grad():
         run()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t) * 1e3)
-print(f"vit encode{' (W8A8 blocks)' if fp8 else ''}{' (hipGraph replay)' if graph else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [{'no fusion' if os.environ.get('EMU_VIT_FUSION') == '0' else ''}]", flush=True)
+print(f"vit encode{' (W8A8 blocks)' if fp8 else ''}{' (hipGraph replay)' if graph else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [fusion mask {os.environ.get('EMU_VIT_FUSION', '3')}]", flush=True)
