@@ -830,6 +830,12 @@ static int vit_blocks(emu_vit* m, bf16_t* x, int Bn, int l0, int l1, const VitWs
         ga.partial = w.splitk; ga.partial_floats = w.splitk_floats;
         return launch_gemm_fp8(ga, s);
     };
+    // V^T out of the qkv epilogue (one image, bf16) writes keys [0, N) and the few pad keys of the last 8-key group; the rest of the
+    // pad columns [N, npad) of the V^T buffer is nobody's: zeroed once per call (the attention kernel multiplies them by masked
+    // probabilities, and a stale NaN pattern times zero is NaN)
+    if (m->fuse_vt && Bn == 1 && !m->fp8 && npad != N && l1 > l0 &&
+        hipMemsetAsync(w.vt, 0, (size_t)Hh * VIT_DP * npad * 2, s) != hipSuccess)
+        return fail(cx, -5, "emu_vit_forward: hipMemsetAsync");
     const bool q8 = m->fp8 && C <= 2048;                 // LayerNorm rows leave as fp8 operands (launch_layernorm_q8)
     bool x8_valid = false;                               // post-norm: w.x8 / w.xs hold the quantised rows of x
     for (int l = l0; l < l1; ++l) {

@@ -435,6 +435,8 @@ def test_true_width_prefill_rope_epilogue_bit_identical(S):
         eng.set_prefill_fusion(fused)
         eng.alloc_kv(1, s_max)
         eng.kcache.fill_(7.0); eng.vcache.fill_(7.0)                        # every slot the prefill owns must be written
+        if eng._ws is not None:
+            eng._ws.view(BF16).fill_(float("nan"))                          # ... and nothing stale in the workspace may be read (V^T pad keys)
         hidden, kstart, pos = eng.prefill(x[:, :S].contiguous(), mask, s_max)
         hidden = hidden.clone()
         kc, vc = eng.kcache[:, :, :, :S].clone(), eng.vcache[:, :, :, :S].clone()
@@ -465,6 +467,8 @@ def test_vit_vt_epilogue_bit_identical(image, postnorm, width, head_width):
     vit.load_weights(synth.iter_synth(synth.vit_param_shapes(v), seed=5, device="cuda", dtype=BF16))
     g = torch.Generator().manual_seed(image)
     img = torch.randn(2, 3, image, image, generator=g).to(BF16).cuda()
+    vit(img[:1])
+    vit._ws.view(BF16).fill_(float("nan"))               # whatever the workspace held before must not reach the tokens (V^T pad keys)
     fused = vit(img[:1]).clone()
     both = vit(img).clone()
     vit.set_fusion(0)
