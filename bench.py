@@ -519,6 +519,8 @@ def main():
     log(f"rank {rank}: weights ready in {time.time() - t0:.1f}s, shard bytes/token {lm.weight_bytes_per_token() / 1e9:.2f} GB, "
         f"mem {torch.cuda.memory_allocated() / 2**30:.1f} GiB")
 
+    if os.environ.get("EMU_DECODE_TAIL") == "1":            # A/B aid: decode attention with the in-kernel split merge (one launch per layer less)
+        lm.set_decode_tail(True)
     # ---- synthetic prompt: 512 random ids + [IMG] 256x<image> [/IMG]
     g = torch.Generator().manual_seed(2)
     text_ids = torch.randint(3, 32000, (a.prompt_tokens,), generator=g)

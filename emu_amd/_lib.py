@@ -139,6 +139,7 @@ _PROTOS = {
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
     "emu_llama_set_prefill_fusion": (i32, [vp, i32]),
+    "emu_llama_set_decode_tail": (i32, [vp, i32]),
     "emu_regress_advance_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "emu_beam_advance": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "emu_llama_beam_reorder_kv": (i32, [vp, vp, vp, i32, i32, i32, vp]),

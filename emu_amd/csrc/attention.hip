@@ -746,8 +746,56 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     // in-kernel last-arriver combine needs device-scope fences (L2 write-backs across XCDs): 3.4x slower per layer; one
     // 16-wave workgroup per head walking the whole context (no partials, one launch): +3.7 us per layer at 52 heads x
     // 800 keys, because 52 CUs pull 0.4 MB each at the per-CU L1 rate while 204 CUs idle.
+    //
+    // Round 4: the last-arriver merge WITHOUT fences (DecodeFusedArgs::arrive).  What made round 1's attempt slow was the
+    // release fence in front of the arrival counter: at agent scope it writes the whole L2's dirty lines back (buffer_wbl2), 364
+    // times per layer.  Here the split state itself is stored with agent-scope (write-through, sc1) stores, the workgroup waits
+    // for their acknowledgement (vmcnt(0)) and bumps a relaxed agent-scope counter; the workgroup that finds the head's last
+    // count reads the states back with agent-scope loads (which do not trust this XCD's L2) and merges them with the combine
+    // kernel's arithmetic.  No cache-wide operation anywhere, no waiting (nobody spins: every workgroup but the last simply
+    // leaves), one launch less per layer.  Stress-tested against the two-launch form bit for bit (tests/test_gpu_model.py) --
+    // and 0.4 % SLOWER per token (94.9 / 94.5 vs 95.3 / 94.9 tokens/s, profiles/r04_decode_tail_merge_ab.log): store
+    // acknowledgement, counter round trip and the coherent loads are three dependent trips to the fabric, which is what a launch
+    // costs inside a graph.  Off by default (emu_llama_set_decode_tail).
+    float* wout = a.ws + (((size_t)b * a.H + h) * nsplit + split) * (D + 2);
+    if constexpr (!SHARE) {
+        if (a.arrive) {
+            __shared__ int s_last;
+            if (tid < D) {
+                __hip_atomic_store(wout + tid, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) {
+                    __hip_atomic_store(wout + D, mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(wout + D + 1, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's state has reached the agent's point of coherence
+            __syncthreads();
+            const int nlive = (slot + DF_CHUNK) / DF_CHUNK;
+            if (tid == 0) {
+                int* cnt = a.arrive + (size_t)b * a.H + h;
+                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = old == nlive - 1;
+                if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            }
+            __syncthreads();
+            if (!s_last || tid >= D) return;
+            const float* w = a.ws + ((size_t)b * a.H + h) * nsplit * (D + 2);
+            auto ldc = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            float m2 = -INFINITY;
+            for (int s2 = 0; s2 < nlive; ++s2) m2 = fmaxf(m2, ldc(w + s2 * (D + 2) + D));
+            float num2 = 0.f, den2 = 0.f;
+#pragma unroll 4
+            for (int s2 = 0; s2 < nlive; ++s2) {
+                const float ms = ldc(w + s2 * (D + 2) + D);
+                const float f = (ms == -INFINITY) ? 0.f : __expf(ms - m2);
+                num2 = fmaf(f, ldc(w + s2 * (D + 2) + tid), num2);
+                den2 = fmaf(f, ldc(w + s2 * (D + 2) + D + 1), den2);
+            }
+            a.o[(size_t)b * a.o_sb + (size_t)h * a.o_sh + tid] = f2bf(den2 > 0.f ? num2 / den2 : 0.f);
+            return;
+        }
+    }
     if (tid < D) {
-        float* wout = a.ws + (((size_t)b * a.H + h) * nsplit + split) * (D + 2);
         wout[tid] = num;
         if (tid == 0) { wout[D] = mt; wout[D + 1] = den; }
     }
@@ -806,10 +854,10 @@ int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s) {
     }
     if (a.D == 128) {
         hipLaunchKernelGGL((decode_fused_kernel<128, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        if (!a.arrive) hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else if (a.D == 64) {
         hipLaunchKernelGGL((decode_fused_kernel<64, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        if (!a.arrive) hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else return -22;
     EMU_CHECK_LAUNCH();
     return 0;

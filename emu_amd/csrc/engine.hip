@@ -378,7 +378,12 @@ struct emu_llama {
     int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
     int l0 = 0, l1 = -1;                         // emu_llama_set_layer_range: layers [l0, l1) run (l1 < 0: all)
     bool prefill_fusion = false;                 // emu_llama_set_prefill_fusion: RoPE + KV append + V^T in the qkv GEMM's epilogue
+    // decode attention without the combine launch (emu_llama_set_decode_tail, off by default): per (row, head) arrival counters of
+    // the split workgroups (zero between launches; owned here: EMU_ARRIVE_INTS ints of device memory)
+    int* arrive = nullptr;
+    bool decode_tail = false;                    // measured 0.4 % SLOWER than the combine launch (profiles/r04_decode_tail_merge_ab.log): opt-in
 };
+constexpr int EMU_ARRIVE_INTS = 65536;
 
 namespace {
 struct LlamaWs {
@@ -450,12 +455,21 @@ int emu_llama_create(emu_ctx* ctx, const emu_llama_cfg* cfg, emu_llama** out) {
         return fail(ctx, -22, "emu_llama_create: head_dim must be 64/128, hidden and ffn_local multiples of 8");
     emu_llama* m = new emu_llama();
     m->ctx = ctx; m->cfg = *cfg;
+    if (hipMalloc(reinterpret_cast<void**>(&m->arrive), EMU_ARRIVE_INTS * sizeof(int)) != hipSuccess ||
+        hipMemset(m->arrive, 0, EMU_ARRIVE_INTS * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->arrive) (void)hipFree(m->arrive);
+        m->arrive = nullptr;                           // the two-launch form needs none
+    }
     m->layers.resize(cfg->layers);
     memset(m->layers.data(), 0, sizeof(emu_llama::Layer) * cfg->layers);
     *out = m;
     return 0;
 }
-void emu_llama_destroy(emu_llama* m) { delete m; }
+void emu_llama_destroy(emu_llama* m) {
+    if (m && m->arrive) (void)hipFree(m->arrive);
+    delete m;
+}
 
 int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* wo, const void* wgu, const void* wdown,
                         const void* ln1, const void* ln2) {
@@ -478,6 +492,11 @@ int emu_llama_set_layer_fp8(emu_llama* m, int layer, const void* wqkv8, const fl
 int emu_llama_set_head_fp8(emu_llama* m, const void* lm_head8, const float* lm_scale) {
     if (!m || !lm_head8 || !lm_scale) return -22;
     m->lm_head8 = reinterpret_cast<const uint8_t*>(lm_head8); m->lm_scale8 = lm_scale;
+    return 0;
+}
+int emu_llama_set_decode_tail(emu_llama* m, int enable) {
+    if (!m) return -22;
+    m->decode_tail = enable != 0;
     return 0;
 }
 int emu_llama_set_prefill_fusion(emu_llama* m, int enable) {
@@ -593,6 +612,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             // RoPE + KV append + attention in one launch; context = slot + 1 is read on the device (graph replay)
             DecodeFusedArgs a{w.qkv, m->cos, m->sin, pos, slot, kc, vc, w.attn, (long)HD, (long)D, kstart, w.dec,
                               Bn, Hl, D, m->s_max, ctx, scale, m->kv_share_nb, m->kv_share_len};
+            if (m->decode_tail && m->arrive && m->kv_share_nb <= 1 && (long)Bn * Hl <= EMU_ARRIVE_INTS) a.arrive = m->arrive;
             TRY(cx, launch_decode_fused(a, s));
         } else {
             if (m->kv_share_nb > 1) return fail(cx, -22, "emu_llama_forward: shared-prefix KV rows serve single-token steps only");

@@ -249,6 +249,9 @@ struct DecodeFusedArgs {
     // workgroups reading the same keys are dispatched onto one XCD so its L2 serves all but the first).  share_nb <= 1:
     // every row owns all of its slots.
     int share_nb = 0, share_len = 0;
+    // Non-null (one-row path only): the last split workgroup of a head to arrive merges the head's live splits itself
+    // (arrive[b * H + h]: zero between launches, the merging workgroup resets it) -- no decode_fused_combine_kernel launch.
+    int* arrive = nullptr;
 };
 constexpr int DECODE_SHARE_MAX = 8;            // beams per group the shared-prefix path takes
 size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max);

@@ -154,6 +154,12 @@ class LlamaEngine:
         self.kv_batch = self.s_max = 0
         self._ws = None
 
+    def set_decode_tail(self, enable: bool) -> None:
+        """Decode attention in one launch (the last split workgroup of a head merges the splits) or, the default, with the separate
+        combine launch.  Same bits; measured 0.4 % slower in one launch.  Invalidates captured decode graphs."""
+        check(lib().emu_llama_set_decode_tail(self.handle, 1 if enable else 0), "emu_llama_set_decode_tail", self.ctx.handle)
+        self.__dict__.pop("_beam_graphs", None)
+
     def set_prefill_fusion(self, enable: bool) -> None:
         check(lib().emu_llama_set_prefill_fusion(self.handle, 1 if enable else 0), "emu_llama_set_prefill_fusion", self.ctx.handle)
         self.prefill_fusion = bool(enable)

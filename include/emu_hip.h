@@ -266,6 +266,12 @@ int emu_llama_set_layer_range(emu_llama* m, int l0, int l1);
  * k / v to the cache and writes V^T for the attention kernel from its own epilogue (same arithmetic and rounding points as the
  * three launches it replaces: bit-identical hidden states and caches); every other call runs the unfused sequence. */
 int emu_llama_set_prefill_fusion(emu_llama* m, int enable);
+
+/* Decode attention in ONE launch (OFF by default): the last split workgroup of a head to arrive merges the head's splits itself
+ * (agent-scope stores / loads of the split states and a relaxed arrival counter: no fence, no spinning) instead of a second,
+ * combine launch; same arithmetic, bit-identical outputs.  Measured 0.4 % slower than the two launches on MI355X (three
+ * dependent fabric round trips in the tail cost what the launch does), so it stays an option for A/B timing. */
+int emu_llama_set_decode_tail(emu_llama* m, int enable);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
 /* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
  * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).

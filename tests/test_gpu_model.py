@@ -482,6 +482,41 @@ def test_vit_vt_epilogue_bit_identical(image, postnorm, width, head_width):
     assert torch.equal(both, both0)                      # (two images: another M, another tile dispatch -- not comparable bit for bit with one)
 
 
+def test_true_width_decode_tail_merge_bit_identical():
+    """Round 4 (an option, off by default: it measured 0.4 % slower): decode attention in one launch -- the last split workgroup of a
+    head to arrive merges the head's splits itself,
+    with agent-scope stores / loads of the split states and a relaxed arrival counter instead of fences -- against the two-launch
+    form (attention + combine): 96 cached steps on a 770-token context at the LLaMA-33B width, two rows, hidden states of every
+    step BIT-identical (a torn or stale split state would show at once: 2 layers x 52 heads x 7 splits x 96 steps x 2 rows),
+    and the arrival counters are back at zero afterwards."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import LlamaCfg
+    from emu_amd.llama import EmuHipContext, LlamaEngine
+    l = LlamaCfg(num_hidden_layers=2)
+    eng = LlamaEngine(l, 256, EmuHipContext(torch.device("cuda", 0)))
+    eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, 256), device="cuda", dtype=BF16))
+    S, steps = 770, 96
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, S, l.hidden_size, generator=g).to(BF16).cuda()
+    xs = torch.randn(steps, 2, l.hidden_size, generator=g).to(BF16).cuda()
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[1, :37] = 0                                                       # a left-padded row: kstart masks inside the first split
+    s_max = eng.kv_capacity(S + steps + 8)
+    outs = {}
+    for tail in (True, False):
+        eng.set_decode_tail(tail)
+        _, kstart, pos = eng.prefill(x, mask, s_max)
+        hs = []
+        p = pos.clone()
+        for i in range(steps):
+            hs.append(eng.decode_embeds(xs[i], p, S + i, kstart).clone())
+            p = p + 1
+        outs[tail] = torch.stack(hs)
+    eng.set_decode_tail(False)
+    assert bool(torch.isfinite(outs[True].float()).all())
+    assert torch.equal(outs[True], outs[False])
+
+
 def test_true_width_five_beam_step_against_oracle_and_single_rows():
     """The reference's default decoding mode at the decoder's true width: one LLaMA-33B-shaped layer, a 300-token prompt, 5 beams
     that share the prompt's cache row and feed five different tokens -- the step runs the 5-row LDS-DMA + MFMA weight streams
