@@ -615,7 +615,13 @@ def main():
             step()
         sync()
         dt = time.perf_counter() - t
+    per_rank_ms = None
     if world > 1:
+        # every rank's own clock around the same K steps (they end together: each step holds 2 x layers all-reduces), then MAX
+        mine = torch.zeros(world, device=rdev, dtype=torch.float64)
+        mine[rank] = dt
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(v) / a.steps * 1e3 for v in mine.tolist()]
         tt = torch.tensor([dt], device=rdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -808,6 +814,10 @@ def main():
                                    f"(256 visual tokens) + {a.prompt_tokens}-token prompt (S={S}), greedy, batch 1",
                        "decoder_layers": lcfg.num_hidden_layers, "vit_layers": vcfg.layers,
                        "parallelism": f"tp{world}" + (" (ranks sharing one GPU: validation only)" if shared else ""), "allreduce": ("p2p one-shot (<=256 KiB) + rccl" if ctx.p2p else "rccl") if world > 1 else None,
+                       "tp": ({"ms_per_token_by_rank": per_rank_ms, "allreduces_per_token": 2 * lcfg.num_hidden_layers,
+                               "allreduce_bytes": 2 * lcfg.hidden_size, "weight_bytes_per_token_per_rank": lm.weight_bytes_per_token(),
+                               "note": "one process per GPU; o_proj / down_proj partial sums all-reduced in place on the launch stream"}
+                              if world > 1 else None),
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "valid": bool(a.layers == 60 and a.vit_layers == 64 and not shared and not a.gemm_tune)},
             "roofline": {"bound": "hbm", "kernel": "gemv_kernel (weight-streaming GEMV, all epilogues)",
