@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # announced on stderr, and the loaded library must report this binding's ABI version either way.
 _OVERRIDE = os.environ.get("EMU_HIP_LIB") if os.environ.get("EMU_HIP_TOOLS") == "1" else None
 LIB_PATH = _OVERRIDE or os.path.join(HERE, "csrc", "libemu_hip.so")
-ABI_VERSION = 2            # emu_version() of the library these prototypes and struct layouts belong to
+ABI_VERSION = 3            # emu_version() of the library these prototypes and struct layouts belong to
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "emu_hip.h")
 
 
@@ -140,6 +140,8 @@ _PROTOS = {
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
     "emu_llama_set_prefill_fusion": (i32, [vp, i32]),
     "emu_llama_set_decode_tail": (i32, [vp, i32]),
+    "emu_llama_set_decode_fused": (i32, [vp, i32, i32]),
+    "emu_llama_decode_fused_stats": (i32, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_long)]),
     "emu_regress_advance_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "emu_beam_advance": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "emu_llama_beam_reorder_kv": (i32, [vp, vp, vp, i32, i32, i32, vp]),

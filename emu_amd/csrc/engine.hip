@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -104,7 +105,7 @@ void emu_prof_end(hipStream_t s, const char* klass, int M, int N, int K, int tag
 
 extern "C" {
 
-int emu_version(void) { return 2; }      // ABI version: emu_amd/_lib.py::ABI_VERSION must match
+int emu_version(void) { return 3; }      // ABI version: emu_amd/_lib.py::ABI_VERSION must match
 
 void emu_set_splitk_scratch(void* ptr, size_t bytes) { emu_gemm_set_splitk_scratch(reinterpret_cast<float*>(ptr), bytes / sizeof(float)); }
 void emu_gemm_force_config(int cfg) { emu_gemm_force_config_set(cfg); }
@@ -382,6 +383,15 @@ struct emu_llama {
     // the split workgroups (zero between launches; owned here: EMU_ARRIVE_INTS ints of device memory)
     int* arrive = nullptr;
     bool decode_tail = false;                    // measured 0.4 % SLOWER than the combine launch (profiles/r04_decode_tail_merge_ab.log): opt-in
+    // whole decoder layers of a one-row step in one launch (decode_layer.hip; emu_llama_set_decode_fused)
+    int decode_fused = 0;                        // 0: the launches above; 1: fused where the shape / mode allows; 2: + in-kernel all-reduce
+    int dl_per_launch = 0;                       // layers per launch (0: all)
+    DecodeLayerPtrs* dl_table = nullptr;         // device copy of the layers' weight pointers
+    bool dl_dirty = true;
+    int* dl_cnt = nullptr;                       // arrival counters of all layers (zeroed at the head of every fused forward)
+    size_t dl_cnt_bytes = 0;
+    unsigned* dl_err = nullptr;                  // give-up counter
+    long dl_forwards = 0;                        // fused forwards issued (tests: the path under test is the one that ran)
 };
 constexpr int EMU_ARRIVE_INTS = 65536;
 
@@ -468,13 +478,43 @@ int emu_llama_create(emu_ctx* ctx, const emu_llama_cfg* cfg, emu_llama** out) {
 }
 void emu_llama_destroy(emu_llama* m) {
     if (m && m->arrive) (void)hipFree(m->arrive);
+    if (m && m->dl_table) (void)hipFree(m->dl_table);
+    if (m && m->dl_cnt) (void)hipFree(m->dl_cnt);
+    if (m && m->dl_err) (void)hipFree(m->dl_err);
     delete m;
+}
+
+int emu_llama_set_decode_fused(emu_llama* m, int enable, int layers_per_launch) {
+    if (!m || layers_per_launch < 0) return -22;
+    if (enable && !m->dl_cnt) {
+        const emu_llama_cfg& c = m->cfg;
+        m->dl_cnt_bytes = decode_layers_cnt_ints(c.layers, c.heads_local) * sizeof(int);
+        if (hipMalloc(reinterpret_cast<void**>(&m->dl_cnt), m->dl_cnt_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&m->dl_table), sizeof(DecodeLayerPtrs) * c.layers) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&m->dl_err), sizeof(unsigned)) != hipSuccess ||
+            hipMemset(m->dl_err, 0, sizeof(unsigned)) != hipSuccess)
+            return fail(m->ctx, -12, "emu_llama_set_decode_fused: device allocation");
+        m->dl_dirty = true;
+    }
+    m->decode_fused = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    m->dl_per_launch = layers_per_launch;
+    return 0;
+}
+int emu_llama_decode_fused_stats(emu_llama* m, unsigned int* giveups, long* forwards) {
+    if (!m) return -22;
+    if (giveups) {
+        *giveups = 0;
+        if (m->dl_err && hipMemcpy(giveups, m->dl_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -5;
+    }
+    if (forwards) *forwards = m->dl_forwards;
+    return 0;
 }
 
 int emu_llama_set_layer(emu_llama* m, int layer, const void* wqkv, const void* wo, const void* wgu, const void* wdown,
                         const void* ln1, const void* ln2) {
     if (!m || layer < 0 || layer >= m->cfg.layers) return -22;
     m->layers[layer] = {B(wqkv), B(wo), B(wgu), B(wdown), B(ln1), B(ln2)};
+    m->dl_dirty = true;
     return 0;
 }
 int emu_llama_set_layer_fp8(emu_llama* m, int layer, const void* wqkv8, const float* sqkv, const void* wo8, const float* so,
@@ -555,7 +595,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     if (w.total > ws_bytes) return fail(cx, -12, "emu_llama_forward: workspace too small");
     hipStream_t s = S(s_);
     const int M = Bn * T, H = c.hidden, Hl = c.heads_local, D = c.head_dim, HD = Hl * D, Fl = c.ffn_local;
-    const bool tp = cx->tp_size > 1 || cx->comm != nullptr;   // a 1-rank communicator still runs the RCCL path (tests)
+    const bool tp = cx->tp_size > 1 || cx->comm != nullptr || cx->p2p_on;   // a 1-rank communicator / comm block still runs the all-reduces (tests, tools/tp_emulate.py)
     const int epi_res = (!tp || cx->tp_rank == 0) ? EPI_RESID : EPI_NONE;   // residual enters the all-reduce once
     const float scale = 1.0f / sqrtf((float)D);
     const size_t kv_layer = (size_t)Bn * Hl * m->s_max * D;
@@ -572,6 +612,66 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     // down_proj that is the NEXT layer's input norm, so a layer may find its normalised rows in w.xn already)
     const bool fuse_norm = m->prefill_fusion && !tp && M > 16 && !m->fp8_prefill;
     bool xn_ready = false;
+    // ---- one-row step with bf16 weights: whole layers per launch (decode_layer.hip), same bits as the launches below
+    if (m->decode_fused && T == 1 && Bn == 1 && D == 128 && !m->fp8_decode && m->kv_share_nb <= 1 && l_end > m->l0 && m->dl_cnt) {
+        DecodeLayersArgs d{};
+        d.table = m->dl_table; d.hA = hA; d.hB = w.hB; d.qkv = w.qkv; d.attn = w.attn; d.act = w.act; d.ws = w.dec;
+        d.cos = m->cos; d.sin = m->sin; d.pos = pos; d.slot = slot; d.kstart = kstart;
+        d.kcache = m->kcache; d.vcache = m->vcache; d.kv_layer = kv_layer;
+        d.H = H; d.Hl = Hl; d.Fl = Fl; d.S_max = m->s_max; d.ctx_max = ctx;
+        d.eps = c.rms_eps; d.scale = scale; d.epi_res = (!tp || cx->tp_rank == 0) ? 1 : 0;
+        d.cnt = m->dl_cnt; d.err = m->dl_err; d.limit_ticks = 20000000LL;          // 0.2 s
+        bool ok = decode_layers_ok(d);
+        // tensor parallelism: mode 2 runs the all-reduces inside the launch over the P2P comm blocks (every rank on its own GPU); mode 1
+        // cuts every layer at its two all-reduces -- [q, attention, o_proj] | all-reduce | [gate/up, down] | all-reduce -- which also
+        // serves RCCL and ranks that share a GPU (a launch that waits for a peer must not hold the CUs the peer needs)
+        bool in_kernel_ar = false;
+        if (ok && tp && m->decode_fused == 2) {
+            long long lim = 0;
+            in_kernel_ar = cx->p2p_on && emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &lim);
+            if (!in_kernel_ar) d.tp_n = 0;
+            else if (lim > d.limit_ticks) d.limit_ticks = lim;     // a lagging peer holds every downstream wait: the peer bound applies
+            ok = decode_layers_ok(d);
+        }
+        if (ok) {
+            if (m->dl_dirty) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(s, &cs);
+                if (cs != hipStreamCaptureStatusNone)
+                    return fail(cx, -16, "emu_llama_forward: the fused decode path needs one eager step before a capture (weight table upload)");
+                std::vector<DecodeLayerPtrs> t(c.layers);
+                for (int l = 0; l < c.layers; ++l) {
+                    const emu_llama::Layer& L = m->layers[l];
+                    t[l] = {L.wqkv, L.wo, L.wgu, L.wdown, L.ln1, L.ln2};
+                }
+                if (hipMemcpy(m->dl_table, t.data(), sizeof(DecodeLayerPtrs) * c.layers, hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(cx, -5, "emu_llama_forward: weight table upload");
+                m->dl_dirty = false;
+            }
+            for (int l = m->l0; l < l_end; ++l)
+                if (!m->layers[l].wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
+            if (hipMemsetAsync(m->dl_cnt, 0, m->dl_cnt_bytes, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
+            if (tp && !in_kernel_ar) {
+                for (int l = m->l0; l < l_end; ++l) {
+                    d.layer0 = l; d.nlayers = 1;
+                    d.role0 = 0; d.role1 = 3;
+                    TRY(cx, launch_decode_layers(d, s));
+                    TRY(cx, emu_allreduce_bf16(cx, w.hB, (size_t)H, s_));
+                    d.role0 = 3; d.role1 = 5;
+                    TRY(cx, launch_decode_layers(d, s));
+                    TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)H, s_));
+                }
+            } else {
+                const int per = m->dl_per_launch > 0 ? m->dl_per_launch : l_end - m->l0;
+                for (int l = m->l0; l < l_end; l += per) {
+                    d.layer0 = l; d.nlayers = std::min(per, l_end - l);
+                    TRY(cx, launch_decode_layers(d, s));
+                }
+            }
+            ++m->dl_forwards;
+            return 0;
+        }
+    }
     for (int l = m->l0; l < l_end; ++l) {
         const emu_llama::Layer& L = m->layers[l];
         if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");

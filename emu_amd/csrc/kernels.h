@@ -257,6 +257,50 @@ constexpr int DECODE_SHARE_MAX = 8;            // beams per group the shared-pre
 size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max);
 int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s);
 
+struct EmuP2p;
+// ---- whole decoder layers of a single-row decode step in ONE launch (decode_layer.hip): qkv projection (+RMSNorm) -> RoPE / KV
+// append / split attention + merge -> o_proj (+residual) -> [all-reduce] -> gate/up (+RMSNorm, SwiGLU) -> down (+residual) ->
+// [all-reduce], for layers [layer0, layer0 + nlayers).  Workgroups are dealt roles by index (in dispatch order: every dependency
+// points to a lower index), wait on arrival counters with their weight slice already requested, and hand results over with
+// agent-scope (write-through) stores; every wait is bounded in wall-clock time (err counts give-ups; results are garbage then).
+struct DecodeLayerPtrs { const bf16_t *wqkv, *wo, *wgu, *wdown, *ln1, *ln2; };
+struct DecodeLayersArgs {
+    const DecodeLayerPtrs* table;              // device memory, indexed by absolute layer
+    int layer0, nlayers;
+    bf16_t* hA;                                // [H] layer input / output (residual stream)
+    bf16_t* hB;                                // [H] post-attention residual stream
+    bf16_t* qkv;                               // [3 * Hl * 128]
+    bf16_t* attn;                              // [Hl * 128]
+    bf16_t* act;                               // [Fl]
+    float* ws;                                 // decode_fused_ws_floats(1, Hl, 128, ctx_max)
+    const bf16_t* cos; const bf16_t* sin;
+    const int32_t* pos; const int32_t* slot; const int32_t* kstart;
+    bf16_t* kcache; bf16_t* vcache;            // layer l at + l * kv_layer elements: [Hl, S_max, 128]
+    size_t kv_layer;
+    int H, Hl, Fl, S_max, ctx_max;
+    float eps, scale;
+    int epi_res;                               // 1: this rank adds the residual (rank 0, or no tensor parallelism)
+    int* cnt;                                  // decode_layers_cnt_ints(layers, Hl) ints, ZERO at launch (all layers of the table)
+    unsigned* err;                             // give-up counter (device)
+    long long limit_ticks;                     // wait bound, 100 MHz ticks
+    // tensor parallelism: the workgroup that completes o_proj / down_proj all-reduces the partial vector over the peers' comm
+    // blocks (p2p.hip's protocol and sequence counters) before the consumers are released.  tp_n == 0: no all-reduce.
+    char* tp_block[8];
+    unsigned long long* tp_seq;
+    int tp_n, tp_rank;
+    // roles [role0, role1) of every layer run in this launch (0 q, 1 attention, 2 o_proj, 3 gate/up, 4 down; 0, 0 = all).  A partial
+    // range covers ONE layer; its first role's input comes from the launch before (tensor parallelism without in-kernel all-reduce:
+    // [q, attention, o_proj] -> all-reduce launch -> [gate/up, down] -> all-reduce launch).
+    int role0, role1;
+    // set by launch_decode_layers
+    int nQ, nA, nO, nG, nD, per_layer, cnt_stride, wave_od;
+};
+size_t decode_layers_cnt_ints(int layers, int Hl);
+bool decode_layers_ok(const DecodeLayersArgs& a);
+int launch_decode_layers(DecodeLayersArgs a, hipStream_t s);
+// the comm blocks / sequence counters of an opened EmuP2p for DecodeLayersArgs::tp_* (false: peers not mapped)
+bool emu_p2p_view(EmuP2p* p, char** block8, unsigned long long** seq, int* n, int* rank, long long* limit_ticks);
+
 // One beam-search step on the device (beam.hip): see emu_beam_step_bf16 in include/emu_hip.h
 struct BeamStepArgs {
     const bf16_t* logits;                      // row of (prompt b, beam j) = logits + b * ld_prompt + j * ld_beam
@@ -310,6 +354,10 @@ int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int l
 // ---- one-shot peer-to-peer all-reduce over IPC-mapped comm blocks (p2p.hip)
 constexpr int EMU_P2P_MAX_RANKS = 8;
 constexpr size_t EMU_P2P_SLOT_BYTES = 256 * 1024;
+// a message is cut into pieces of EMU_P2P_PIECE elements, each with its own sequence counter and flag per slot; the comm block is
+// [slot 0 | slot 1 | flags: 2 x EMU_P2P_PIECES x u64]
+constexpr int EMU_P2P_PIECE = 512 * 8;
+constexpr int EMU_P2P_PIECES = (int)(EMU_P2P_SLOT_BYTES / (EMU_P2P_PIECE * 2));
 struct EmuP2p;
 EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out);          // nullptr on failure
 int emu_p2p_open(EmuP2p* p, const void* handles);                      // n x 64 bytes, rank order (own entry ignored)

@@ -38,8 +38,8 @@ struct P2pPeers {
 
 // piece g of a message: elements [g * P2P_PIECE, (g + 1) * P2P_PIECE), one 16-byte vector per lane of workgroup g, which runs
 // its own instance of the protocol (own sequence counter, own flag per slot, own 8 KiB of each slot)
-constexpr int P2P_PIECE = 512 * 8;
-constexpr int P2P_PIECES = (int)(EMU_P2P_SLOT_BYTES / (P2P_PIECE * 2));
+constexpr int P2P_PIECE = EMU_P2P_PIECE;
+constexpr int P2P_PIECES = EMU_P2P_PIECES;
 
 __device__ __forceinline__ unsigned long long* flag_of(char* block, int slot, int g) {
     return reinterpret_cast<unsigned long long*>(block + 2 * EMU_P2P_SLOT_BYTES) + slot * P2P_PIECES + g;
@@ -177,6 +177,15 @@ int emu_p2p_allreduce(EmuP2p* p, bf16_t* x, size_t n, hipStream_t s) {
     }
     EMU_CHECK_LAUNCH();
     return 0;
+}
+
+bool emu_p2p_view(EmuP2p* p, char** block8, unsigned long long** seq, int* n, int* rank, long long* limit_ticks) {
+    if (!p) return false;
+    for (int r = 0; r < p->n; ++r)
+        if (!p->block[r]) return false;
+    for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r) block8[r] = r < p->n ? p->block[r] : nullptr;
+    *seq = p->seq; *n = p->n; *rank = p->rank; *limit_ticks = p->limit_ticks;
+    return true;
 }
 
 void emu_p2p_set_timeout_ms(EmuP2p* p, int ms) { if (p && ms > 0) p->limit_ticks = (long long)ms * 100000LL; }

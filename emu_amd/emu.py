@@ -302,7 +302,7 @@ class EmuModel:
         lm = self.decoder.lm
         B, width, hidden, dev = first.shape[0], first.shape[1], lm.cfg.hidden_size, self.ctx.device
         L = lib()
-        key = (B, lm.s_max, self.n_query, lm.kcache.data_ptr())
+        key = (B, lm.s_max, self.n_query, lm.kcache.data_ptr(), lm.mode_epoch)
         st = getattr(self, "_regress_state", None)
         if st is None or st["key"] != key:
             i32 = dict(dtype=torch.int32, device=dev)
@@ -337,6 +337,7 @@ class EmuModel:
         for _ in range(n):
             st["graph"].replay()
         lm.ctx.check_p2p()
+        lm.check_decode_fused()
         return st["out_all"].permute(1, 0, 2).clone()                               # [B, n_query, width] (never a view of the state)
 
     @torch.no_grad()

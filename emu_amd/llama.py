@@ -8,12 +8,13 @@ All arithmetic runs in libemu_hip.so; torch only owns the memory.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Iterable, Optional, Tuple
 
 import torch
 
 from . import ops
-from ._lib import LlamaCfgC, check, lib
+from ._lib import EmuHipError, LlamaCfgC, check, lib
 from .conf.emu_conf import LlamaCfg
 from .tp import ShardPlan
 
@@ -153,12 +154,45 @@ class LlamaEngine:
         self.kcache = self.vcache = None
         self.kv_batch = self.s_max = 0
         self._ws = None
+        # every captured decode graph (GreedyState, beam search, EmuModel's regress loop) carries the epoch it was captured under in
+        # its key: a mode switch (fp8 weights, decode tail, fused layers) bumps it, so no graph of another mode is ever replayed
+        self.mode_epoch = 0
+        self.decode_fused = 0
+        mode = int(os.environ.get("EMU_DECODE_FUSED", "1"))
+        if mode:
+            self.set_decode_fused(mode)
+
+    def _mode_changed(self) -> None:
+        self.mode_epoch += 1
+        self.__dict__.pop("_beam_graphs", None)
 
     def set_decode_tail(self, enable: bool) -> None:
         """Decode attention in one launch (the last split workgroup of a head merges the splits) or, the default, with the separate
         combine launch.  Same bits; measured 0.4 % slower in one launch.  Invalidates captured decode graphs."""
         check(lib().emu_llama_set_decode_tail(self.handle, 1 if enable else 0), "emu_llama_set_decode_tail", self.ctx.handle)
-        self.__dict__.pop("_beam_graphs", None)
+        self._mode_changed()
+
+    def set_decode_fused(self, enable: int, layers_per_launch: int = 0) -> None:
+        """One-row decode steps (greedy decode, ``generate_image``'s regress loop) with bf16 weights run whole decoder layers per
+        launch (csrc/decode_layer.hip: ``layers_per_launch`` layers, 0 = all) instead of six launches + two all-reduces per layer;
+        bit-identical to the launches.  Under tensor parallelism 1 = cut at the all-reduces (four launches per layer), 2 = all-reduces
+        inside the launch over the P2P comm blocks (one GPU per rank).  On by default (EMU_DECODE_FUSED=0/1/2 in the environment
+        overrides).  Invalidates captured decode graphs."""
+        check(lib().emu_llama_set_decode_fused(self.handle, int(enable), int(layers_per_launch)), "emu_llama_set_decode_fused",
+              self.ctx.handle)
+        self.decode_fused = int(enable)
+        self._mode_changed()
+
+    def decode_fused_stats(self) -> Tuple[int, int]:
+        """(give-ups of the fused path's bounded waits -- non-zero means garbage was computed --, forwards that took the fused path)."""
+        g, f = C.c_uint(0), C.c_long(0)
+        check(lib().emu_llama_decode_fused_stats(self.handle, C.byref(g), C.byref(f)), "emu_llama_decode_fused_stats", self.ctx.handle)
+        return int(g.value), int(f.value)
+
+    def check_decode_fused(self) -> None:
+        g, _ = self.decode_fused_stats()
+        if g:
+            raise EmuHipError(f"fused decode layers: {g} in-kernel wait(s) ran into the time limit; the step's outputs are invalid")
 
     def set_prefill_fusion(self, enable: bool) -> None:
         check(lib().emu_llama_set_prefill_fusion(self.handle, 1 if enable else 0), "emu_llama_set_prefill_fusion", self.ctx.handle)
@@ -252,6 +286,7 @@ class LlamaEngine:
             self.quantize_fp8()
         check(lib().emu_llama_use_fp8(self.handle, (2 if prefill else 1) if enable else 0), "emu_llama_use_fp8", self.ctx.handle)
         self.fp8_decode = bool(enable)
+        self._mode_changed()
 
     def fp8_dequantized(self, key: str) -> torch.Tensor:
         """fp32 value of a registered fp8 tensor (tests: feed the oracle the exact weights the stream uses)."""
@@ -443,6 +478,7 @@ class LlamaEngine:
                         break
         ids = out_ids.t().to(torch.int64)                       # [B, max_new]
         self.ctx.check_p2p()
+        self.check_decode_fused()
         if not stop_on_eos:
             return ids
         return apply_eos_padding(ids, eos_id, pad_id)
@@ -773,7 +809,8 @@ class LlamaEngine:
         runs the same launches eagerly."""
         dev, V, rows = self.device, self.vocab, B * nb
         L = lib()
-        key = (B, nb, S, self.s_max, max_len, int(min_len), float(length_penalty), int(eos_id), bool(v431), self.kcache.data_ptr())
+        key = (B, nb, S, self.s_max, max_len, int(min_len), float(length_penalty), int(eos_id), bool(v431), self.kcache.data_ptr(),
+               self.mode_epoch)
         cache = self.__dict__.setdefault("_beam_graphs", {})
         st = cache.get(key)
         if st is None:
@@ -941,7 +978,7 @@ class GreedyState:
         self.hidden = torch.empty(B, eng.cfg.hidden_size, device=dev, dtype=BF16)
         self.logits = torch.empty(B, eng.vocab, device=dev, dtype=BF16)
         self.ws = eng._workspace(B, 1)
-        self.graph = None
+        self.graph, self._epoch = None, -1
 
     def reset(self, first_ids: torch.Tensor, next_pos: torch.Tensor, S: int) -> None:
         """Rewind the device-side state to the end of the prompt, in place (a captured graph stays valid)."""
@@ -962,12 +999,12 @@ class GreedyState:
 
     def step_graph(self) -> None:
         """Replay the step from a hipGraph captured on first use (launch-bound at TP>1: ~550 launches/token)."""
-        if self.graph is None:
-            self.step()                                   # warm-up outside capture (lazy module loads)
+        if self.graph is None or self._epoch != self.eng.mode_epoch:
+            self.step()                                   # warm-up outside capture (lazy module loads, weight table upload)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.step()
-            self.graph = g
+            self.graph, self._epoch = g, self.eng.mode_epoch
             return                                        # capture does not execute: state advanced once by warm-up...
         self.graph.replay()
 

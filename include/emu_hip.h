@@ -272,6 +272,24 @@ int emu_llama_set_prefill_fusion(emu_llama* m, int enable);
  * combine launch; same arithmetic, bit-identical outputs.  Measured 0.4 % slower than the two launches on MI355X (three
  * dependent fabric round trips in the tail cost what the launch does), so it stays an option for A/B timing. */
 int emu_llama_set_decode_tail(emu_llama* m, int enable);
+
+/* Whole decoder layers of a one-row decode step in ONE launch (csrc/decode_layer.hip): with enable != 0, emu_llama_forward calls
+ * with B == 1, T == 1, bf16 weights, head_dim 128 and no shared-prefix KV rows run layers_per_launch layers (0 = all layers of the
+ * call) per launch instead of six launches (+ two all-reduces) per layer.  The workgroups of the launches it replaces become roles
+ * of one grid that wait on arrival counters with their weight slice already requested; results are bit-identical to the launches
+ * (same rows per workgroup and summation order).  Under tensor parallelism, enable == 1 cuts every layer at its two all-reduces
+ * ([q, attention, o_proj] | emu_allreduce_bf16 | [gate/up, down] | emu_allreduce_bf16: four launches instead of eight), and
+ * enable == 2 runs the all-reduces INSIDE the launch over the P2P comm blocks (emu_tp_p2p_enable must be on, else as 1): the
+ * workgroup that completes o_proj / down_proj runs the peer exchange while the consumers' weight slices are already in flight.
+ * Mode 2 needs every rank on its own GPU (a launch that waits for a peer holds its CUs).  Every in-kernel wait is bounded in
+ * wall-clock time.
+ * The first fused forward after a weight change uploads a pointer table and must therefore run outside stream capture (-16).
+ * Replaces: the per-layer module calls of the LlamaDecoderLayer loop (Emu2/emu/emu.py:133-138, :213-229) and the device hops of
+ * Emu2/emu/mixin.py:44-81. */
+int emu_llama_set_decode_fused(emu_llama* m, int enable, int layers_per_launch);
+/* giveups: in-kernel waits that ran into their time limit since creation (non-zero: outputs are garbage, treat as an error);
+ * forwards: emu_llama_forward calls that took the fused path.  Either pointer may be NULL.  Synchronises the device. */
+int emu_llama_decode_fused_stats(emu_llama* m, unsigned int* giveups, long* forwards);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
 /* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
  * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-rank decode cost of a TP shard on ONE GPU: rank 0's 1/tp slice of LLaMA-33B with a 1-rank RCCL communicator in the
 loop (the all-reduce launches are real, their cross-GPU latency is not).  With a third argument "p2p" the all-reduces are the
-one-shot peer-to-peer kernel (csrc/p2p.hip) with one rank instead.  Usage: python tools/tp_emulate.py [tp] [steps] [p2p]"""
+one-shot peer-to-peer kernel (csrc/p2p.hip) with one rank instead.  Usage: python tools/tp_emulate.py [tp] [steps] [p2p|rccl] [modes, e.g. 0,1,2]
+(modes: emu_llama_set_decode_fused -- 0 launches, 1 fused layers cut at the all-reduces, 2 all-reduce inside the launch; tp = 1: 0,1)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,8 +17,9 @@ real = EmuHipContext(dev, 0, 1)
 p2p = len(sys.argv) > 3 and sys.argv[3] == "p2p"
 if p2p:
     real.init_tp(lambda b: b, force=True, allgather_bytes=lambda b: [b], rccl=False)
-else:
+elif not (len(sys.argv) > 3 and sys.argv[3] == "none"):       # "none": no communicator at all (the tp = 1 decode, modes 0,1)
     real.init_tp(lambda b: b, force=True)
+per_launch = int(os.environ.get("EMU_DL_PER", "0"))           # layers per fused launch (0 = all)
 
 
 class ShardView:                      # the engine plans its shard from (tp_rank, tp_size); RCCL sees the 1-rank context
@@ -35,19 +37,27 @@ eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device
 S = 770
 x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
 mask = torch.ones(1, S, dtype=torch.long)
+modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2]
+names = {0: "launches (8 per layer)", 1: "fused, cut at the all-reduces (4 launches per layer)", 2: "fused, all-reduce inside (1 launch per token)"}
 with torch.no_grad():
     hidden, kstart, next_pos = eng.prefill(x, mask, eng.kv_capacity(S + steps + 24))
     cur = ops.argmax(eng.logits(hidden[:, -1, :]), suppress_id=2)
     out = torch.zeros(steps + 16, 1, device=dev, dtype=torch.int32)
-    for graph in (True, False):
-        st = GreedyState(eng, 1, cur, next_pos, S, kstart, out)
-        fn = st.step_graph if graph else st.step
-        for _ in range(4):
-            fn()
-        torch.cuda.synchronize(); t = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / steps * 1e3
-        print(f"tp={tp} shard on one GPU, {'p2p' if p2p else 'rccl'} all-reduce, {'hipGraph' if graph else 'eager'}: {ms:.3f} ms/token "
-              f"({eng.weight_bytes_per_token() / 1e9:.2f} GB of weights per token per rank)")
+    first = None
+    for mode in modes:
+        eng.set_decode_fused(mode, per_launch)
+        for graph in (True, False):
+            st = GreedyState(eng, 1, cur, next_pos, S, kstart, out)
+            fn = st.step_graph if graph else st.step
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t) / steps * 1e3
+            ids = out[: steps + 4, 0].tolist()
+            first = first or ids
+            print(f"tp={tp} shard on one GPU, {'p2p' if p2p else 'rccl'} all-reduce, {names[mode]}, {'hipGraph' if graph else 'eager'}: "
+                  f"{ms:.3f} ms/token ({eng.weight_bytes_per_token() / 1e9:.2f} GB of weights per token per rank; ids "
+                  f"{'match' if ids == first else 'DIFFER'}; give-ups {eng.decode_fused_stats()[0]})", flush=True)
