@@ -142,6 +142,7 @@ _PROTOS = {
     "emu_llama_set_decode_tail": (i32, [vp, i32]),
     "emu_llama_set_decode_fused": (i32, [vp, i32, i32]),
     "emu_llama_decode_fused_stats": (i32, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_long)]),
+    "emu_llama_set_decode_trace": (i32, [vp, vp]),
     "emu_regress_advance_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "emu_beam_advance": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "emu_llama_beam_reorder_kv": (i32, [vp, vp, vp, i32, i32, i32, vp]),

@@ -64,17 +64,25 @@ __device__ __forceinline__ int* head_slot(int* cl, int h) { return cl + h * DL_L
 __device__ __forceinline__ int* phase(int* cl, int Hl, int p) { return cl + Hl * DL_LINE + p * DL_PH_INTS; }
 __device__ __forceinline__ int nsub_of(int n) { return n < DL_NSUB ? n : DL_NSUB; }
 
-// one lane waits for *p >= target (bounded), the workgroup follows through a barrier.  p == nullptr: nothing to wait for.
-__device__ __forceinline__ void dl_wait(const int* p, int target, const DecodeLayersArgs& a) {
-    if (p && threadIdx.x == 0 && ld_agent(p) < target) {
+// Every wave waits for itself (uniform loads, no workgroup barrier, so nothing here drains the weight requests in flight).  `seen` is
+// the counter as read by a load issued AHEAD of the wave's weight requests (loads return in order: it is back long before they are):
+// in the steady state of a phase it already says ready and the wait costs nothing; only the first ~1000 workgroups of a phase poll.
+__device__ __forceinline__ int dl_peek(const int* p, int target) { return p ? ld_agent(p) : target; }
+__device__ __forceinline__ void dl_wait(const int* p, int target, int seen, const DecodeLayersArgs& a) {
+    if (p && __builtin_amdgcn_readfirstlane(seen) < target) {
         const bool dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         const long long t0 = wall_clock64();
-        while (ld_agent(p) < target) {
-            if (dead || wall_clock64() - t0 > a.limit_ticks) { atomicAdd(a.err, 1u); break; }
+        while (__builtin_amdgcn_readfirstlane(ld_agent(p)) < target) {
+            if (dead || wall_clock64() - t0 > a.limit_ticks) {
+                if ((threadIdx.x & 63) == 0) atomicAdd(a.err, 1u);
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
         }
     }
-    __syncthreads();
+#ifdef EMU_TRACE
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 4 + 2] = (unsigned long long)wall_clock64();
+#endif
 }
 
 // arrival of workgroup idx (of n) at a phase; lane 0 of wave 0, after stores_acked().  True for the one workgroup that completes
@@ -160,35 +168,38 @@ __device__ __forceinline__ void dl_close(const DecodeLayersArgs& a, int* ph, bf1
 }
 
 // ----------------------------------------------------------------------------------------------- Q / G: rows behind an RMSNorm
-// gemv_rt_kernel<4, 4, true, EPI, false> (gemv.hip) with the wait between the weight requests and the activation loads; the
-// rolling form gemv_kernel<4, 1, true, EPI, -1> sums in the same order, so either launch it replaces gives these bits.
+// gemv_rt_kernel<4, 4, true, EPI, false> (gemv.hip; K <= 8192 = four 256-lane trips): the arrival counter is requested first, then
+// the WHOLE weight slice; the counter is back within a microsecond (loads return in order), the gain and the input follow the weights
+// into the queue, and the statistics go through a raw s_barrier.  gemv_kernel<4, 1, true, EPI, -1> (the rolling "head" form the
+// multi-launch step prefers at TP = 1) sums in the same order, so either launch this replaces gives these bits; inside this grid the
+// rolling form measured 25-35 % SLOWER per phase (profiles/r05_decode_fused_timeline_*.log): its input loads sit on the dependency
+// chain of trips 2 and 3, and here they are agent-scope loads served by the L2, not L1 hits.
 template <int EPI>
 __device__ __forceinline__ void role_norm_rows(const DecodeLayersArgs& a, const bf16_t* W, const bf16_t* gain, const bf16_t* x,
                                                bf16_t* out, int N, int blk, const int* wp, int wt, float* sm) {
     constexpr int R = 4, KIT = 4;
     float* red = sm;                 // [4][R]
-    float* fin = sm + 16;            // [R]
     float* ssp = sm + 20;            // [4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int K = a.H;
     const int n0 = blk * R;
-    // weights through one descriptor: lanes beyond the row's end read on into the next row (zero beyond the matrix), against a zero
-    // activation (the activation descriptor ends at K)
+    const int seen = dl_peek(wp, wt);
+    // one descriptor per operand: lanes beyond a row's end read on into the next row (zero beyond the matrix) against a zero
+    // activation (the activation / gain descriptors end at K)
     const rsrc_t rw = make_rsrc(W, (uint32_t)N * (uint32_t)K * 2);
     u32x4 wv[KIT][R];
 #pragma unroll
     for (int it = 0; it < KIT; ++it)
 #pragma unroll
         for (int r = 0; r < R; ++r) wv[it][r] = ldw16(rw, (uint32_t)(tid + 256 * it) * 16, (uint32_t)(n0 + r) * (uint32_t)K * 2);
-    dl_wait(wp, wt, a);
-    const rsrc_t rg = make_rsrc(gain, (uint32_t)K * 2);
-    u32x4 gv[KIT];
-#pragma unroll
-    for (int it = 0; it < KIT; ++it) gv[it] = __builtin_amdgcn_raw_buffer_load_b128(rg, (uint32_t)(tid + 256 * it) * 16, 0, 0);
+    dl_wait(wp, wt, seen, a);
     const rsrc_t rx = make_rsrc(x, (uint32_t)K * 2);
-    u32x4 xv[KIT];
+    const rsrc_t rg = make_rsrc(gain, (uint32_t)K * 2);
+    u32x4 xv[KIT], gv[KIT];
 #pragma unroll
     for (int it = 0; it < KIT; ++it) xv[it] = ldb16(rx, (uint32_t)(tid + 256 * it) * 16);    // beyond K: zero
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) gv[it] = __builtin_amdgcn_raw_buffer_load_b128(rg, (uint32_t)(tid + 256 * it) * 16, 0, 0);
     float ss = 0.f;
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
@@ -198,9 +209,11 @@ __device__ __forceinline__ void role_norm_rows(const DecodeLayersArgs& a, const 
         for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
     }
     ss = wave_sum(ss);
-    if (lane == 0) ssp[wave] = ss;
-    __syncthreads();
-    const float rinv = rsqrtf((ssp[0] + ssp[1] + ssp[2] + ssp[3]) / (float)K + a.eps);
+    if (lane == 0) *reinterpret_cast<volatile float*>(&ssp[wave]) = ss;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const volatile float* sp = ssp;
+    const float rinv = rsqrtf((sp[0] + sp[1] + sp[2] + sp[3]) / (float)K + a.eps);
     // the packed vectors are opaque from here: unpack again below instead of keeping 32 floats alive across the reduction (the
     // weight slice holds 64 registers)
 #pragma unroll
@@ -249,32 +262,37 @@ __device__ __forceinline__ void role_norm_rows(const DecodeLayersArgs& a, const 
         }
         stores_acked();
     }
-    (void)fin;
 }
 
 // ----------------------------------------------------------------------------------------------------------- O / D: plain rows
-// Block form: R = 2 rows per workgroup, KIT 256-lane trips, every weight load up front (gemv_kernel<2, 1, false, *, 4> for
-// K <= 8192, gemv_rt_kernel<2, 9, false, *, false> for K <= 18432: same per-thread slices and summation order).
-template <int KIT>
+// Block form: R rows per workgroup, KIT 256-lane trips, every weight load up front (gemv_kernel<2, 1, false, *, 4> for K <= 8192,
+// gemv_rt_kernel<2, 9, false, *, false> for K <= 18432: same per-thread slices and summation order; rows are independent, so R is
+// free -- o_proj takes 4 to keep as many bytes in flight per workgroup as the 2 x 9 trips of down_proj).
+template <int R, int KIT>
 __device__ __forceinline__ void role_rows_block(const DecodeLayersArgs& a, const bf16_t* W, const bf16_t* x, const bf16_t* res,
                                                 bf16_t* out, int N, int K, int blk, const int* wp, int wt, float* sm) {
-    constexpr int R = 2;
+    static_assert(R == 2 || R == 4, "2 or 4 rows per workgroup");
     float* red = sm;                 // [4][R]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n0 = blk * R;
+    const int seen = dl_peek(wp, wt);
     const rsrc_t rw = make_rsrc(W, (uint32_t)N * (uint32_t)K * 2);
     u32x4 wv[KIT][R];
 #pragma unroll
     for (int it = 0; it < KIT; ++it)
 #pragma unroll
         for (int r = 0; r < R; ++r) wv[it][r] = ldw16(rw, (uint32_t)(tid + 256 * it) * 16, (uint32_t)(n0 + r) * (uint32_t)K * 2);
-    dl_wait(wp, wt, a);
+    dl_wait(wp, wt, seen, a);
     const rsrc_t rx = make_rsrc(x, (uint32_t)K * 2);
     u32x4 xv[KIT];
 #pragma unroll
     for (int it = 0; it < KIT; ++it) xv[it] = ldb16(rx, (uint32_t)(tid + 256 * it) * 16);
-    uint32_t rpair = 0;
-    if (res && tid == 0) rpair = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(res, (uint32_t)N * 2), (uint32_t)n0 * 2, 0, AUX_SC1);
+    u32x2 rq = {0u, 0u};
+    if (res && tid == 0) {
+        const rsrc_t rr = make_rsrc(res, (uint32_t)N * 2);
+        if constexpr (R == 4) rq = __builtin_amdgcn_raw_buffer_load_b64(rr, (uint32_t)n0 * 2, 0, AUX_SC1);
+        else rq.x = __builtin_amdgcn_raw_buffer_load_b32(rr, (uint32_t)n0 * 2, 0, AUX_SC1);
+    }
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
@@ -296,10 +314,15 @@ __device__ __forceinline__ void role_rows_block(const DecodeLayersArgs& a, const
     }
     __syncthreads();
     if (tid == 0) {
-        float v0 = bfround(red[0] + red[R] + red[2 * R] + red[3 * R]);
-        float v1 = bfround(red[1] + red[R + 1] + red[2 * R + 1] + red[3 * R + 1]);
-        if (res) { v0 += bflo(rpair); v1 += bfhi(rpair); }
-        st_agent32(out + n0, packbf(v0, v1));
+        float v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = bfround(red[r] + red[R + r] + red[2 * R + r] + red[3 * R + r]);
+        if (res) {
+            v[0] += bflo(rq.x); v[1] += bfhi(rq.x);
+            if constexpr (R == 4) { v[2] += bflo(rq.y); v[3] += bfhi(rq.y); }
+        }
+        if constexpr (R == 4) st_agent64(out + n0, packbf(v[0], v[1]), packbf(v[2], v[3]));
+        else st_agent32(out + n0, packbf(v[0], v[1]));
         stores_acked();
     }
 }
@@ -312,13 +335,14 @@ __device__ __forceinline__ void role_rows_wave(const DecodeLayersArgs& a, const 
     constexpr int RW = 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n0 = (blk * 4 + __builtin_amdgcn_readfirstlane(wave)) * RW;
+    const int seen = dl_peek(wp, wt);
     const rsrc_t rw = make_rsrc(W, (uint32_t)N * (uint32_t)K * 2);
     u32x4 wv[KITW][RW];
 #pragma unroll
     for (int it = 0; it < KITW; ++it)
 #pragma unroll
         for (int r = 0; r < RW; ++r) wv[it][r] = ldw16(rw, (uint32_t)(lane + 64 * it) * 16, (uint32_t)(n0 + r) * (uint32_t)K * 2);
-    dl_wait(wp, wt, a);
+    dl_wait(wp, wt, seen, a);
     const rsrc_t rx = make_rsrc(x, (uint32_t)K * 2);
     u32x4 xv[KITW];
 #pragma unroll
@@ -374,6 +398,8 @@ __device__ __forceinline__ bool role_attention(const DecodeLayersArgs& a, bf16_t
     const size_t hb = (size_t)h * a.S_max;
     const bf16_t* kc = kcl + hb * D;
     const bf16_t* vc = vcl + hb * D;
+    const int* qp = wait_q ? head_slot(cl, h) : nullptr;
+    const int seen = dl_peek(qp, 3 * D / 4);
     const u32x4 cv = ld16(a.cos + (size_t)pos * D + dc), sv = ld16(a.sin + (size_t)pos * D + dc);
     u32x4 kr[ITER], vr[ITER];
 #pragma unroll
@@ -384,7 +410,7 @@ __device__ __forceinline__ bool role_attention(const DecodeLayersArgs& a, bf16_t
         kr[it] = ld16(kc + off);
         vr[it] = ld16(vc + off);
     }
-    dl_wait(wait_q ? head_slot(cl, h) : nullptr, 3 * D / 4, a);   // the 96 four-row workgroups of this head's q, k and v rows
+    dl_wait(qp, 3 * D / 4, seen, a);                   // the 96 four-row workgroups of this head's q, k and v rows
     const int HD = a.Hl * D;
     const rsrc_t rq = make_rsrc(a.qkv, (uint32_t)(3 * HD) * 2);
     const uint32_t qo = (uint32_t)(h * D) * 2, ko = qo + (uint32_t)HD * 2, vo = ko + (uint32_t)HD * 2;
@@ -505,9 +531,7 @@ __device__ __forceinline__ bool role_attention(const DecodeLayersArgs& a, bf16_t
 
 // ------------------------------------------------------------------------------------------------------------------- the grid
 template <bool WAVE>
-__global__ __launch_bounds__(256, 4) void decode_layers_kernel(const DecodeLayersArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[16 * 130 + 8];
-    __shared__ int s_closer;
+__device__ __forceinline__ int decode_layers_body(const DecodeLayersArgs& a, float* sm, int& s_closer) {
     const int tid = threadIdx.x;
     int b = blockIdx.x;
     const int li = b / a.per_layer;
@@ -530,7 +554,7 @@ __global__ __launch_bounds__(256, 4) void decode_layers_kernel(const DecodeLayer
                 const int h = ((b * 4) % HD) >> 7;
                 __hip_atomic_fetch_add(head_slot(cl, h), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            return;
+            return DL_Q;
         }
         b -= a.nQ;
     }
@@ -539,19 +563,21 @@ __global__ __launch_bounds__(256, 4) void decode_layers_kernel(const DecodeLayer
             const int nsplit = a.nA / a.Hl;
             role_attention(a, a.kcache + (size_t)layer * a.kv_layer, a.vcache + (size_t)layer * a.kv_layer, b % nsplit, b / nsplit, cl, nsplit,
                            r0 <= DL_Q, sm);
-            return;
+            return DL_A;
         }
         b -= a.nA;
     }
     bool closer = false;
+    int role = DL_D;
     int* ph = nullptr;
     bf16_t* vec = nullptr;
     if (r0 <= DL_O && a.role1 > DL_O && b < a.nO) {
+        role = DL_O;
         ph = phase(cl, a.Hl, PH_O);
         vec = a.hB;
         const int* wp = r0 <= DL_A ? phase(cl, a.Hl, PH_A) : nullptr;
         if constexpr (WAVE) role_rows_wave<2>(a, L.wo, a.attn, a.epi_res ? a.hA : nullptr, a.hB, a.H, HD, b, wp, a.Hl);
-        else role_rows_block<4>(a, L.wo, a.attn, a.epi_res ? a.hA : nullptr, a.hB, a.H, HD, b, wp, a.Hl, sm);
+        else role_rows_block<4, 4>(a, L.wo, a.attn, a.epi_res ? a.hA : nullptr, a.hB, a.H, HD, b, wp, a.Hl, sm);
         if (tid == 0) closer = dl_arrive(ph, b, a.nO);
     } else {
         if (r0 <= DL_O && a.role1 > DL_O) b -= a.nO;
@@ -560,20 +586,42 @@ __global__ __launch_bounds__(256, 4) void decode_layers_kernel(const DecodeLayer
             role_norm_rows<EPI_SWIGLU>(a, L.wgu, L.ln2, a.hB, a.act, 2 * a.Fl, b, r0 <= DL_O ? ready_word(pho, tp) : nullptr,
                                        ready_target(a.nO, tp), sm);
             if (tid == 0) dl_arrive(phase(cl, a.Hl, PH_G), b, a.nG);
-            return;
+            return DL_G;
         }
         if (r0 <= DL_G) b -= a.nG;
         ph = phase(cl, a.Hl, PH_D);
         vec = a.hA;
         const int* phg = r0 <= DL_G ? phase(cl, a.Hl, PH_G) : nullptr;
         if constexpr (WAVE) role_rows_wave<5>(a, L.wdown, a.act, a.epi_res ? a.hB : nullptr, a.hA, a.H, a.Fl, b, phg, nsub_of(a.nG));
-        else role_rows_block<9>(a, L.wdown, a.act, a.epi_res ? a.hB : nullptr, a.hA, a.H, a.Fl, b, phg, nsub_of(a.nG), sm);
+        else role_rows_block<2, 9>(a, L.wdown, a.act, a.epi_res ? a.hB : nullptr, a.hA, a.H, a.Fl, b, phg, nsub_of(a.nG), sm);
         if (tid == 0) closer = dl_arrive(ph, b, a.nD);
     }
-    if (!tp) return;
+    if (!tp) return role;
     if (tid == 0) s_closer = closer;
     __syncthreads();
     if (s_closer) dl_close(a, ph, vec, a.H, sm);
+    return role;
+}
+
+template <bool WAVE>
+__global__ __launch_bounds__(256, 4) void decode_layers_kernel(const DecodeLayersArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm[16 * 130 + 8];
+    __shared__ int s_closer;
+#ifdef EMU_TRACE
+    // tools/decode_trace.py (the -DEMU_TRACE twin library only): per-workgroup timeline {role | layer << 8, entry, input ready, exit}
+    // in 100 MHz ticks
+    if (a.trace && threadIdx.x == 0) {
+        a.trace[(size_t)blockIdx.x * 4 + 1] = (unsigned long long)wall_clock64();
+        a.trace[(size_t)blockIdx.x * 4 + 2] = 0;
+    }
+    const int role = decode_layers_body<WAVE>(a, sm, s_closer);
+    if (a.trace && threadIdx.x == 0) {
+        a.trace[(size_t)blockIdx.x * 4] = (unsigned long long)(role | ((a.layer0 + blockIdx.x / a.per_layer) << 8));
+        a.trace[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)wall_clock64();
+    }
+#else
+    (void)decode_layers_body<WAVE>(a, sm, s_closer);
+#endif
 }
 
 }  // namespace
@@ -595,9 +643,9 @@ int launch_decode_layers(DecodeLayersArgs a, hipStream_t s) {
     a.wave_od = (HD <= 1024 && a.Fl <= 2560 && a.H >= 1024) ? 1 : 0;
     a.nQ = 3 * HD / 4;
     a.nA = ((a.ctx_max + DL_CHUNK - 1) / DL_CHUNK) * a.Hl;
-    a.nO = a.wave_od ? (a.H + 15) / 16 : (a.H + 1) / 2;
+    a.nO = a.wave_od ? (a.H + 15) / 16 : (a.H + 3) / 4;
     a.nG = a.Fl / 2;
-    a.nD = a.nO;
+    a.nD = a.wave_od ? (a.H + 15) / 16 : (a.H + 1) / 2;
     if (a.role1 <= a.role0) { a.role0 = DL_Q; a.role1 = DL_D + 1; }
     if (a.role0 < DL_Q || a.role1 > DL_D + 1) return -22;
     const int counts[5] = {a.nQ, a.nA, a.nO, a.nG, a.nD};

@@ -378,7 +378,7 @@ struct emu_llama {
     int kv_batch = 0, s_max = 0;
     int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
     int l0 = 0, l1 = -1;                         // emu_llama_set_layer_range: layers [l0, l1) run (l1 < 0: all)
-    bool prefill_fusion = false;                 // emu_llama_set_prefill_fusion: RoPE + KV append + V^T in the qkv GEMM's epilogue
+    bool prefill_fusion = false;                 // emu_llama_set_prefill_fusion: RoPE + KV append + V^T in the qkv GEMM's epilogue (one-shot: the next T > 1 forward consumes it)
     // decode attention without the combine launch (emu_llama_set_decode_tail, off by default): per (row, head) arrival counters of
     // the split workgroups (zero between launches; owned here: EMU_ARRIVE_INTS ints of device memory)
     int* arrive = nullptr;
@@ -392,6 +392,7 @@ struct emu_llama {
     size_t dl_cnt_bytes = 0;
     unsigned* dl_err = nullptr;                  // give-up counter
     long dl_forwards = 0;                        // fused forwards issued (tests: the path under test is the one that ran)
+    unsigned long long* dl_trace = nullptr;      // emu_llama_set_decode_trace (tools; -DEMU_TRACE twin library only)
 };
 constexpr int EMU_ARRIVE_INTS = 65536;
 
@@ -500,6 +501,11 @@ int emu_llama_set_decode_fused(emu_llama* m, int enable, int layers_per_launch) 
     m->dl_per_launch = layers_per_launch;
     return 0;
 }
+int emu_llama_set_decode_trace(emu_llama* m, void* buf) {
+    if (!m) return -22;
+    m->dl_trace = reinterpret_cast<unsigned long long*>(buf);
+    return 0;
+}
 int emu_llama_decode_fused_stats(emu_llama* m, unsigned int* giveups, long* forwards) {
     if (!m) return -22;
     if (giveups) {
@@ -606,11 +612,15 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     // promises slot[i] = i): the qkv projection rotates q / k, appends k / v to the cache and writes V^T itself
     // (GemmArgs::rope_*), instead of the rope_kv and transpose_v launches.  The V^T buffer's pad columns [ctx, spad) are
     // never written on that path: zeroed once per call (the attention kernel multiplies them by masked probabilities).
-    bool fuse_rope = m->prefill_fusion && Bn == 1 && T > 16 && T == ctx && D == 128 && !(HD & 255) && !m->fp8_prefill && m->kv_share_nb <= 1;
+    // The promise is per call: it is consumed here, so a later emu_llama_forward with rows in another slot order (any caller that did
+    // not renew it) runs the unfused sequence, which honours slot[] everywhere.
+    const bool promise = m->prefill_fusion;
+    if (T > 1) m->prefill_fusion = false;
+    bool fuse_rope = promise && Bn == 1 && T > 16 && T == ctx && D == 128 && !(HD & 255) && !m->fp8_prefill && m->kv_share_nb <= 1;
     if (fuse_rope && hipMemsetAsync(w.vt, 0, (size_t)HD * spad * 2, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
     // (prefill fusion, no tensor parallelism: the K-slice sums of o_proj / down_proj apply the RMSNorm that follows them; for
     // down_proj that is the NEXT layer's input norm, so a layer may find its normalised rows in w.xn already)
-    const bool fuse_norm = m->prefill_fusion && !tp && M > 16 && !m->fp8_prefill;
+    const bool fuse_norm = promise && !tp && M > 16 && !m->fp8_prefill;
     bool xn_ready = false;
     // ---- one-row step with bf16 weights: whole layers per launch (decode_layer.hip), same bits as the launches below
     if (m->decode_fused && T == 1 && Bn == 1 && D == 128 && !m->fp8_decode && m->kv_share_nb <= 1 && l_end > m->l0 && m->dl_cnt) {
@@ -621,6 +631,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         d.H = H; d.Hl = Hl; d.Fl = Fl; d.S_max = m->s_max; d.ctx_max = ctx;
         d.eps = c.rms_eps; d.scale = scale; d.epi_res = (!tp || cx->tp_rank == 0) ? 1 : 0;
         d.cnt = m->dl_cnt; d.err = m->dl_err; d.limit_ticks = 20000000LL;          // 0.2 s
+        d.trace = m->dl_trace;
         bool ok = decode_layers_ok(d);
         // tensor parallelism: mode 2 runs the all-reduces inside the launch over the P2P comm blocks (every rank on its own GPU); mode 1
         // cuts every layer at its two all-reduces -- [q, attention, o_proj] | all-reduce | [gate/up, down] | all-reduce -- which also

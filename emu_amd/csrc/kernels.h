@@ -292,6 +292,7 @@ struct DecodeLayersArgs {
     // range covers ONE layer; its first role's input comes from the launch before (tensor parallelism without in-kernel all-reduce:
     // [q, attention, o_proj] -> all-reduce launch -> [gate/up, down] -> all-reduce launch).
     int role0, role1;
+    unsigned long long* trace;                 // tools only (nullptr = off): 4 x u64 per workgroup {role | layer << 8, entry, input ready, exit}
     // set by launch_decode_layers
     int nQ, nA, nO, nG, nD, per_layer, cnt_stride, wave_od;
 };

@@ -157,8 +157,11 @@ class LlamaEngine:
         # every captured decode graph (GreedyState, beam search, EmuModel's regress loop) carries the epoch it was captured under in
         # its key: a mode switch (fp8 weights, decode tail, fused layers) bumps it, so no graph of another mode is ever replayed
         self.mode_epoch = 0
+        # whole decoder layers per launch (csrc/decode_layer.hip): built, bit-identical, and measured SLOWER than the launches on
+        # MI355X (12.45 vs 10.57 ms per token at TP = 1, 3.95 vs 3.57 for a TP = 8 shard: profiles/r05_decode_fused_*.log), so it
+        # is an option (EMU_DECODE_FUSED=1|2 or set_decode_fused), off by default
         self.decode_fused = 0
-        mode = int(os.environ.get("EMU_DECODE_FUSED", "1"))
+        mode = int(os.environ.get("EMU_DECODE_FUSED", "0"))
         if mode:
             self.set_decode_fused(mode)
 
@@ -176,8 +179,8 @@ class LlamaEngine:
         """One-row decode steps (greedy decode, ``generate_image``'s regress loop) with bf16 weights run whole decoder layers per
         launch (csrc/decode_layer.hip: ``layers_per_launch`` layers, 0 = all) instead of six launches + two all-reduces per layer;
         bit-identical to the launches.  Under tensor parallelism 1 = cut at the all-reduces (four launches per layer), 2 = all-reduces
-        inside the launch over the P2P comm blocks (one GPU per rank).  On by default (EMU_DECODE_FUSED=0/1/2 in the environment
-        overrides).  Invalidates captured decode graphs."""
+        inside the launch over the P2P comm blocks (one GPU per rank).  OFF by default: measured slower than the launches (see
+        __init__; EMU_DECODE_FUSED=1|2 in the environment switches it on).  Invalidates captured decode graphs."""
         check(lib().emu_llama_set_decode_fused(self.handle, int(enable), int(layers_per_launch)), "emu_llama_set_decode_fused",
               self.ctx.handle)
         self.decode_fused = int(enable)
@@ -195,8 +198,12 @@ class LlamaEngine:
             raise EmuHipError(f"fused decode layers: {g} in-kernel wait(s) ran into the time limit; the step's outputs are invalid")
 
     def set_prefill_fusion(self, enable: bool) -> None:
-        check(lib().emu_llama_set_prefill_fusion(self.handle, 1 if enable else 0), "emu_llama_set_prefill_fusion", self.ctx.handle)
+        """Whether ``prefill`` promises the library slot-ordered rows (the fused RoPE / KV-append / V^T / norm epilogues).  The
+        promise itself is per call (emu_llama_set_prefill_fusion is consumed by the next T > 1 forward): ``prefill`` renews it
+        before every forward it issues; a direct ``forward`` call with rows in any other slot order never inherits it."""
         self.prefill_fusion = bool(enable)
+        if not enable:
+            check(lib().emu_llama_set_prefill_fusion(self.handle, 0), "emu_llama_set_prefill_fusion", self.ctx.handle)
 
     # ------------------------------------------------------------------ weights
     def _dev(self, t: torch.Tensor) -> torch.Tensor:
@@ -430,6 +437,8 @@ class LlamaEngine:
         slot = torch.arange(S, device=self.device)[None].expand(B, -1)
         kstart = (S - n_real).to(torch.int32).contiguous()
         hidden = embeds.to(device=self.device, dtype=BF16).reshape(B * S, H).contiguous().clone()
+        if self.prefill_fusion:                          # slot = arange(S) below: the promise the fused epilogues need, for this call
+            check(lib().emu_llama_set_prefill_fusion(self.handle, 1), "emu_llama_set_prefill_fusion", self.ctx.handle)
         self.forward(hidden, B, S, pos.reshape(-1).to(torch.int32).contiguous(),
                      slot.reshape(-1).to(torch.int32).contiguous(), kstart, ctx=S)
         return hidden.view(B, S, H), kstart, next_pos.to(torch.int32).contiguous()

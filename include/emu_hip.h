@@ -260,8 +260,10 @@ int emu_llama_set_kv_share(emu_llama* m, int beams, int shared_slots);
  * layer instead of 60 layers of accumulated bf16 rounding); production code never calls it. */
 int emu_llama_set_layer_range(emu_llama* m, int l0, int l1);
 
-/* Prefill fusion (off by default): a caller that sets it PROMISES that every emu_llama_forward call with T > 1 rows passes
- * slot[i] = i (the rows of the one batch element are the whole context, in order -- what EmuModel's prefill does).  Then, for
+/* Prefill fusion (off by default), a PER-CALL promise: a caller that sets it promises that its NEXT emu_llama_forward call with
+ * T > 1 rows passes slot[i] = i (the rows of the one batch element are the whole context, in order -- what EmuModel's prefill
+ * does); that call consumes the promise, so any other caller of emu_llama_forward (rows in another slot order) gets the
+ * unfused sequence, which honours slot[] everywhere, unless it renews the promise itself.  Then, for
  * B = 1, T == ctx, head_dim 128 and heads_local * 128 a multiple of 256, the qkv projection applies RoPE to q and k, appends
  * k / v to the cache and writes V^T for the attention kernel from its own epilogue (same arithmetic and rounding points as the
  * three launches it replaces: bit-identical hidden states and caches); every other call runs the unfused sequence. */
@@ -290,6 +292,9 @@ int emu_llama_set_decode_fused(emu_llama* m, int enable, int layers_per_launch);
 /* giveups: in-kernel waits that ran into their time limit since creation (non-zero: outputs are garbage, treat as an error);
  * forwards: emu_llama_forward calls that took the fused path.  Either pointer may be NULL.  Synchronises the device. */
 int emu_llama_decode_fused_stats(emu_llama* m, unsigned int* giveups, long* forwards);
+/* Tools hook (tools/decode_trace.py): device buffer of 4 x u64 per workgroup of the LAST fused launch of a forward -- {role | layer << 8,
+ * entry, input ready (0: no wait), exit} in 100 MHz ticks; written only by a library built with -DEMU_TRACE; NULL = off. */
+int emu_llama_set_decode_trace(emu_llama* m, void* buf);
 size_t emu_llama_workspace_bytes(const emu_llama* m, int B, int T);
 /* all decoder layers over B*T rows (T > 1: prefill with MFMA GEMMs + flash attention; T == 1: decode with
  * weight-streaming GEMVs).  hidden [B*T, hidden] is the residual stream, updated in place (NOT final-normed).
