@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12      # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK = 2.5e15
+MFMA_FP8_PEAK = 5.0e15    # dense fp8 (MI355X_MICROARCH.md); priced against for the W8A8 legs only
 
 
 def parse():
@@ -215,6 +216,96 @@ def _reference_layer_time(W32, dtype, cfg, ctx_len, k0, v0, x0, seconds):
     return tot / n, n
 
 
+def _filled(shapes, seed=0):
+    """Weights for a CPU TIMING run: every tensor its own memory, filled from one small random pool by block copies (drawing
+    2.5 B normals on one host thread would take longer than the measurement); norm gains 1, values N(0, 0.02^2)."""
+    g = torch.Generator().manual_seed(seed)
+    pool = torch.randn(1 << 22, generator=g) * 0.02
+    out = {}
+    for k, sh in shapes.items():
+        n = 1
+        for d in sh:
+            n *= d
+        if k.endswith(("norm.weight", "norm1.weight", "norm2.weight", "norm3.weight", "layernorm.weight", "norm_out.weight")) and len(sh) == 1:
+            out[k] = torch.ones(sh)
+        else:
+            t = torch.empty(n)
+            for o in range(0, n, pool.numel()):
+                m = min(pool.numel(), n - o)
+                t[o:o + m] = pool[:m]
+            out[k] = t.view(sh)
+    return out
+
+
+def cpu_baseline_legs(seconds: float, threads: int, S: int):
+    """The reference's CPU path for the non-decode legs, on a bounded sample each: one UNet forward of the
+    CFG pair (restated diffusers-0.24 arithmetic, oracle/unet_ref.py: diffusers is not installable here) -> denoise steps/s; one
+    true-shape EVA-CLIP block -> images/s = 1 / (64 blocks); one LLaMA-33B decoder layer over the S prompt rows -> prefill ms =
+    60 layers.  fp32 on `threads` host threads (the decode baseline's calibrated thread count)."""
+    from emu_amd import synth
+    from emu_amd.conf.emu_conf import CLIPVisionCfg, LlamaCfg
+    from oracle import emu2_ref as R
+    from oracle import unet_ref as U
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    out = {}
+    with torch.no_grad():
+        # ---- ViT block
+        v = CLIPVisionCfg()
+        vc = R.VitCfg()                                                # the EVA-CLIP defaults (448 / 14 / 1792 / 64 blocks / MLP 15360)
+        shapes = {k: sh for k, sh in synth.vit_param_shapes(v).items() if k.startswith("visual.blocks.0.")}
+        W = _filled(shapes)
+        x = torch.randn(1, vc.tokens, vc.width) * 0.5
+        R.vit_block(x, W, 0, vc)
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds * 0.15 or n < 2:
+            R.vit_block(x, W, 0, vc); n += 1
+        tb = (time.perf_counter() - t0) / n
+        out["vit"] = {"value": 1.0 / (vc.layers * tb), "unit": "images/s", "cores": threads, "kind": "port",
+                      "sample": f"1 true-shape EVA-CLIP block (1025 x 1792, 16 heads, MLP 15360; oracle/emu2_ref.vit_block) x{n}, fp32 on "
+                                f"{threads} of {ncpu} host threads; images/s = 1 / ({vc.layers} x {tb * 1e3:.1f} ms)"}
+        del W
+        # ---- prefill layer
+        l = LlamaCfg(num_hidden_layers=1)
+        shapes = {k: sh for k, sh in synth.llama_param_shapes(l, 8).items() if ".layers.0." in k}
+        W = _filled(shapes)
+        cfg = R.LlamaCfg(layers=1, vocab=8)
+        x = torch.randn(1, S, cfg.hidden) * 0.1
+        mask = torch.ones(1, S, dtype=torch.long)
+        R.llama_model(x, mask, W, cfg, final_norm=False)
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < seconds * 0.25 or n < 1:
+            R.llama_model(x, mask, W, cfg, final_norm=False); n += 1
+        tl = (time.perf_counter() - t0) / n
+        out["prefill"] = {"value": 60 * tl * 1e3, "unit": "ms", "cores": threads, "kind": "port", "higher_is_better": False,
+                          "sample": f"1 true-shape LLaMA-33B decoder layer over the S = {S} prompt rows (oracle/emu2_ref.llama_layer, "
+                                    f"eager fp32 attention) x{n}, fp32 on {threads} of {ncpu} host threads; prefill = 60 x {tl * 1e3:.0f} ms"}
+        del W
+        # ---- UNet forward of the CFG pair
+        ucfg = U.UNetCfg()
+        W = _filled(U.unet_param_shapes(ucfg))
+        g = torch.Generator().manual_seed(3)
+        prompt = torch.randn(2, 64, 1792, generator=g)
+        lat = torch.randn(2, 4, 128, 128, generator=g)
+        tid = torch.tensor([1024, 1024, 0, 0, 1024, 1024] * 2)
+        t0 = time.perf_counter()
+        U.unet_forward(lat[:1], torch.tensor(981.0), prompt[:1], prompt[:1].mean(1), tid[:6], W, ucfg)
+        t1 = time.perf_counter() - t0                                  # the cond half alone (also the warm-up)
+        if 2.2 * t1 < seconds:
+            t0 = time.perf_counter()
+            U.unet_forward(lat, torch.tensor(981.0), prompt, prompt.mean(1), tid, W, ucfg)
+            t2 = time.perf_counter() - t0
+            how = f"one forward of the CFG pair (batch 2) = {t2:.1f} s"
+        else:
+            t2 = 2 * t1
+            how = f"one forward of the cond half (batch 1) = {t1:.1f} s, doubled for the CFG pair"
+        out["denoise"] = {"value": 1.0 / t2, "unit": "steps/s", "cores": threads, "kind": "port",
+                          "sample": f"restated SDXL-style UNet (2.53 B parameters, oracle/unet_ref.unet_forward: diffusers 0.24 is not installable "
+                                    f"here, so the port is the reference arithmetic), 128 x 128 latents, 64 context tokens, fp32 on {threads} of "
+                                    f"{ncpu} host threads: {how}; guidance + Euler update are negligible beside it"}
+    return out
+
+
 VIT_FLOPS_PER_IMAGE = 9.39e12       # BASELINE.md section 2 / SURVEY 8d: EVA-CLIP 64 blocks x 1025 tokens x 1792
 UNET_FLOPS_PER_STEP = 13.48e12      # BASELINE.md section 2: one denoise step (CFG batch 2) at 128x128 latents, 64 ctx tokens
 UNET_WEIGHT_BYTES = 2.0 * 2.53e9      # SURVEY 8a row a15: 2.53 B parameters, bf16
@@ -310,7 +401,11 @@ def denoise_leg(ctx, dev, steps, world, dist, fusion=-1):
                            "e4m3 scales on weights and activation rows; the blocks' LayerNorms emit the fp8 rows, attention outputs and "
                            "the GEGLU product are quantised by a launch of their own); convs, GroupNorm, attention, proj_in / proj_out bf16",
                    "note": "extra leg on random-init weights: the distance is what per-row e4m3 costs on unstructured matrices over "
-                           f"{steps} steps, not a quality claim; never this leg's value"}
+                           f"{steps} steps, not a quality claim; never this leg's value",
+                   "roofline": {"bound": "mfma", "achieved": UNET_FLOPS_PER_STEP * steps / dt8 / 1e12, "peak": MFMA_FP8_PEAK / 1e12,
+                                "unit": "TFLOP/s", "frac": UNET_FLOPS_PER_STEP * steps / dt8 / MFMA_FP8_PEAK, "traffic": None,
+                                "note": "whole step against the dense fp8 peak although only the transformer blocks' GEMMs (7.9 of the "
+                                        "13.48 TFLOP) run fp8: the convs and attention are bf16, so this understates the fp8 GEMMs"}}
         except Exception as e:
             fp8 = {"ms_per_step": None, "note": f"fp8 transformer-block leg failed: {e}"}
         finally:
@@ -717,6 +812,20 @@ def main():
                    "prefill_ms": pf8 * 1e3, "vit_encode_fp8": vit8, "prefill_note": "S=%d prefill with W8A8 GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4 "
                    "(per-row e4m3 scales on weights and activations), attention / norms / KV bf16" % S,
                    "note": "extra leg, not the headline metric (which stays bf16 like the reference)"}
+            kv8 = 2 * lcfg.num_hidden_layers * lcfg.hidden_size * 2 * (S + a.warmup + a.steps // 2) // world
+            fp8["roofline"] = {"bound": "hbm", "kernel": "gemv_fp8* (e4m3 weight-streaming GEMV)", "achieved": wb.value / (ms.value * 1e-3) / 1e9,
+                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": wb.value / (ms.value * 1e-3) / HBM_PEAK, "traffic": None,
+                               "bytes_per_launch": wb.value / max(1, nl.value), "avg_launch_us": ms.value * 1e3 / max(1, nl.value),
+                               "token_level_frac": (lm.weight_bytes_per_token() + kv8) * (a.steps / dt8) / HBM_PEAK,
+                               "measured": f"HIP events around each fp8 GEMV, eager replay of {n_prof} steps"}
+            pfl8 = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
+                                             + 2 * S * S * lcfg.hidden_size)
+            fp8["prefill_roofline"] = {"bound": "mfma", "achieved": pfl8 / world / pf8 / 1e12, "peak": MFMA_FP8_PEAK / 1e12, "unit": "TFLOP/s",
+                                       "frac": pfl8 / world / pf8 / MFMA_FP8_PEAK, "traffic": None,
+                                       "note": "W8A8 GEMMs priced against the dense fp8 peak; attention, norms and the row quantisers run bf16 / fp32"}
+            if isinstance(vit8, dict) and vit8.get("ms"):
+                vit8["roofline"] = {"bound": "mfma", "achieved": VIT_FLOPS_PER_IMAGE / (vit8["ms"] * 1e-3) / 1e12, "peak": MFMA_FP8_PEAK / 1e12,
+                                    "unit": "TFLOP/s", "frac": VIT_FLOPS_PER_IMAGE / (vit8["ms"] * 1e-3) / MFMA_FP8_PEAK, "traffic": None}
         except Exception as e:
             fp8 = {"value": None, "note": f"fp8 leg failed: {e}"}
         finally:
@@ -856,6 +965,16 @@ def main():
             except Exception as e:                              # never lose the GPU line to a host-side problem
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
+            # the other legs of the metric beside their CPU path: bounded samples, same thread count
+            try:
+                th = int(res["cpu_baseline"].get("cores") or min(os.cpu_count() or 1, 64))
+                cl = cpu_baseline_legs(a.cpu_seconds, th, S)
+                if denoise is not None:
+                    res["denoise"]["cpu_baseline"] = cl["denoise"]
+                res["extra"]["vit_cpu_baseline"] = cl["vit"]
+                res["extra"]["prefill_cpu_baseline"] = cl["prefill"]
+            except Exception as e:
+                res["extra"]["legs_cpu_baseline_note"] = f"failed: {type(e).__name__}: {e}"
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
