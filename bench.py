@@ -461,7 +461,13 @@ def config_legs(m, lm, ctx, dev, vcfg, lcfg, img, unet_eng):
         ids = torch.cat(parts)[None]
         S = ids.shape[1]
         imgs = img.expand(4, -1, -1, -1).contiguous()
-        t_vit, _ = timed(lambda: m.encode_image(imgs), reps=1)
+        m.encode_image(imgs)                                 # first call at this batch: workspace allocation, cold code
+        def enc4():                                          # steady state like the other legs: mean of 4 back-to-back calls
+            for _ in range(4):
+                r = m.encode_image(imgs)
+            return r
+        t_vit, _ = timed(enc4, reps=2)
+        t_vit /= 4
         x = m._prompt_embeds(ids, imgs, vcfg.n_query)
         mask = torch.ones(1, S, dtype=torch.long)
         s_max = lm.kv_capacity(S + 8)
@@ -470,7 +476,8 @@ def config_legs(m, lm, ctx, dev, vcfg, lcfg, img, unet_eng):
                                        + 2 * S * S * lcfg.hidden_size)
         out["prefill_fewshot_S1544"] = {"config": "BASELINE.json configs[2]: 4 images + 512-token prompt", "S": S,
                                         "prefill_ms": t_pf * 1e3, "tflops": fl / t_pf / 1e12, "mfma_frac": fl / t_pf / MFMA_BF16_PEAK,
-                                        "vit_encode_4_images_ms": t_vit * 1e3}
+                                        "vit_encode_4_images_ms": t_vit * 1e3,
+                                        "vit_note": "ONE batched encode of the 4 images (M = 4100 rows per GEMM), mean of 4 back-to-back calls"}
         # ---- generate_image (Emu2-Gen: n_query 64), 20-token prompt: S0 + 1 prefill + 63 cached steps
         nq_saved = m.n_query
         m.n_query = 64

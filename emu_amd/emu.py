@@ -193,13 +193,25 @@ class EmuModel:
                      stop_on_eos: bool = True, num_beams: int = 1, length_penalty: float = -1.0, do_sample: bool = False,
                      temperature=None, top_k=None, top_p=None, repetition_penalty: float = 1.0,
                      penalty_alpha: Optional[float] = None, no_repeat_ngram_size: int = 0,
-                     num_return_sequences: int = 1, hf_semantics: Optional[str] = None) -> torch.Tensor:
+                     num_return_sequences: int = 1, hf_semantics: Optional[str] = None,
+                     eos_token_id: Optional[int] = None, min_new_tokens: Optional[int] = None) -> torch.Tensor:
         """``generate`` at the token-id level: returns the NEW ids [B, n] (what HF returns for inputs_embeds).  Mode
         selection as transformers does it: contrastive search (penalty_alpha > 0, top_k > 1, one beam, no sampling), beam
         search / beam sampling (num_beams > 1), sampling or penalised greedy, plain greedy (device-side loop, hipGraph).
         ``hf_semantics`` (default: ``self.hf_semantics`` = "4.31", the transformers release the reference pins): beam-search
-        conventions, see ``LlamaEngine.beam_search_generate``; "5.x" = the installed library the golden fixtures come from."""
+        conventions, see ``LlamaEngine.beam_search_generate``; "5.x" = the installed library the golden fixtures come from.
+        The two releases also differ in what ``min_length=min_len`` (emu.py:220) enforces when generation is driven by
+        ``inputs_embeds``: 4.31 compares against the EMPTY id sequence (min_len new tokens), 5.x subtracts the prompt length first
+        (``_prepare_generated_length``: the default min_len = 1 then enforces nothing and EOS may be the first token -- pinned by
+        the real reference's ids in tests/golden/generate_beam_eos_tiny.npz).  ``eos_token_id`` / ``min_new_tokens``: the options
+        of that name the reference forwards to ``lm.generate`` through ``**kwargs`` (emu.py:175,228)."""
         B, S = input_ids.shape
+        sem = hf_semantics or getattr(self, "hf_semantics", "4.31")
+        eos = EOS_TOKEN_ID if eos_token_id is None else int(eos_token_id)
+        if min_new_tokens is not None:
+            min_len = max(int(min_len), int(min_new_tokens)) if sem == "4.31" else int(min_new_tokens)
+        elif sem != "4.31":
+            min_len = max(int(min_len) - S, 0)
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
             x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
@@ -209,21 +221,20 @@ class EmuModel:
             if ngram or nret != 1:
                 raise NotImplementedError("contrastive search with no_repeat_ngram_size / several returned sequences is not built")
             return self.decoder.lm.contrastive_generate(x.view(B, S, -1), attention_mask, max_new_tokens, float(penalty_alpha),
-                                                        int(top_k), min_len, repetition_penalty, eos_id=EOS_TOKEN_ID,
+                                                        int(top_k), min_len, repetition_penalty, eos_id=eos,
                                                         pad_id=PAD_TOKEN_ID)
         if num_beams > 1:
             return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
-                                                        length_penalty, eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID,
+                                                        length_penalty, eos_id=eos, pad_id=PAD_TOKEN_ID,
                                                         do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
                                                         repetition_penalty=repetition_penalty, no_repeat_ngram_size=ngram,
-                                                        num_return_sequences=nret,
-                                                        hf_semantics=hf_semantics or getattr(self, "hf_semantics", "4.31"))
+                                                        num_return_sequences=nret, hf_semantics=sem)
         if do_sample or repetition_penalty != 1.0 or ngram or nret != 1:
             return self.decoder.lm.sample_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len, do_sample,
-                                                   temperature, top_k, top_p, repetition_penalty, eos_id=EOS_TOKEN_ID,
+                                                   temperature, top_k, top_p, repetition_penalty, eos_id=eos,
                                                    pad_id=PAD_TOKEN_ID, no_repeat_ngram_size=ngram, num_return_sequences=nret)
         return self.decoder.lm.greedy_generate(x.view(B, S, -1), attention_mask, max_new_tokens, min_len,
-                                               eos_id=EOS_TOKEN_ID, pad_id=PAD_TOKEN_ID, use_graph=self.use_graph,
+                                               eos_id=eos, pad_id=PAD_TOKEN_ID, use_graph=self.use_graph,
                                                stop_on_eos=stop_on_eos)
 
     @torch.no_grad()
@@ -234,10 +245,10 @@ class EmuModel:
                  skip_special_tokens=True, **kwargs):
         # the reference forwards **kwargs to transformers' generate (emu.py:175,228); the options this engine honours
         # are mapped, anything else is refused rather than silently ignored
-        if "min_new_tokens" in kwargs:
-            min_len = max(int(min_len), int(kwargs.pop("min_new_tokens")))
+        min_new = int(kwargs.pop("min_new_tokens")) if "min_new_tokens" in kwargs else None
         if "min_length" in kwargs:
             min_len = max(int(min_len), int(kwargs.pop("min_length")))
+        eos_override = kwargs.pop("eos_token_id", None)
         kwargs.pop("use_cache", None)                   # always cached
         ngram = int(kwargs.pop("no_repeat_ngram_size", 0) or 0)
         nret = int(kwargs.pop("num_return_sequences", 1) or 1)
@@ -251,7 +262,8 @@ class EmuModel:
         ids = self.generate_ids(inputs.input_ids, inputs.attention_mask, image, video, max_new_tokens, min_len,
                                 num_beams=num_beams, length_penalty=length_penalty, do_sample=do_sample,
                                 temperature=temperature, top_k=top_k, top_p=top_p, repetition_penalty=repetition_penalty,
-                                penalty_alpha=penalty_alpha, no_repeat_ngram_size=ngram, num_return_sequences=nret)
+                                penalty_alpha=penalty_alpha, no_repeat_ngram_size=ngram, num_return_sequences=nret,
+                                eos_token_id=eos_override, min_new_tokens=min_new)
         return tok.batch_decode(ids.cpu(), skip_special_tokens=skip_special_tokens)
 
     # ------------------------------------------------------------------ generate_image (emu.py:92-153)

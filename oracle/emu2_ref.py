@@ -273,13 +273,15 @@ def embed_tokens(ids: Tensor, W: Weights) -> Tensor:
 
 def greedy_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: LlamaCfg,
                     max_new_tokens: int, min_len: int = 1,
-                    return_margins: bool = False):
+                    return_margins: bool = False, eos_id: Optional[int] = None):
     """``lm.generate(inputs_embeds=..., num_beams=1, do_sample=False)`` as called at
     Emu2/emu/emu.py:213-229: returns ONLY the new ids [B, <=max_new_tokens];
     position_ids = cumsum(attention_mask)-1 (left padding); EOS suppressed while fewer
     than ``min_len`` tokens exist (MinLengthLogitsProcessor; with inputs_embeds the id
-    sequence starts empty); finished rows emit PAD; stops when all rows finished."""
+    sequence starts empty; ``min_len`` here is the EFFECTIVE minimum, see ``effective_min_len``); finished rows emit PAD;
+    stops when all rows finished."""
     B, S, _ = embeds.shape
+    EOS = EOS_ID if eos_id is None else int(eos_id)
     cache = KVCache(cfg.layers)
     mask = attention_mask.clone()
     pos = (mask.long().cumsum(-1) - 1).masked_fill(mask == 0, 1)
@@ -291,13 +293,13 @@ def greedy_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: Lla
         h = llama_model(x, mask, W, cfg, position_ids=pos, cache=cache)
         logits = F.linear(h[:, -1, :], W["decoder.lm.lm_head.weight"]).to(torch.float32)
         if step < min_len:
-            logits[:, EOS_ID] = -float("inf")
+            logits[:, EOS] = -float("inf")
         top2 = logits.topk(2, dim=-1).values
         margins.append(top2[:, 0] - top2[:, 1])
         nxt = logits.argmax(dim=-1)
         nxt = nxt * unfinished + PAD_ID * (1 - unfinished)
         out.append(nxt)
-        unfinished = unfinished * (nxt != EOS_ID).long()
+        unfinished = unfinished * (nxt != EOS).long()
         if unfinished.max() == 0:
             break
         x = embed_tokens(nxt[:, None], W)
@@ -311,7 +313,7 @@ def greedy_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: Lla
 
 def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg: LlamaCfg, num_beams: int,
                          max_new_tokens: int, min_len: int = 1, length_penalty: float = -1.0,
-                         return_margin: bool = False):
+                         return_margin: bool = False, eos_id: Optional[int] = None):
     """``lm.generate(inputs_embeds=..., num_beams=N, do_sample=False)`` with the reference's defaults
     (Emu2/emu/emu.py:163-172,213-229: num_beams=5, length_penalty=-1, early_stopping unset=False): restatement of
     transformers' beam search -- 2N best continuations of (beam, token) per step; the N best unfinished ones keep
@@ -319,6 +321,7 @@ def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg
     stop when the best running beam cannot beat the worst kept result (heuristic at the current length)."""
     B, S, _ = embeds.shape
     nb, NEG = num_beams, -1.0e9
+    EOS = EOS_ID if eos_id is None else int(eos_id)        # (``eos_token_id=`` forwarded through EmuModel.generate's **kwargs)
     x = embeds.repeat_interleave(nb, dim=0)
     mask = attention_mask.repeat_interleave(nb, dim=0).clone()
     pos = (mask.long().cumsum(-1) - 1).masked_fill(mask == 0, 1)
@@ -340,13 +343,13 @@ def beam_search_generate(embeds: Tensor, attention_mask: Tensor, W: Weights, cfg
         logits = F.linear(h[:, -1, :], W["decoder.lm.lm_head.weight"]).to(torch.float32)
         lp = torch.log_softmax(logits, dim=-1)
         if cur < min_len:
-            lp[:, EOS_ID] = -float("inf")
+            lp[:, EOS] = -float("inf")
         acc = (lp.view(B, nb, V) + run_sc[:, :, None]).reshape(B, nb * V)
         top_lp, top_i = torch.topk(acc, k=2 * nb)
         src, tok = top_i // V, top_i % V
         cand = g3(run_seq, src)
         cand[:, :, cur] = tok
-        hits = (tok == EOS_ID) | (cur + 1 >= max_new_tokens)
+        hits = (tok == EOS) | (cur + 1 >= max_new_tokens)
         r_lp = top_lp + hits.float() * NEG
         nxt = torch.topk(r_lp, k=nb)[1]
         if cur + 1 < max_new_tokens:
@@ -394,9 +397,20 @@ def scatter_image_embeds(text_embeds: Tensor, input_ids: Tensor, image_embeds: T
     return out
 
 
+def effective_min_len(min_len: int, prompt_len: int, hf_semantics: str = "5.x") -> int:
+    """How many generated tokens ``min_length=min_len`` (Emu2/emu/emu.py:220) really enforces when ``lm.generate`` is driven by
+    ``inputs_embeds``.  transformers 5.x (the installed library, the source of the golden fixtures) subtracts the prompt length:
+    ``GenerationMixin._prepare_generated_length``: ``min_length = max(min_length - inputs_embeds.shape[1], 0)`` -- the reference's
+    default min_len = 1 then enforces NOTHING, and EOS may be the first token (pinned by tests/golden/generate_beam_eos_tiny.npz).
+    transformers 4.31 (the reference's pin; restated, not installable here) has no such correction: its MinLengthLogitsProcessor
+    compares against the EMPTY id sequence, so min_len new tokens are enforced."""
+    return int(min_len) if hf_semantics == "4.31" else max(int(min_len) - int(prompt_len), 0)
+
+
 def emu_generate(input_ids: Tensor, attention_mask: Tensor, image: Optional[Tensor], W: Weights,
                  cfg: EmuCfg, max_new_tokens: int, min_len: int = 1, n_query: Optional[int] = None,
-                 return_margins: bool = False, num_beams: int = 1, video: Optional[Tensor] = None):
+                 return_margins: bool = False, num_beams: int = 1, video: Optional[Tensor] = None,
+                 eos_id: Optional[int] = None, hf_semantics: str = "5.x"):
     """EmuModel.generate at the token-id level (greedy or beam search), Emu2/emu/emu.py:184-229; video frames are
     encoded with v_query tokens each and land on the [gIMG] slots (:205-211)."""
     x = embed_tokens(input_ids, W)
@@ -408,10 +422,11 @@ def emu_generate(input_ids: Tensor, attention_mask: Tensor, image: Optional[Tens
         e = encode_image(video, W, cfg, cfg.v_query)
         e = F.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"])
         x = scatter_image_embeds(x, input_ids, e, token_id=GIMG_ID)
+    min_len = effective_min_len(min_len, input_ids.shape[1], hf_semantics)
     if num_beams > 1:
         return beam_search_generate(x, attention_mask, W, cfg.llama, num_beams, max_new_tokens, min_len,
-                                    return_margin=return_margins)
-    return greedy_generate(x, attention_mask, W, cfg.llama, max_new_tokens, min_len, return_margins)
+                                    return_margin=return_margins, eos_id=eos_id)
+    return greedy_generate(x, attention_mask, W, cfg.llama, max_new_tokens, min_len, return_margins, eos_id=eos_id)
 
 
 def _suffix_count(flag: Tensor) -> Tensor:

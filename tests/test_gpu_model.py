@@ -721,3 +721,33 @@ def test_sharded_checkpoint_loads_strict_and_generates_reference_ids(tmp_path, g
     # a second load (e.g. fine-tuned weights over base weights) keeps the model ready: bookkeeping is by layer index
     m.load_weights(iter_checkpoint(str(tmp_path)), strict=True)
     assert m.decoder.lm.ready and m.visual.ready
+
+
+def test_generate_default_mode_finished_hypotheses_real_reference(tiny_model, golden_dir):
+    """EmuModel.generate_ids (5 / 3 beams, length_penalty -1) where hypotheses END ON EOS before the length limit, against the
+    REAL reference's ids (tests/golden/generate_beam_eos_tiny.npz; ``eos_token_id`` forwarded as the reference's **kwargs do).
+    Under hf_semantics="5.x" the ids are the library's on every case whose decisions the oracle finds clear in bf16 arithmetic
+    (the oracle in bf16 == the fixture); under the default "4.31" the GPU path equals its torch pipeline (kernel step vs host
+    step), and differs from the 5.x ids exactly on the cases where EOS leads a returned row (4.31 masks EOS at the first step)."""
+    from oracle import emu2_ref as R
+    m, W, cfg = tiny_model
+    z = tiny.load(golden_dir, "generate_beam_eos_tiny.npz")
+    Wb = R.cast_weights(W, BF16)
+    keys = sorted(k[:-4] for k in z if k.endswith("_eos"))
+    checked = 0
+    for key in keys:
+        ids, mask = _t(z[key + "_ids"]), _t(z[key + "_mask"])
+        img = _t(z["image"]) if bool(z[key + "_has_image"]) else None
+        nb, n_new, eos = int(z[key + "_nb"]), int(z[key + "_n_new"]), int(z[key + "_eos"])
+        want = z[key + "_out"].tolist()
+        bf = R.emu_generate(ids, mask, None if img is None else img.to(BF16), Wb, cfg, max_new_tokens=n_new, num_beams=nb, eos_id=eos)
+        got = m.generate_ids(ids, mask, None if img is None else img.cuda(), max_new_tokens=n_new, num_beams=nb, hf_semantics="5.x",
+                             eos_token_id=eos).cpu().tolist()
+        if bf.tolist() == want:                          # decisions that survive bf16 rounding: the GPU must reproduce the library
+            assert got == want, key
+            checked += 1
+        g431 = m.generate_ids(ids, mask, None if img is None else img.cuda(), max_new_tokens=n_new, num_beams=nb,
+                              eos_token_id=eos).cpu()
+        if any(row[0] == eos for row in want):
+            assert not bool((g431[:, 0] == eos).any()), key
+    assert checked >= 4, checked

@@ -605,3 +605,59 @@ def test_stream_handle_refuses_another_device_without_switching(monkeypatch):
     with pytest.raises(ValueError, match="current device"):
         ops.stream(torch.device("cuda", 1))
     assert switched == []
+
+
+def _eos_cases(z):
+    return sorted(k[:-4] for k in z if k.endswith("_eos"))
+
+
+def _prompt_x(z, key, W, cfg):
+    import numpy as np
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    ids = t(z[key + "_ids"])
+    x = R.embed_tokens(ids, W)
+    if bool(z[key + "_has_image"]):
+        e = R.encode_image(t(z["image"]), W, cfg, None)
+        e = torch.nn.functional.linear(e.reshape(-1, e.shape[-1]), W["project_up.weight"])
+        x = R.scatter_image_embeds(x, ids, e)
+    return ids, t(z[key + "_mask"]), x
+
+
+def test_product_beam_search_finished_hypotheses_real_reference(golden_dir, monkeypatch):
+    """The reference's default decoding mode (5 beams, length_penalty -1) on prompts where hypotheses END ON EOS before the length
+    limit, against the ids of the REAL reference (tests/golden/generate_beam_eos_tiny.npz, oracle/make_golden_beam_eos.py: the
+    installed transformers 5.x with ``eos_token_id`` forwarded through ``generate``'s **kwargs).  Pins, under
+    hf_semantics="5.x": the scorer's finished-hypothesis branch (length penalty of a short hypothesis, early stop, EOS / PAD
+    fill of the returned rows of a ragged batch) and that min_length = 1 enforces nothing with inputs_embeds (EOS first).
+    And the "4.31" conventions differ from these ids only where the restatement of that release says they must: on the cases
+    where EOS would be the FIRST token (4.31 masks it: min_length counts generated tokens there)."""
+    from emu_amd import llama as L, ops
+    from tests import tiny
+    from tests.fake_engine import FakeEngine
+    z = tiny.load(golden_dir, "generate_beam_eos_tiny.npz")
+    v, l, vocab, W = tiny.weights_from(z)
+    cfg = tiny.oracle_cfg(v, l, vocab)
+    monkeypatch.setattr(L, "BF16", torch.float32)
+    monkeypatch.setattr(ops, "embed_gather", lambda ids, table, out=None: out.copy_(table[ids.long()]))
+    n_first, n_cases = 0, 0
+    for key in _eos_cases(z):
+        ids, mask, x = _prompt_x(z, key, W, cfg)
+        nb, n_new, eos = int(z[key + "_nb"]), int(z[key + "_n_new"]), int(z[key + "_eos"])
+        want = z[key + "_out"]
+        S = ids.shape[1]
+        got = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, nb, n_new, min_len=max(1 - S, 0),
+                                                 eos_id=eos, hf_semantics="5.x")
+        assert got.tolist() == want.tolist(), key
+        # 4.31: product == restatement; and == the 5.x ids unless EOS leads a returned row
+        got431 = L.LlamaEngine.beam_search_generate(FakeEngine(l, vocab, W, cfg.llama), x, mask, nb, n_new, min_len=1, eos_id=eos,
+                                                    hf_semantics="4.31")
+        want431 = torch.cat([_beam_431(x[b:b + 1], mask[b:b + 1], W, cfg, nb, n_new, eos_id=eos) for b in range(x.shape[0])]) \
+            if x.shape[0] == 1 else None
+        if want431 is not None:
+            assert got431.tolist() == want431.tolist(), key
+        eos_first = bool((torch.from_numpy(want)[:, 0] == eos).any())
+        n_first += eos_first
+        n_cases += 1
+        if eos_first:
+            assert not bool((got431[:, 0] == eos).any()), key          # 4.31 never returns EOS as the first token (min_length 1)
+    assert n_cases >= 5 and 0 < n_first < n_cases                         # both kinds of case are present
