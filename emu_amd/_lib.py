@@ -152,6 +152,8 @@ _PROTOS = {
     "emu_unet_set_context": (i32, [vp, vp, i32, vp, i32, vp, sz, vp, sz, vp]),
     "emu_unet_step": (i32, [vp, vp, i32, i32, vp, vp, vp, f32, vp, sz, vp]),
     "emu_unet_forward": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "emu_unet_set_cfg_half": (i32, [vp, i32]),
+    "emu_unet_cfg_euler_step": (i32, [vp, vp, vp, i32, i32, vp, vp, f32, vp]),
 }
 
 

@@ -70,6 +70,7 @@ struct emu_unet {
                                         // bit 2: cross-attention inside the attn2 to_q epilogue
     int fusion_avail = 0;               // what the registered tensors allow (set by emu_unet_finalize)
     bool fp8 = false;                   // emu_unet_use_fp8: the transformer blocks' GEMMs W8A8 (fusion bit 0 has no fp8 form)
+    int cfg_half = -1;                  // emu_unet_set_cfg_half: -1 = the CFG pair (batch 2); 0 / 1 = only the cond / uncond row (a rank pair splits the pair)
     // resolved structure
     const bf16_t *conv_in_w, *conv_in_b, *te1w, *te1b, *te2w, *te2b, *ae1w, *ae1b, *ae2w, *ae2b, *tpw, *tpb;
     const bf16_t *cno_g, *cno_b, *cout_w, *cout_b;
@@ -290,6 +291,7 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
     const int HW = H * W, M = Bn * HW, C = t.c, D = 64;
     const int hwpad = (HW + 63) / 64 * 64, npad = (u->n_ctx + 63) / 64 * 64, n = u->n_ctx;
     const float scale = 0.125f;
+    const int hb = u->cfg_half < 0 ? 0 : u->cfg_half;     // first row of the CFG pair this call computes
     // Fused path (emu_unet_set_fusion): the three LayerNorms of a block live inside their consumer GEMMs -- the producer of the
     // stream (proj_in, attn1 / attn2 out-projection, ff-out) emits per-row partial sums from its epilogue, the consumer (qkv,
     // attn2 q, GEGLU) multiplies the un-normalised rows by W * gamma and corrects with mean / rstd in its epilogue -- and the qkv
@@ -328,8 +330,8 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
             UTRY(launch_quant_fp8_rows(w.att, C, w.x8, C, w.xs, M, C, s));
             UTRY(gemm8(u, w, tb.o1_8, tb.o1b, a, b, M, C, C, C, C, EPI_RESID, s));
             UTRY(launch_layernorm_q8(b, tb.ln2g, tb.ln2b, nullptr, nullptr, w.x8, w.xs, M, C, 1e-5f, s));
-            { const bf16_t* kv = u->ctx_cache + tb.ctx_off;
-              const bf16_t* vt = kv + (size_t)Bn * n * 2 * C;
+            { const bf16_t* kv = u->ctx_cache + tb.ctx_off + (size_t)hb * n * 2 * C;     // the cache holds both rows of the CFG pair
+              const bf16_t* vt = u->ctx_cache + tb.ctx_off + (size_t)2 * n * 2 * C + (size_t)hb * C * npad;
               if (fca8) {                                // to_q + the 64-key attention in one launch: writes w.att directly
                   Fx fx;
                   fx.cross_k = kv; fx.cross_vt = vt; fx.cross_ldk = 2 * C; fx.cross_n = n; fx.cross_npad = npad; fx.cross_rows = HW;
@@ -369,8 +371,8 @@ int run_transformer(emu_unet* u, const Transformer& t, const bf16_t* x, bf16_t* 
         // cross attention on the cached context K / Vt
         lnx = b;
         if (!fln) { UTRY(launch_layernorm(b, tb.ln2g, tb.ln2b, nullptr, w.ln, M, C, 1e-5f, s)); lnx = w.ln; }
-        { const bf16_t* kv = u->ctx_cache + tb.ctx_off;
-          const bf16_t* vt = kv + (size_t)Bn * n * 2 * C;
+        { const bf16_t* kv = u->ctx_cache + tb.ctx_off + (size_t)hb * n * 2 * C;
+          const bf16_t* vt = u->ctx_cache + tb.ctx_off + (size_t)2 * n * 2 * C + (size_t)hb * C * npad;
           Fx fx;
           if (fln) { fx.ln = &tb.q2_ln; fx.stats_in = st; }
           if (fca) {                                     // to_q + the whole 64-key attention in one launch: writes w.att directly
@@ -604,12 +606,13 @@ int emu_unet_set_context(emu_unet* u, const void* ctx_tokens, int n_ctx, const v
 // The UNet forward on the im2col'ed, already scaled input in ws.colin; result (noise prediction, NHWC [2*HW, 4]) in out.
 static int unet_body(emu_unet* u, const Ws& w, int H, int W, const bf16_t* temb_table, const int32_t* step, bf16_t* out, hipStream_t s) {
     const emu_unet_cfg& c = u->cfg;
-    const int Bn = 2;
+    const int Bn = u->cfg_half < 0 ? 2 : 1;
+    const bf16_t* aug = u->aug_emb + (u->cfg_half < 0 ? 0 : (size_t)u->cfg_half * c.temb_dim);
     // ---- time embedding: Timesteps row of this step -> MLP; + aug_emb; SiLU; every resnet's time_emb_proj in one GEMV
     UTRY(launch_gather_step_row(temb_table, step, w.temb_in, Bn, c.ch[0], s));
     UTRY(gemm(u, w.temb_in, u->te1w, u->te1b, nullptr, w.e1, Bn, c.temb_dim, c.ch[0], c.ch[0], 0, c.temb_dim, EPI_SILU, s));
     UTRY(gemm(u, w.e1, u->te2w, u->te2b, nullptr, w.emb, Bn, c.temb_dim, c.temb_dim, c.temb_dim, 0, c.temb_dim, EPI_NONE, s));
-    UTRY(launch_add_silu(w.emb, u->aug_emb, nullptr, w.semb, Bn * c.temb_dim, s));
+    UTRY(launch_add_silu(w.emb, aug, nullptr, w.semb, Bn * c.temb_dim, s));
     UTRY(gemm(u, w.semb, u->tpw, u->tpb, nullptr, w.temb_all, Bn, u->temb_total, c.temb_dim, c.temb_dim, 0, u->temb_total, EPI_NONE, s));
     // ---- conv_in
     int hs[3] = {H, (H + 1) / 2, (H + 3) / 4}, wsz[3] = {W, (W + 1) / 2, (W + 3) / 4};
@@ -669,6 +672,7 @@ int emu_unet_step(emu_unet* u, void* latents, int H, int W, const void* temb_tab
     if (!u || !u->finalized || !latents || !temb_table || !sigmas || !step_dev) return -22;
     if (!u->ctx_cache) return ufail(u, -22, "emu_unet_step: emu_unet_set_context has not been called");
     if ((H & 3) || (W & 3)) return ufail(u, -22, "emu_unet_step: latent H, W must be multiples of 4");
+    if (u->cfg_half >= 0) return ufail(u, -22, "emu_unet_step: one row of the CFG pair is set (emu_unet_set_cfg_half): emu_unet_forward + emu_unet_cfg_euler_step");
     const Ws w = plan_ws(u, H, W, workspace);
     u->splitk = w.splitk; u->splitk_floats = w.splitk_floats;
     if (w.total > ws_bytes) return ufail(u, -12, "emu_unet_step: workspace too small");
@@ -695,6 +699,20 @@ int emu_unet_forward(emu_unet* u, const void* latents, int H, int W, const void*
     UTRY(launch_unet_prep_input(B16(latents), reinterpret_cast<const float*>(sigmas), step_dev, w.colin, u->cfg.in_ch, H, W,
                                 u->cfg.kpad_in, s));
     return unet_body(u, w, H, W, B16(temb_table), step_dev, reinterpret_cast<bf16_t*>(eps_out), s);
+}
+
+int emu_unet_set_cfg_half(emu_unet* u, int half) {
+    if (!u || half < -1 || half > 1) return -22;
+    u->cfg_half = half;
+    return 0;
+}
+
+int emu_unet_cfg_euler_step(emu_unet* u, const void* eps_pair, void* latents, int H, int W, const void* sigmas, int32_t* step_dev,
+                            float guidance, emu_stream_t s_) {
+    if (!u || !eps_pair || !latents || !sigmas || !step_dev) return -22;
+    UTRY(launch_cfg_euler_step(B16(eps_pair), reinterpret_cast<bf16_t*>(latents), reinterpret_cast<const float*>(sigmas), step_dev, guidance,
+                               u->cfg.in_ch, H * W, S(s_)));
+    return 0;
 }
 
 }  // extern "C"

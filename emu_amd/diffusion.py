@@ -45,6 +45,14 @@ class EmuVisualGeneration:
         self.transform = lambda img: image_transform(img, eva_size, eva_mean, eva_std)
         self.negative_prompt = {}                   # "" / "[NULL_IMAGE]" -> embeds, computed once (diffusion.py:197-210)
         self.use_graph = True
+        # classifier-free guidance split over ranks 0 and 1 (``enable_cfg_split``): a single image's denoise loop then
+        # runs half the UNet rows per rank and exchanges 131 KB per step, instead of a full replica on every rank
+        self.cfg_pair = None
+
+    def enable_cfg_split(self) -> None:
+        """Collective over the default process group (torch.distributed must be initialised, world size >= 2)."""
+        from .tp import CfgPair
+        self.cfg_pair = CfgPair()
 
     def device(self, module=None):
         return self.multimodal_encoder.ctx.device
@@ -112,6 +120,11 @@ class EmuVisualGeneration:
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         if latents is None:
             latents = torch.randn((1, self.unet.cfg.in_channels, h, w), device=dev, dtype=BF16)
+        pair = self.cfg_pair
+        if pair is not None and pair.half is not None and guidance_scale > 1.0:
+            latents = pair.broadcast(latents.to(dev, BF16).contiguous())         # both ranks denoise rank 0's noise
+            latents = (latents * sch.init_noise_sigma).contiguous()
+            return self.unet.denoise_cfg_split(latents, guidance_scale, pair.half, pair.all_gather)
         latents = (latents.to(dev, BF16) * sch.init_noise_sigma).contiguous()
         return self.unet.denoise(latents, guidance_scale, use_graph=self.use_graph)
 

@@ -105,3 +105,34 @@ def image_parallel_encode(images: torch.Tensor, encode, rank: int, world: int, a
             if i < n:
                 out[i] = parts[r][j]
     return torch.stack(out, dim=0)
+
+
+class CfgPair:
+    """The two ranks that split the UNet's classifier-free-guidance pair (Emu2/emu/diffusion.py:131-145): ranks 0 and 1
+    of the default process group.  ``half``: 0 (cond) / 1 (uncond) on those ranks, None elsewhere (such ranks keep running a full
+    replica).  Every rank of the default group must construct it (``dist.new_group`` is collective).  Under gloo (ranks sharing
+    one GPU in the validation runs) the exchanges go through the host; under nccl (= RCCL) they stay on the device."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.group = dist.new_group([0, 1])
+        self.half = self.rank if self.rank < 2 else None
+        self.host = dist.get_backend() == "gloo"
+
+    def all_gather(self, t: torch.Tensor):
+        """[cond part, uncond part] of a device tensor held by each of the two ranks."""
+        src = t.cpu() if self.host else t
+        parts = [torch.empty_like(src) for _ in range(2)]
+        self.dist.all_gather(parts, src, group=self.group)
+        return [p.to(t.device) for p in parts] if self.host else parts
+
+    def broadcast(self, t: torch.Tensor) -> torch.Tensor:
+        """rank 0's tensor on both ranks (the initial latents: every rank draws from its own generator)."""
+        if self.host:
+            c = t.cpu()
+            self.dist.broadcast(c, src=0, group=self.group)
+            return c.to(t.device)
+        self.dist.broadcast(t, src=0, group=self.group)
+        return t

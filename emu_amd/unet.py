@@ -404,6 +404,40 @@ class UNetEngine:
                                   self.step_dev.data_ptr(), float(guidance), ws.data_ptr(), ws.numel(), ops.stream(self.device)),
               "emu_unet_step", self.ctx.handle)
 
+    # ------------------------------------------------------------------ CFG pair split over two ranks
+    def set_cfg_half(self, half: int) -> None:
+        """-1: the CFG pair in one batch (default); 0 / 1: this engine computes only the cond / uncond row (emu_unet_set_cfg_half)."""
+        check(lib().emu_unet_set_cfg_half(self.handle, int(half)), "emu_unet_set_cfg_half", self.ctx.handle)
+        self.cfg_half = int(half)
+        self._graph = None
+
+    @torch.no_grad()
+    def denoise_cfg_split(self, latents: torch.Tensor, guidance: float, half: int, all_gather, steps: Optional[int] = None):
+        """The loop of diffusion.py:130-149 with the classifier-free-guidance pair split over TWO ranks: this rank runs the UNet on
+        row ``half`` (0 = cond, 1 = uncond) only -- half the GEMM rows per step -- the two noise predictions ([H*W, 4] bf16: 131 KB at
+        128 x 128) are exchanged with ``all_gather`` (tensor -> [cond part, uncond part], torch.distributed.all_gather semantics
+        over the pair), and both ranks apply guidance + the Euler update to their own copy of the latents (identical inputs, same
+        kernel: identical latents on both ranks, asserted by the tests).  A single image's latency scales over the pair; beyond two
+        GPUs the UNet has nothing left to split cleanly (heads 5/10/20, channels 320: SURVEY 8e) and runs replicas."""
+        assert latents.is_cuda and latents.dtype == BF16 and latents.is_contiguous() and latents.shape[0] == 1 and half in (0, 1)
+        n = len(self.schedule.timesteps) if steps is None else steps
+        _, Cc, H, W = latents.shape
+        ws = self._workspace(H, W)
+        self.set_cfg_half(half)
+        try:
+            eps = torch.empty(H * W, Cc, device=self.device, dtype=BF16)
+            for _ in range(n):
+                check(lib().emu_unet_forward(self.handle, latents.data_ptr(), H, W, self.temb_table.data_ptr(), self.sigmas.data_ptr(),
+                                             self.step_dev.data_ptr(), eps.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream(self.device)),
+                      "emu_unet_forward", self.ctx.handle)
+                pair = torch.cat(list(all_gather(eps)), dim=0).contiguous()        # [2*H*W, 4], cond first
+                check(lib().emu_unet_cfg_euler_step(self.handle, pair.data_ptr(), latents.data_ptr(), H, W, self.sigmas.data_ptr(),
+                                                    self.step_dev.data_ptr(), float(guidance), ops.stream(self.device)),
+                      "emu_unet_cfg_euler_step", self.ctx.handle)
+        finally:
+            self.set_cfg_half(-1)
+        return latents
+
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, guidance: float = 3.0, use_graph: bool = True, steps: Optional[int] = None):
         """The loop of diffusion.py:130-149 on latents [1,4,H,W] (already multiplied by init_noise_sigma), in place.

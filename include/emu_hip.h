@@ -455,6 +455,15 @@ int emu_unet_step(emu_unet* u, void* latents, int H, int W, const void* temb_tab
 /* bare UNet forward (parity tests): eps_out NHWC [2*H*W, 4] for cat([latents]*2) / sqrt(sigmas[step]^2 + 1) */
 int emu_unet_forward(emu_unet* u, const void* latents, int H, int W, const void* temb_table, const void* sigmas,
                      const int32_t* step_dev, void* eps_out, void* workspace, size_t ws_bytes, emu_stream_t s);
+/* Classifier-free guidance split over a rank pair (Emu2/emu/diffusion.py:131-145 runs cat([latents] * 2) through the
+ * UNet and chunk(2)s the prediction): half = 0 / 1 makes emu_unet_forward compute ONLY the cond / uncond row of the pair (batch 1;
+ * eps_out is then [H*W, 4]) against the context emu_unet_set_context cached for both rows; -1 (default) restores the pair.  The
+ * ranks exchange their halves (131 KB per step at 128 x 128 latents) and each applies emu_unet_cfg_euler_step -- guidance + Euler
+ * update of emu_unet_step on eps_pair [2*H*W, 4] (cond first), advancing step_dev.  emu_unet_step refuses while a half is set. */
+int emu_unet_set_cfg_half(emu_unet* u, int half);
+int emu_unet_cfg_euler_step(emu_unet* u, const void* eps_pair, void* latents, int H, int W, const void* sigmas, int32_t* step_dev,
+                            float guidance, emu_stream_t s);
+
 
 #ifdef __cplusplus
 }

@@ -303,3 +303,56 @@ def test_pipeline_autoencoding_end_to_end(tiny_unet, tiny_vae, golden_dir):
 
 
 import numpy as np  # noqa: E402
+
+
+def test_cfg_half_rows_equal_the_pair(tiny_unet):
+    """CFG split (Emu2/emu/diffusion.py:131-145): the UNet on ONE row of the (cond, uncond) pair against the cached
+    context of both rows gives that row of the batch-2 prediction (same arithmetic; GEMM tile / K-slice choices follow the row
+    count, so equality is up to summation order: rel-L2 < 5e-3, and exact where the tiles agree), and a denoise loop whose two
+    halves are computed one after the other and exchanged equals the batched loop within bf16 noise."""
+    from emu_amd import ops
+    from emu_amd._lib import check, lib
+    eng, W, ocfg = tiny_unet
+    H = Wd = 16
+    prompt = rnd(2, 8, 128, seed=71)
+    sch = eng.set_timesteps(6)
+    eng.set_context(prompt.cuda(), 128, 128)
+    lat = (rnd(1, 4, H, Wd, seed=72).float() * sch.init_noise_sigma).to(BF16).cuda().contiguous()
+    pair = eng.forward(lat, 0)                                            # [2, 4, H, W]
+    halves = []
+    ws = eng._workspace(H, Wd)
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for half in (0, 1):
+        eng.set_cfg_half(half)
+        eps = torch.empty(H * Wd, 4, device="cuda", dtype=BF16)
+        check(lib().emu_unet_forward(eng.handle, lat.data_ptr(), H, Wd, eng.temb_table.data_ptr(), eng.sigmas.data_ptr(), st.data_ptr(),
+                                     eps.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream(eng.device)), "emu_unet_forward")
+        halves.append(eps.view(H, Wd, 4).permute(2, 0, 1).clone())
+    eng.set_cfg_half(-1)
+    for half in (0, 1):
+        assert rel_err(halves[half], pair[half]) < 5e-3, (half, rel_err(halves[half], pair[half]))
+    assert rel_err(halves[0], pair[1]) > 1e-2                             # the rows do differ (the context does)
+    # the whole loop: batched reference vs the split loop with a local stand-in for the peer (the other half computed here)
+    eng.set_timesteps(6)
+    ref = eng.denoise(lat.clone(), 3.0, use_graph=False)
+    eng.set_timesteps(6)
+    x = lat.clone()
+    other = {}
+
+    def gather(mine):                                                     # this rank is "cond"; the peer's row is computed in place
+        eng.set_cfg_half(1)
+        e = torch.empty_like(mine)
+        check(lib().emu_unet_forward(eng.handle, x.data_ptr(), H, Wd, eng.temb_table.data_ptr(), eng.sigmas.data_ptr(),
+                                     eng.step_dev.data_ptr(), e.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream(eng.device)), "emu_unet_forward")
+        eng.set_cfg_half(0)
+        other["n"] = other.get("n", 0) + 1
+        return [mine, e]
+    got = eng.denoise_cfg_split(x, 3.0, 0, gather)
+    assert other["n"] == 6
+    assert rel_err(got, ref) < 2e-2, rel_err(got, ref)
+    with pytest.raises(Exception):
+        eng.set_cfg_half(0)
+        try:
+            eng.step(lat.clone(), 3.0)                                    # the fused step refuses while a half is set
+        finally:
+            eng.set_cfg_half(-1)
