@@ -79,6 +79,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     EMU_TRACE_MARK(a.trace, 0);
+    const uint32_t pfd = prefetch_lines(a.pf_ptr, a.pf_bytes, blockIdx.x * T::THREADS + tid, gridDim.x * T::THREADS);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave / (T::WN * T::WM), wtile = wave % (T::WN * T::WM);
     const int wn = wtile / T::WM, wm = wtile % T::WM;
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(T::THREADS, T::MINW) void gemm2_kernel(const GemmAr
         }
     }
     wait_vmcnt<0>();                                   // drain the tail LDS-DMA before the LDS is released
+    prefetch_release(pfd);
     EMU_TRACE_MARK(a.trace, 2);
 #ifdef EMU_TRACE
     struct TraceEnd { unsigned long long* t; __device__ ~TraceEnd() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EMU_TRACE_MARK(t, 3); } } trace_end{a.trace};
@@ -830,6 +832,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     if (!a.partial) { a.partial = g_splitk_scratch; a.partial_floats = g_splitk_floats; }
     a.slice_rr = (g_tune >> 1) & 1;
+    if (g_tune & (1 << 16)) { a.pf_ptr = nullptr; a.pf_bytes = 0; }      // A/B: no successor prefetch
     if (a.cross_k) {                                   // the cross-attention epilogue lives on the 128 x 64 tile
         if constexpr (EPI == EPI_NONE && !CONV) { launch_cfg<EPI, CONV, CfgK>(a, s); EMU_CHECK_LAUNCH(); return 0; }
         return -22;
@@ -888,6 +891,7 @@ int launch_v2(const GemmArgs& a0, hipStream_t s) {
             if (a.ln_c) { rest.ln_c = a.ln_c + head.N; rest.ln_d = a.ln_d + head.N; }
             if (a.row_stats_out) rest.row_stats_out = a.row_stats_out + (size_t)(head.N / LN_SLOT_COLS) * a.M * 2;   // slots of 128 columns
             rest.C = a.C + (GLU ? head.N / 2 : head.N);
+            rest.pf_ptr = nullptr; rest.pf_bytes = 0;              // the head launch prefetches for the successor
             int st = launch_gemm256(head, s, -1, 1);
             if (st != 0) return st;
             const int keep = g_force_cfg;

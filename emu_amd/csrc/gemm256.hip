@@ -82,6 +82,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * QXB];
     const int tid = threadIdx.x, lane = tid & 63;
     EMU_TRACE_MARK(a.trace, 0);
+    const uint32_t pfd = prefetch_lines(a.pf_ptr, a.pf_bytes, blockIdx.x * 512u + tid, gridDim.x * 512u);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
         wait_vmcnt<2>();
     }
     bar();
+    prefetch_release(pfd);                          // (older than every tile load: complete behind the prologue's counted wait)
     EMU_TRACE_MARK(a.trace, 1);
     if (wr == 1) bar();                             // group 1 runs one barrier behind group 0
     for (int t = 0; t < nk; t += 2) {

@@ -65,6 +65,28 @@ __device__ __forceinline__ bool conv_tap(const ConvGeom& g, int py, int px, int 
 // consumer's registers (its 20 statistics pairs, the fp32 ln_c / ln_d quads) and vice versa.
 constexpr int FX_LN = 1;            // GemmArgs::ln_*: LayerNorm of A folded into this GEMM
 constexpr int FX_STATS = 2;         // GemmArgs::row_stats_out: emit per-row partial sums of C
+// successor prefetch (GemmArgs::pf_*): this thread's (at most two) lines, requested and never waited for; the value returned keeps
+// the destination register allocated until the caller has passed its first counted wait (loads return in order: the register is
+// written for the last time before any later load of the wave lands)
+__device__ __forceinline__ uint32_t prefetch_lines(const void* p, size_t bytes, uint32_t gid, uint32_t total) {
+    uint32_t d = 0;
+    if (p) {
+        const size_t lines = bytes >> 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t l = (size_t)gid + (size_t)i * total;
+            if (l < lines) {
+                // "+v": the destination stays LIVE between the two requests -- as a plain output the compiler reuses the register of a
+                // load still in flight as scratch for the second address, and the late dword then lands in an address (a wild
+                // global_load, MEMORY_APERTURE_VIOLATION: measured) -- and, being an input too, can never share the address pair
+                asm volatile("global_load_dword %0, %1, off" : "+v"(d) : "v"(reinterpret_cast<const char*>(p) + (l << 7)) : "memory");
+            }
+        }
+    }
+    return d;
+}
+__device__ __forceinline__ void prefetch_release(uint32_t d) { asm volatile("" :: "v"(d)); }
+
 constexpr int FX_VT = 4;            // GemmArgs::vt_out: V heads stored key-contiguous
 constexpr int FX_CROSS = 8;         // GemmArgs::cross_*: cross-attention over <= 64 cached keys in the epilogue (128 x 64 tile)
 constexpr int FX_ROPE = 16;         // GemmArgs::rope_*: RoPE + KV append (+ FX_VT) in the epilogue of the LLaMA prefill's qkv projection (256x256 tile)

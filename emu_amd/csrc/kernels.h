@@ -125,6 +125,17 @@ struct GemmArgs {
     int norm_ld = 0;
     float norm_eps = 0.f;
     int slab_rows = 0;                  // set by launch_gemm
+    // ---- successor prefetch: the weights of the launch that FOLLOWS this one on the stream (a model forward knows them).  Every
+    // thread requests up to two 128-byte lines of [pf_ptr, pf_ptr + pf_bytes) -- one dword each, consecutive lines on consecutive
+    // threads, results discarded -- ahead of its own first k tile, so the matrix travels HBM -> infinity cache while this GEMM runs
+    // and the successor finds it there (a GEMM over weights last touched a whole denoise step ago starts 1.5-4.7 us late and stalls
+    // on every k tile of a short K otherwise: profiles/r04_mall_prefetch_probe.log).  Used by the UNet's transformer blocks, whose
+    // matrices (3-26 MB) fit the two lines per thread: same-run 25.07 -> 24.19 ms per denoise step.  NOT used where a matrix is larger
+    // than that (ViT fc1 / fc2 55 MB, the LLaMA prefill): whole-matrix requests queue ahead of the wave's own first tile (ViT +4 %),
+    // and a capped k-major cover of every row's first tiles measured +1 % (ViT) / +2 % (prefill) and only -2 % on the UNet
+    // (scattered lines): profiles/r05_prefetch_ab_*.log.  nullptr = off; emu_gemm_tune bit 16 switches it off globally (A/B).
+    const void* pf_ptr = nullptr;
+    size_t pf_bytes = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // tools hook: where the next GEMM launches of a -DEMU_TRACE build write their per-workgroup timelines (nullptr = off)

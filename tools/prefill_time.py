@@ -24,19 +24,24 @@ if os.environ.get("EMU_PREFILL_FUSION") == "0":      # A/B: the rope_kv + transp
     eng.set_prefill_fusion(False)
 x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
 mask = torch.ones(1, S, dtype=torch.long, device=dev)
-ts = []
-with torch.no_grad():
-    cap = eng.kv_capacity(S + 64)
-    run = lambda: eng.prefill(x, mask, cap)
-    if graph:
-        run(); torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = eng.prefill(x, mask, cap)
-        run = g.replay
-    for i in range(reps + 2):
-        torch.cuda.synchronize(); t = time.perf_counter()
-        run()
-        torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t) * 1e3)
-print(f"prefill S={S}{' (hipGraph replay)' if graph else ''}{'' if eng.prefill_fusion else ' (rope_kv + transpose_v launches)'}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [tune {os.environ.get('EMU_TUNE', '0')}]", flush=True)
+from emu_amd._lib import lib
+tunes = [int(t) for t in os.environ["EMU_TUNES"].split(",")] if os.environ.get("EMU_TUNES") else [int(os.environ.get("EMU_TUNE", "0"))]
+for tune in tunes:                                     # EMU_TUNES=0,65536,0,65536: same-run A/B of emu_gemm_tune masks
+    lib().emu_gemm_tune(tune)
+    ts = []
+    with torch.no_grad():
+        cap = eng.kv_capacity(S + 64)
+        run = lambda: eng.prefill(x, mask, cap)
+        if graph:
+            run(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = eng.prefill(x, mask, cap)
+            run = g.replay
+        for i in range(reps + 2):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+    print(f"prefill S={S}{' (hipGraph replay)' if graph else ''}{'' if eng.prefill_fusion else ' (rope_kv + transpose_v launches)'}: min {min(ts[2:]):.2f} ms  "
+          f"median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [tune {tune}]", flush=True)

@@ -21,18 +21,25 @@ if fp8:
     eng.use_fp8(True)
 if os.environ.get("EMU_VIT_FUSION"):                 # A/B: emu_vit_set_fusion mask (0 = the launch sequence of rounds 1-3, 3 = default)
     eng.set_fusion(int(os.environ["EMU_VIT_FUSION"]))
-ts = []
-with torch.no_grad():
-    run = lambda: eng.forward(img)
-    if graph:
-        eng.forward(img); torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = eng.forward(img)
-        run = g.replay
-    for i in range(reps + 2):
-        torch.cuda.synchronize(); t = time.perf_counter()
-        run()
-        torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t) * 1e3)
-print(f"vit encode{' (W8A8 blocks)' if fp8 else ''}{' (hipGraph replay)' if graph else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  [fusion mask {os.environ.get('EMU_VIT_FUSION', '3')}]", flush=True)
+batch = int(os.environ.get("EMU_VIT_BATCH", "1"))        # images per encode (configs[2]: 4)
+if batch > 1:
+    img = img.expand(batch, -1, -1, -1).contiguous()
+from emu_amd._lib import lib
+for tune in [int(x) for x in os.environ.get("EMU_TUNES", "0").split(",")]:        # same-run A/B of emu_gemm_tune masks (65536 = no prefetch)
+    lib().emu_gemm_tune(tune)
+    ts = []
+    with torch.no_grad():
+        run = lambda: eng.forward(img)
+        if graph:
+            eng.forward(img); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = eng.forward(img)
+            run = g.replay
+        for i in range(reps + 2):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+    print(f"vit encode{' (W8A8 blocks)' if fp8 else ''}{' (hipGraph replay)' if graph else ''}: min {min(ts[2:]):.2f} ms  median {sorted(ts[2:])[len(ts[2:]) // 2]:.2f} ms  "
+          f"[fusion mask {os.environ.get('EMU_VIT_FUSION', '3')}, batch {batch}, tune {tune}]", flush=True)
