@@ -630,18 +630,22 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         d.kcache = m->kcache; d.vcache = m->vcache; d.kv_layer = kv_layer;
         d.H = H; d.Hl = Hl; d.Fl = Fl; d.S_max = m->s_max; d.ctx_max = ctx;
         d.eps = c.rms_eps; d.scale = scale; d.epi_res = (!tp || cx->tp_rank == 0) ? 1 : 0;
-        d.cnt = m->dl_cnt; d.err = m->dl_err; d.limit_ticks = 20000000LL;          // 0.2 s
+        // wait bound: 2 s of wall clock (100 MHz ticks), or the peer-to-peer time-out where that is longer -- rank processes that SHARE
+        // a GPU (validation runs) are time-sliced against each other, and a wave that is switched out keeps its start time: the 0.2 s
+        // of the first version ran out under eight ranks on one device (garbage from step 4 on, give-ups counted)
+        d.cnt = m->dl_cnt; d.err = m->dl_err; d.limit_ticks = 200000000LL;
         d.trace = m->dl_trace;
         bool ok = decode_layers_ok(d);
         // tensor parallelism: mode 2 runs the all-reduces inside the launch over the P2P comm blocks (every rank on its own GPU); mode 1
         // cuts every layer at its two all-reduces -- [q, attention, o_proj] | all-reduce | [gate/up, down] | all-reduce -- which also
         // serves RCCL and ranks that share a GPU (a launch that waits for a peer must not hold the CUs the peer needs)
         bool in_kernel_ar = false;
-        if (ok && tp && m->decode_fused == 2) {
+        if (ok && tp && cx->p2p) {
             long long lim = 0;
-            in_kernel_ar = cx->p2p_on && emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &lim);
+            const bool view = emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &lim);
+            in_kernel_ar = view && cx->p2p_on && m->decode_fused == 2;
             if (!in_kernel_ar) d.tp_n = 0;
-            else if (lim > d.limit_ticks) d.limit_ticks = lim;     // a lagging peer holds every downstream wait: the peer bound applies
+            if (view && lim > d.limit_ticks) d.limit_ticks = lim;  // a lagging peer holds every downstream wait: the peer bound applies
             ok = decode_layers_ok(d);
         }
         if (ok) {

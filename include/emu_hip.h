@@ -283,8 +283,10 @@ int emu_llama_set_decode_tail(emu_llama* m, int enable);
  * ([q, attention, o_proj] | emu_allreduce_bf16 | [gate/up, down] | emu_allreduce_bf16: four launches instead of eight), and
  * enable == 2 runs the all-reduces INSIDE the launch over the P2P comm blocks (emu_tp_p2p_enable must be on, else as 1): the
  * workgroup that completes o_proj / down_proj runs the peer exchange while the consumers' weight slices are already in flight.
- * Mode 2 needs every rank on its own GPU (a launch that waits for a peer holds its CUs).  Every in-kernel wait is bounded in
- * wall-clock time.
+ * Mode 2 needs every rank on its own GPU (a launch that waits for a peer holds its CUs), and every fused mode needs the DEVICE TO
+ * ITSELF: processes that share a GPU can starve each other's producer workgroups of CU slots (observed with eight rank processes on
+ * one device: a time-out, then garbage and a non-zero give-up count).  Every in-kernel wait is bounded in wall-clock time (2 s, or
+ * the peer-to-peer time-out where longer).
  * The first fused forward after a weight change uploads a pointer table and must therefore run outside stream capture (-16).
  * Replaces: the per-layer module calls of the LlamaDecoderLayer loop (Emu2/emu/emu.py:133-138, :213-229) and the device hops of
  * Emu2/emu/mixin.py:44-81. */

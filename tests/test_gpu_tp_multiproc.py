@@ -42,6 +42,20 @@ def test_engine_tp_ranks_sharing_one_gpu(world):
     assert r.stdout.count("p2p all-reduce on") == world, r.stdout[-3000:]
 
 
+def test_engine_tp8_true_width_shards():
+    """Eight ranks sharing this GPU, a 2-layer decoder at the true LLaMA-33B width (52 -> 56 heads, 7 per rank; ffn 2240 per rank):
+    greedy ids of the unsharded engine on the same weights at every step whose top-2 logit margin is clear, eager and replayed
+    from a hipGraph (tests/tp_truewidth_worker.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", EMU_TP_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "tp_truewidth_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ids match") == 2 and "DIFFER" not in r.stdout, r.stdout[-3000:]
+
+
 def test_bench_two_ranks_sharing_one_gpu():
     """`bench.py --gpus 2` end to end (what the driver launches on a multi-GPU node), at reduced depth, with both ranks on this one
     device (EMU_TP_SHARED_GPU=1: gloo rendezvous, every all-reduce through the peer-to-peer kernels): one JSON line from rank 0

@@ -104,13 +104,16 @@ def main():
         ok &= p2p_checks(ctx, dev, rank, world)
     m = EmuModel(v, TextDecoderCfg(instruct=True), llama_cfg=l, device=dev, ctx=ctx)
     m.load_state_dict(W, strict=True)
-    for use_graph in (False, True):
+    # fused decode layers (cut at the all-reduces) as well where the ranks' grids are small enough to be resident together: two ranks
+    # of the tiny model (a launch that waits inside must not starve the other rank's producers of CU slots: one GPU per rank otherwise)
+    for use_graph, fused in ((False, 0), (True, 0)) + (((False, 1), (True, 1)) if world == 2 else ()):
         m.use_graph = use_graph
+        m.decoder.lm.set_decode_fused(fused)
         got1 = m.generate_ids(t(z["ids1"]), t(z["mask1"]), t(z["image"]).to(dev), max_new_tokens=8).cpu()
         got2 = m.generate_ids(t(z["ids2"]), t(z["mask2"]), None, max_new_tokens=6).cpu()
         ok &= got1.tolist() == z["new1"].tolist() and got2.tolist() == z["new2"].tolist()
         if not ok:
-            print(f"rank {rank} graph={use_graph}: {got1.tolist()} vs {z['new1'].tolist()}; {got2.tolist()} vs {z['new2'].tolist()}",
+            print(f"rank {rank} graph={use_graph} fused={fused}: {got1.tolist()} vs {z['new1'].tolist()}; {got2.tolist()} vs {z['new2'].tolist()}",
                   flush=True)
     # every rank holds the same ids (the all-reduced hidden state is identical on all ranks)
     flag = torch.tensor([1 if ok else 0], device="cpu" if shared else dev)
