@@ -891,23 +891,22 @@ def main():
     # HBM traffic of the GEMV launches comes from PMC counters (FETCH_SIZE), which a timing run cannot collect itself:
     # the committed pass over THIS command (profiles/r03_gemv_pmc_traffic.json, gfx950-corrected) gives traffic /
     # algorithmic bytes for the same kernels; traffic = that ratio x this run's algorithmic bytes per launch
-    traffic, traffic_src = None, None
-    try:
-        here = os.path.dirname(os.path.abspath(__file__))
-        pmc = json.load(open(os.path.join(here, "profiles", "r03_gemv_pmc_traffic.json")))
-        if pmc.get("source_sha256") != gemv_source_hash():
-            traffic_src = ("profiles/r03_gemv_pmc_traffic.json is STALE (taken on other kernel sources: re-run tools/pmc_traffic.sh); "
-                           "traffic not reported")
-        else:
+    traffic, traffic_src = None, "no PMC pass over the GEMV sources committed"
+    for rnd in ("r05", "r03"):                               # the newest committed pass whose kernel sources are these
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_gemv_pmc_traffic.json")))
+        except Exception:
+            continue
+        if pmc.get("source_sha256") == gemv_source_hash():
             ratio = float(pmc["all_gemv_launches"]["traffic_over_algorithmic"])
             traffic = ratio * bytes_per_launch
-            traffic_src = ("profiles/r03_gemv_pmc_traffic.json (same kernel sources, sha256 checked): rocprofv3 --pmc FETCH_SIZE "
+            traffic_src = (f"profiles/{rnd}_gemv_pmc_traffic.json (same kernel sources, sha256 checked): rocprofv3 --pmc FETCH_SIZE "
                            f"pass over `bench.py --pmc-mode`, gfx950-corrected; traffic / algorithmic = {ratio:.4f}")
-    except Exception as e:
-        traffic_src = f"no PMC pass available ({type(e).__name__})"
+            break
+        traffic_src = f"profiles/{rnd}_gemv_pmc_traffic.json is STALE (taken on other kernel sources: re-run tools/pmc_traffic.sh); traffic not reported"
 
     prefill_traffic, prefill_traffic_src = None, "no PMC pass over the GEMM sources committed"
-    for rnd in ("r04", "r03"):                               # the newest committed pass whose kernel sources are these
+    for rnd in ("r05", "r04", "r03"):                        # the newest committed pass whose kernel sources are these
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_prefill_gemm_pmc_traffic.json")))
         except Exception:
