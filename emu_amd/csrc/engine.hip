@@ -86,6 +86,9 @@ int emu_ctx_fail(emu_ctx* c, int code, const char* what) { return fail(c, code, 
 
 bool emu_prof_on() { return g_lprof.on; }
 void emu_prof_begin(hipStream_t s) {
+    g_lprof.cur_a = nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;             // eager launches only: no events inside a stream capture
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
     if (g_lprof.used == g_lprof.pool.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_lprof.cur_a = nullptr; return; }
@@ -95,6 +98,10 @@ void emu_prof_begin(hipStream_t s) {
     g_lprof.cur_b = g_lprof.pool[g_lprof.used].second;
     ++g_lprof.used;
     (void)hipEventRecord(g_lprof.cur_a, s);
+}
+void emu_prof_drop() {                                   // the launch between begin and end did not happen (-95 / -22): forget the pair
+    if (g_lprof.cur_a && g_lprof.used) --g_lprof.used;
+    g_lprof.cur_a = nullptr;
 }
 void emu_prof_end(hipStream_t s, const char* klass, int M, int N, int K, int tag, double flops) {
     if (!g_lprof.cur_a) return;

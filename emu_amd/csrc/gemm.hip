@@ -1025,7 +1025,8 @@ int launch_gemm_fp8(const GemmArgs& a, hipStream_t s) {
     if (!emu_prof_on()) return launch_gemm_fp8_impl(a, s);
     emu_prof_begin(s);
     const int st = launch_gemm_fp8_impl(a, s);
-    emu_prof_end(s, "gemm_fp8", a.M, a.N, a.K, a.epi, 2.0 * a.M * a.N * a.K);
+    if (st == 0) emu_prof_end(s, "gemm_fp8", a.M, a.N, a.K, a.epi, 2.0 * a.M * a.N * a.K);
+    else emu_prof_drop();
     return st;
 }
 
@@ -1034,7 +1035,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (!emu_prof_on()) return launch_gemm_impl(a, s);
     emu_prof_begin(s);
     const int st = launch_gemm_impl(a, s);
-    emu_prof_end(s, a.conv.mode != CONV_NONE ? "conv" : "gemm", a.M, a.N, a.K, a.epi | (gemm_fx(a) << 8), 2.0 * a.M * a.N * a.K);
+    if (st == 0) emu_prof_end(s, a.conv.mode != CONV_NONE ? "conv" : "gemm", a.M, a.N, a.K, a.epi | (gemm_fx(a) << 8), 2.0 * a.M * a.N * a.K);
+    else emu_prof_drop();                                  // (a -95 probe of a fused form, a refused shape: nothing was launched)
     return st;
 }
 static int launch_gemm_impl(const GemmArgs& a, hipStream_t s) {

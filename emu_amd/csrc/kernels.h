@@ -165,6 +165,7 @@ int emu_gemm_tune_get();
 bool emu_prof_on();
 void emu_prof_begin(hipStream_t s);
 void emu_prof_end(hipStream_t s, const char* klass, int M, int N, int K, int tag, double flops);
+void emu_prof_drop();                   // the wrapped launch returned non-zero (not launched: -95 probe, -22): record nothing
 
 // ---- row-wise / elementwise (elementwise.hip)
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int cols, int ldx, int ldy, float eps, hipStream_t s);

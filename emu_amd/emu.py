@@ -224,6 +224,12 @@ class EmuModel:
                                                         int(top_k), min_len, repetition_penalty, eos_id=eos,
                                                         pad_id=PAD_TOKEN_ID)
         if num_beams > 1:
+            if sem == "4.31" and min_len < 1:
+                # 4.31's BeamHypotheses.add scores an EOS hypothesis over hyp.shape[-1] ** length_penalty with the EOS excluded: a
+                # hypothesis that ends at the first step has length 0 (0 ** lp), a case that release only avoids through its
+                # min_length = 1 default; the restatement here does not define it either
+                raise ValueError("beam search under hf_semantics='4.31' needs min_len >= 1 (an EOS hypothesis of length 0 is scored over "
+                                 "0 ** length_penalty in that release); pass min_len >= 1 or hf_semantics='5.x'")
             return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
                                                         length_penalty, eos_id=eos, pad_id=PAD_TOKEN_ID,
                                                         do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,

@@ -341,6 +341,18 @@ class LlamaEngine:
 
     KV_SHARE_MAX = 8                                   # DECODE_SHARE_MAX of the decode attention kernel
 
+    def release_kv(self, which: Optional[str] = None) -> None:
+        """Free the persistent KV caches (``which`` = "main" / "beam" / None for both): alloc_kv keeps the main and the beam cache
+        resident for the life of the engine (several GB per rank after one 5-beam search at 60 layers) so that captured graphs stay
+        valid; a server that is done with beam search hands the memory back here.  Captured decode graphs are dropped."""
+        slots = self.__dict__.get("_kv_slots", {})
+        for k in ([which] if which else list(slots)):
+            cur = slots.pop(k, None)
+            if cur is not None and self.kcache is cur[0]:      # the engine's current cache goes: the next prefill allocates anew
+                self.kcache = self.vcache = None
+                self.kv_batch = self.s_max = 0
+        self._mode_changed()
+
     def set_kv_share(self, rows_per_prompt: int, shared_slots: int) -> None:
         """Groups of ``rows_per_prompt`` consecutive cache rows keep their first ``shared_slots`` slots (the prompt) in the
         group's first row only (include/emu_hip.h: emu_llama_set_kv_share); (0, 0) = every row owns its slots."""

@@ -147,3 +147,16 @@ def test_mode_switch_drops_graphs():
     torch.cuda.synchronize()
     assert eng.decode_fused_stats()[1] > f0          # the later steps ran fused (warm-up step of the re-capture at least)
     assert torch.equal(out, ref[0])
+
+
+def test_release_kv_frees_and_reallocates():
+    """the persistent main / beam caches can be handed back (LlamaEngine.release_kv); the next prefill allocates anew."""
+    from emu_amd.conf.emu_conf import LlamaCfg
+    cfg = LlamaCfg(**CFGS["wave"])
+    eng = _engine(cfg, 1024)
+    a = _run(eng, 0, 100, 3)
+    assert eng.kcache is not None
+    eng.release_kv()
+    assert eng.kcache is None and not eng.__dict__.get("_kv_slots")
+    b = _run(eng, 0, 100, 3)
+    _same(a, b)

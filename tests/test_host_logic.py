@@ -661,3 +661,18 @@ def test_product_beam_search_finished_hypotheses_real_reference(golden_dir, monk
         if eos_first:
             assert not bool((got431[:, 0] == eos).any()), key          # 4.31 never returns EOS as the first token (min_length 1)
     assert n_cases >= 5 and 0 < n_first < n_cases                         # both kinds of case are present
+
+
+def test_effective_min_len_per_release():
+    """min_length under inputs_embeds: transformers 5.x subtracts the prompt length (GenerationMixin._prepare_generated_length), 4.31
+    counts generated tokens (restated); pinned by the real library's EOS-first rows in tests/golden/generate_beam_eos_tiny.npz."""
+    assert R.effective_min_len(1, 12, "5.x") == 0 and R.effective_min_len(1, 12, "4.31") == 1
+    assert R.effective_min_len(20, 12, "5.x") == 8 and R.effective_min_len(0, 12, "4.31") == 0
+    import inspect
+    try:
+        from transformers.generation import utils
+        src = inspect.getsource(utils.GenerationMixin._prepare_generated_length)
+    except Exception:
+        pytest.skip("transformers internals not importable")
+    if "min_length - inputs_tensor.shape[1]" not in src.replace("generation_config.", ""):
+        pytest.skip("the installed transformers words the correction differently")
