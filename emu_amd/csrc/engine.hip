@@ -504,7 +504,7 @@ int emu_llama_set_decode_fused(emu_llama* m, int enable, int layers_per_launch) 
             return fail(m->ctx, -12, "emu_llama_set_decode_fused: device allocation");
         m->dl_dirty = true;
     }
-    m->decode_fused = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    m->decode_fused = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
     m->dl_per_launch = layers_per_launch;
     return 0;
 }
@@ -673,7 +673,29 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             for (int l = m->l0; l < l_end; ++l)
                 if (!m->layers[l].wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
             if (hipMemsetAsync(m->dl_cnt, 0, m->dl_cnt_bytes, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
+            if (tp && m->decode_fused == 3 && cx->p2p_on && emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &d.limit_ticks)) {
+                // mode 3: the weight streams with an RMSNorm in front stay stand-alone launches; the attention (split merge by the
+                // head's last split) and the two row-sharded projections run as single-role launches whose LAST workgroup to arrive
+                // runs the all-reduce -- nobody waits inside a launch except that one workgroup for its peers, so rank processes that
+                // share a device cannot starve each other: 5 launches per layer instead of 8
+                if (d.limit_ticks < 200000000LL) d.limit_ticks = 200000000LL;
+                for (int l = m->l0; l < l_end; ++l) {
+                    const emu_llama::Layer& L = m->layers[l];
+                    d.layer0 = l; d.nlayers = 1;
+                    TRY(cx, linear(hA, L.wqkv, nullptr, nullptr, L.ln1, w.qkv, 1, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
+                    DecodeLayersArgs a1 = d; a1.tp_n = 0; a1.role0 = 1; a1.role1 = 2;
+                    TRY(cx, launch_decode_layers(a1, s));
+                    d.role0 = 2; d.role1 = 3;
+                    TRY(cx, launch_decode_layers(d, s));
+                    TRY(cx, linear(w.hB, L.wgu, nullptr, nullptr, L.ln2, w.act, 1, 2 * Fl, H, H, H, 0, Fl, c.rms_eps, EPI_SWIGLU, s));
+                    d.role0 = 4; d.role1 = 5;
+                    TRY(cx, launch_decode_layers(d, s));
+                }
+                ++m->dl_forwards;
+                return 0;
+            }
             if (tp && !in_kernel_ar) {
+                d.tp_n = 0;
                 for (int l = m->l0; l < l_end; ++l) {
                     d.layer0 = l; d.nlayers = 1;
                     d.role0 = 0; d.role1 = 3;

@@ -283,8 +283,12 @@ int emu_llama_set_decode_tail(emu_llama* m, int enable);
  * ([q, attention, o_proj] | emu_allreduce_bf16 | [gate/up, down] | emu_allreduce_bf16: four launches instead of eight), and
  * enable == 2 runs the all-reduces INSIDE the launch over the P2P comm blocks (emu_tp_p2p_enable must be on, else as 1): the
  * workgroup that completes o_proj / down_proj runs the peer exchange while the consumers' weight slices are already in flight.
+ * enable == 3 (tensor parallelism with the P2P path on; otherwise as 1): the two RMSNorm-fronted weight streams stay stand-alone
+ * launches, the attention (its split merge done by the head's last split) and the two row-sharded projections run as single-role
+ * launches whose LAST workgroup to arrive runs the all-reduce in its tail -- 5 launches per layer instead of 8, and nothing waits
+ * inside a launch except that one workgroup for its peers, so this mode is safe for rank processes sharing a device.
  * Mode 2 needs every rank on its own GPU (a launch that waits for a peer holds its CUs), and every fused mode needs the DEVICE TO
- * ITSELF: processes that share a GPU can starve each other's producer workgroups of CU slots (observed with eight rank processes on
+ * ITSELF (modes 1 and 2; also mode 1's cut layers wait inside their launches): processes that share a GPU can starve each other's producer workgroups of CU slots (observed with eight rank processes on
  * one device: a time-out, then garbage and a non-zero give-up count).  Every in-kernel wait is bounded in wall-clock time (2 s, or
  * the peer-to-peer time-out where longer).
  * The first fused forward after a weight change uploads a pointer table and must therefore run outside stream capture (-16).

@@ -104,7 +104,7 @@ def test_fused_equals_launches_llama33b_width():
 @pytest.mark.parametrize("tp", [2, 8])
 def test_fused_tp_shard_modes(tp):
     """Rank 0's shard of a TP decoder with a one-rank P2P comm block: launches + all-reduce kernel (mode 0), layers cut at the
-    all-reduces (1) and the all-reduce inside the launch (2) give the same bits; TP = 8 takes the wave forms (7 heads, K = 896)."""
+    all-reduces (1), the all-reduce inside the launch (2) and in the tail of single-role launches (3) give the same bits; TP = 8 takes the wave forms (7 heads, K = 896)."""
     from emu_amd.conf.emu_conf import LlamaCfg
     cfg = LlamaCfg(num_hidden_layers=2)
     eng = _engine(cfg, 2048, tp=tp, p2p=True)
@@ -115,7 +115,12 @@ def test_fused_tp_shard_modes(tp):
     g, f1 = eng.decode_fused_stats()
     assert g == 0 and f1 - f0 == 5
     _same(ref, _run(eng, 2, 200, 5, graph=True))
-    assert eng.decode_fused_stats()[0] == 0
+    # mode 3: the all-reduce in the tail of the single-role o_proj / down_proj launches, the split merge in the attention launch
+    f2 = eng.decode_fused_stats()[1]
+    _same(ref, _run(eng, 3, 200, 5))
+    _same(ref, _run(eng, 3, 200, 5, graph=True))
+    g, f3 = eng.decode_fused_stats()
+    assert g == 0 and f3 > f2
     eng.ctx.check_p2p()
 
 

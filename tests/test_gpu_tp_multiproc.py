@@ -45,7 +45,8 @@ def test_engine_tp_ranks_sharing_one_gpu(world):
 def test_engine_tp8_true_width_shards():
     """Eight ranks sharing this GPU, a 2-layer decoder at the true LLaMA-33B width (52 -> 56 heads, 7 per rank; ffn 2240 per rank):
     greedy ids of the unsharded engine on the same weights at every step whose top-2 logit margin is clear, eager and replayed
-    from a hipGraph (tests/tp_truewidth_worker.py)."""
+    from a hipGraph, with the stand-alone all-reduce launches and with the all-reduce in the projections' tails (mode 3)
+    (tests/tp_truewidth_worker.py)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", EMU_TP_SHARED_GPU="1")
@@ -53,7 +54,7 @@ def test_engine_tp8_true_width_shards():
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "tp_truewidth_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("ids match") == 2 and "DIFFER" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("ids match") == 4 and "DIFFER" not in r.stdout, r.stdout[-3000:]
 
 
 def test_bench_two_ranks_sharing_one_gpu():

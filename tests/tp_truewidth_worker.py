@@ -2,7 +2,8 @@
 every all-reduce through the peer-to-peer kernels) run a 2-layer decoder at the TRUE LLaMA-33B width -- 52 heads padded to 56,
 seven per rank, ffn 17920 / 8 = 2240, the wave-form o_proj / down_proj of the shards -- and must generate the greedy ids of the
 unsharded engine on the same weights wherever the unsharded run's top-2 logit margin is clear (lm_head x 8; steps behind the first
-unclear margin are not compared).  The launches only: the fused decode layers (emu_llama_set_decode_fused) wait inside a launch, and
+unclear margin are not compared).  The launches, and mode 3 of emu_llama_set_decode_fused (the all-reduce in the tail of the o_proj /
+down_proj launches: only that one workgroup waits, for its peers); the fused layers of modes 1 / 2 wait inside a launch, and
 rank processes that SHARE a device can starve each other's producer workgroups of CU slots (a 20 s time-out and garbage, observed
 with eight ranks here) -- that path needs the device to itself and is covered per shard in tests/test_gpu_decode_fused.py.
 Exit code 0 = pass."""
@@ -74,7 +75,7 @@ def main():
     eng = LlamaEngine(cfg, V, ctx)
     eng.load_weights(weights())
     ok = decided >= 6
-    for mode in (0,):
+    for mode in (0, 3):
         eng.set_decode_fused(mode)
         for use_graph in (False, True):
             with torch.no_grad():

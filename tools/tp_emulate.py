@@ -2,7 +2,8 @@
 """Per-rank decode cost of a TP shard on ONE GPU: rank 0's 1/tp slice of LLaMA-33B with a 1-rank RCCL communicator in the
 loop (the all-reduce launches are real, their cross-GPU latency is not).  With a third argument "p2p" the all-reduces are the
 one-shot peer-to-peer kernel (csrc/p2p.hip) with one rank instead.  Usage: python tools/tp_emulate.py [tp] [steps] [p2p|rccl] [modes, e.g. 0,1,2]
-(modes: emu_llama_set_decode_fused -- 0 launches, 1 fused layers cut at the all-reduces, 2 all-reduce inside the launch; tp = 1: 0,1)"""
+(modes: emu_llama_set_decode_fused -- 0 launches, 1 fused layers cut at the all-reduces, 2 all-reduce inside the launch, 3 the all-reduce in the
+tail of the o_proj / down_proj launches; tp = 1: 0,1)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,8 +38,9 @@ eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device
 S = 770
 x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
 mask = torch.ones(1, S, dtype=torch.long)
-modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2]
-names = {0: "launches (8 per layer)", 1: "fused, cut at the all-reduces (4 launches per layer)", 2: "fused, all-reduce inside (1 launch per token)"}
+modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2, 3]
+names = {0: "launches (8 per layer)", 1: "fused, cut at the all-reduces (4 launches per layer)", 2: "fused, all-reduce inside (1 launch per token)",
+         3: "tail all-reduce (5 launches per layer: qkv | attention | o_proj + all-reduce | gate/up | down + all-reduce)"}
 with torch.no_grad():
     hidden, kstart, next_pos = eng.prefill(x, mask, eng.kv_capacity(S + steps + 24))
     cur = ops.argmax(eng.logits(hidden[:, -1, :]), suppress_id=2)
