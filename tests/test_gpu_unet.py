@@ -356,3 +356,31 @@ def test_cfg_half_rows_equal_the_pair(tiny_unet):
             eng.step(lat.clone(), 3.0)                                    # the fused step refuses while a half is set
         finally:
             eng.set_cfg_half(-1)
+
+
+def test_successor_prefetch_changes_no_bit(tiny_unet):
+    """GemmArgs::pf_* (the UNet's transformer GEMMs request their successor's weight matrix from inside the kernel): requests only,
+    results discarded -- the noise prediction and a whole denoise loop are BIT-identical with the prefetch switched off
+    (emu_gemm_tune bit 16), eager and replayed from a hipGraph."""
+    from emu_amd._lib import lib
+    eng, W, ocfg = tiny_unet
+    H = Wd = 16
+    prompt = rnd(2, 8, 128, seed=81)
+    outs = {}
+    try:
+        for tune in (0, 1 << 16):
+            lib().emu_gemm_tune(tune)
+            sch = eng.set_timesteps(5)
+            eng.set_context(prompt.cuda(), 128, 128)
+            lat = (rnd(1, 4, H, Wd, seed=82).float() * sch.init_noise_sigma).to(BF16).cuda().contiguous()
+            eps = eng.forward(lat, 0).clone()
+            a = eng.denoise(lat.clone(), 3.0, use_graph=False).clone()
+            eng.set_timesteps(5)
+            eng._graph = None
+            b = eng.denoise(lat.clone(), 3.0, use_graph=True).clone()
+            outs[tune] = (eps, a, b)
+    finally:
+        lib().emu_gemm_tune(0)
+    for x, y in zip(outs[0], outs[1 << 16]):
+        assert torch.equal(x, y)
+    assert torch.equal(outs[0][1], outs[0][2])
