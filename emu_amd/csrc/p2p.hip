@@ -6,9 +6,9 @@
 // 16-byte vector per lane each (13 KB = 2 workgroups, 256 KiB = 32), and every piece runs the protocol on its own counter,
 // flag and slot region.  All-reduce number s of a piece (a device-side counter, so a captured hipGraph replays correctly)
 // uses slot s & 1:
-//   1. copy my partial vector into MY slot, system-scope release, flag[slot] = s;
-//   2. for every rank r in rank order (my own included): wait until r's flag[slot] >= s (system-scope acquire), read r's
-//      slot over xGMI, add in fp32 -- the same order on every rank, so all ranks hold bit-identical sums;
+//   1. copy my partial vector into MY slot with system-scope (write-through) stores, wait for their acknowledgement, flag[slot] = s;
+//   2. for every rank r in rank order (my own included): wait until r's flag[slot] >= s, read r's slot over xGMI with
+//      system-scope loads, add in fp32 -- the same order on every rank, so all ranks hold bit-identical sums;
 //   3. round to bf16 in place.
 // Point-to-point xGMI means every rank reads the other N - 1 vectors directly (N - 1 links busy per rank, one hop, no
 // ring): for 13 KB the cost is one flag round trip + one remote read, not 2 (N - 1) ring steps.
@@ -55,6 +55,11 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
     const int e0 = g * P2P_PIECE + tid * 8;                                 // my 8 elements
     const size_t off = (size_t)slot * EMU_P2P_SLOT_BYTES + (size_t)e0 * 2;
     const bool full = e0 + 8 <= n, part = e0 < n;
+    // The exchange carries no cache-wide fence (round 5; the first version bracketed it with two __threadfence_system(), ~3.5 us each
+    // of the launch's 6.8): the slot is written with system-scope (sc0 sc1, write-through) stores whose acknowledgement the wave waits
+    // for before the flag goes out, and read with system-scope loads, which no cache level serves -- MI355X_MICROARCH.md's
+    // "{sc0 sc1 stores and loads both sides}" form, the one csrc/decode_layer.hip's in-launch all-reduce uses as well.
+    const __amdgpu_buffer_rsrc_t rmine = __builtin_amdgcn_make_buffer_rsrc(p.block[p.rank], 0, (uint32_t)(2 * EMU_P2P_SLOT_BYTES), 0x00020000);
     // ---- 1. publish my piece
     if (part) {
         u32x4 v;
@@ -64,29 +69,30 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
             for (int j = 0; e0 + j < n; ++j) t[j] = x[e0 + j];
             v = *reinterpret_cast<u32x4*>(t);
         }
-        *reinterpret_cast<u32x4*>(p.block[p.rank] + off) = v;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmine, (uint32_t)off, 0, 17);
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's share has reached the system's point of coherence
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag_of(p.block[p.rank], slot, g), s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(flag_of(p.block[p.rank], slot, g), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // ---- 2. wait for every rank's piece of this sequence number
     if (tid < p.n) {
         unsigned long long* f = flag_of(p.block[tid], slot, g);
         const bool dead = __hip_atomic_load(&g_p2p_giveups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < s) {
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < s) {
             if (dead || wall_clock64() - t0 > p.limit_ticks) { atomicAdd(&g_p2p_giveups, 1u); break; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
     __syncthreads();
-    __threadfence_system();                                                // every wave: nothing of this slot's previous use is cached
     // ---- 3. sum in rank order, fp32
     if (part) {
         u32x4 v[EMU_P2P_MAX_RANKS];
 #pragma unroll
         for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r)
-            if (r < p.n) v[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.block[r] + off));
+            if (r < p.n)
+                v[r] = __builtin_amdgcn_raw_buffer_load_b128(
+                    __builtin_amdgcn_make_buffer_rsrc(p.block[r], 0, (uint32_t)(2 * EMU_P2P_SLOT_BYTES), 0x00020000), (uint32_t)off, 0, 17);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r)
