@@ -21,6 +21,7 @@ if p2p:
 elif not (len(sys.argv) > 3 and sys.argv[3] == "none"):       # "none": no communicator at all (the tp = 1 decode, modes 0,1)
     real.init_tp(lambda b: b, force=True)
 per_launch = int(os.environ.get("EMU_DL_PER", "0"))           # layers per fused launch (0 = all)
+tail = os.environ.get("EMU_DECODE_TAIL") == "1"              # decode attention with the in-kernel split merge (one launch less per layer)
 
 
 class ShardView:                      # the engine plans its shard from (tp_rank, tp_size); RCCL sees the 1-rank context
@@ -35,6 +36,8 @@ l = LlamaCfg()
 V = 32274
 eng = LlamaEngine(l, V, ShardView(real, tp))
 eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device=dev, dtype=torch.bfloat16))
+if tail:
+    eng.set_decode_tail(True)
 S = 770
 x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
 mask = torch.ones(1, S, dtype=torch.long)
@@ -62,4 +65,4 @@ with torch.no_grad():
             first = first or ids
             print(f"tp={tp} shard on one GPU, {'p2p' if p2p else 'rccl'} all-reduce, {names[mode]}, {'hipGraph' if graph else 'eager'}: "
                   f"{ms:.3f} ms/token ({eng.weight_bytes_per_token() / 1e9:.2f} GB of weights per token per rank; ids "
-                  f"{'match' if ids == first else 'DIFFER'}; give-ups {eng.decode_fused_stats()[0]})", flush=True)
+                  f"{'match' if ids == first else 'DIFFER'}; give-ups {eng.decode_fused_stats()[0]}{'; decode tail merge' if tail else ''})", flush=True)
