@@ -931,7 +931,9 @@ def main():
                        "parallelism": f"tp{world}" + (" (ranks sharing one GPU: validation only)" if shared else ""), "allreduce": ("p2p one-shot (<=256 KiB) + rccl" if ctx.p2p else "rccl") if world > 1 else None,
                        "tp": ({"ms_per_token_by_rank": per_rank_ms, "allreduces_per_token": 2 * lcfg.num_hidden_layers,
                                "allreduce_bytes": 2 * lcfg.hidden_size, "weight_bytes_per_token_per_rank": lm.weight_bytes_per_token(),
-                               "note": "one process per GPU; o_proj / down_proj partial sums all-reduced in place on the launch stream"}
+                               "prefill_overlap_min_rows": lm.tp_overlap_rows, "prefill_overlap_forwards": lm.tp_overlap_count(),
+                               "note": "one process per GPU; decode: o_proj / down_proj partial sums all-reduced in place on the launch stream; prompts of "
+                                       ">= prefill_overlap_min_rows rows: two row halves, each half's all-reduce on a second stream behind the other half's GEMMs"}
                               if world > 1 else None),
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "valid": bool(a.layers == 60 and a.vit_layers == 64 and not shared and not a.gemm_tune)},

@@ -139,6 +139,8 @@ _PROTOS = {
     "emu_unet_temb_total": (i32, [vp]),
     "emu_llama_set_layer_range": (i32, [vp, i32, i32]),
     "emu_llama_set_prefill_fusion": (i32, [vp, i32]),
+    "emu_llama_set_tp_overlap": (i32, [vp, i32]),
+    "emu_llama_tp_overlap_count": (lng, [vp]),
     "emu_llama_set_decode_tail": (i32, [vp, i32]),
     "emu_llama_set_decode_fused": (i32, [vp, i32, i32]),
     "emu_llama_decode_fused_stats": (i32, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_long)]),

@@ -18,6 +18,10 @@ struct emu_ctx {
     ncclComm_t comm = nullptr;
     EmuP2p* p2p = nullptr;                          // one-shot all-reduce blocks (p2p.hip); used only once enabled
     bool p2p_on = false;
+    // tensor-parallel prefill in two concurrent lanes (emu_llama_set_tp_overlap): the second half of a prompt's rows runs on
+    // lane_stream beside the caller's stream; the events chain the two
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ar_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
 };
 
@@ -192,6 +196,8 @@ void emu_ctx_destroy(emu_ctx* ctx) {
     if (!ctx) return;
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     emu_p2p_destroy(ctx->p2p);
+    for (hipEvent_t e : ctx->ar_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     delete ctx;
 }
 
@@ -400,6 +406,9 @@ struct emu_llama {
     unsigned* dl_err = nullptr;                  // give-up counter
     long dl_forwards = 0;                        // fused forwards issued (tests: the path under test is the one that ran)
     unsigned long long* dl_trace = nullptr;      // emu_llama_set_decode_trace (tools; -DEMU_TRACE twin library only)
+    // tensor-parallel prefill in two row halves whose all-reduces run on the context's second stream (emu_llama_set_tp_overlap)
+    int tp_overlap_rows = 0;                     // 0: off; else the smallest prompt (rows) that takes the two-half schedule
+    long ov_forwards = 0;                        // forwards that took it (tests, tools)
 };
 constexpr int EMU_ARRIVE_INTS = 65536;
 
@@ -411,6 +420,8 @@ struct LlamaWs {
     float* dec;
     float* splitk;          // prefill only: K-slices of the GEMMs' tail round
     size_t splitk_floats;
+    bf16_t* vt2;            // two-lane tensor-parallel prefill (emu_llama_set_tp_overlap): the second lane's own V^T ...
+    float* splitk2;         // ... and K-slice scratch (the lanes' GEMMs run concurrently)
     size_t total;
 };
 LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
@@ -433,6 +444,9 @@ LlamaWs llama_ws(const emu_llama* m, int Bn, int T, void* base) {
     const size_t kmax = std::max<size_t>(std::max<size_t>(c.hidden, HD), c.ffn_local);
     w.x8 = (uint8_t*)take(M > 16 ? M * kmax : 0);
     w.xs = (float*)take(M > 16 ? M * sizeof(float) : 0);
+    const bool lanes = m->tp_overlap_rows > 0 && Bn == 1 && T >= m->tp_overlap_rows;
+    w.vt2 = (bf16_t*)take(lanes ? HD * spad * 2 : 0);
+    w.splitk2 = (float*)take(lanes ? w.splitk_floats * sizeof(float) : 0);
     w.total = off;
     return w;
 }
@@ -462,6 +476,123 @@ int linear_then_rmsnorm(const LlamaWs& w, const bf16_t* A, const bf16_t* W, cons
     int st = linear(A, W, nullptr, res, nullptr, C, M, N, K, K, K, N, N, 0.f, epi, s, nullptr, w.splitk, w.splitk_floats);
     if (st) return st;
     return launch_rmsnorm(C, gain, xn, M, N, N, N, eps, s);
+}
+
+// ---- Tensor-parallel prefill of a long prompt as TWO CONCURRENT LANES (SURVEY 8e / north_star: "all-reduce overlapped with the
+// next GEMM"; replaces the serial schedule of the loop in emu_llama_forward).  The prompt's rows are cut once, at a multiple of 256
+// (whole 256-row GEMM tiles and whole 64-key attention tiles below the cut), into A = [0, Ma) and B = [Ma, M).  Causal attention
+// makes A independent of B, and B needs nothing of A but its keys / values of the SAME layer, so each half walks all layers as its
+// own chain
+//     [RMSNorm, qkv (+ RoPE / KV append / V^T), attention, o_proj] -> all-reduce -> [RMSNorm, gate/up + SwiGLU, down] -> all-reduce
+// on its own stream: A on the caller's, B on cx->lane_stream, one event per layer (A's K / V rows are in the cache) the only edge
+// between them.  While one lane's partial sums are on the wire the other lane's GEMMs have the CUs, and where both lanes compute,
+// their launches (a TP = 8 shard's GEMM over 772 rows is 30-odd tiles on 256 CUs) share the chip instead of queueing behind each
+// other.  A first version kept ONE compute stream and interleaved the halves stage by stage with every all-reduce on a side
+// stream: +43 % per rank on one GPU (profiles/r05_tp_prefill_two_half_v1_single_compute_stream.log) -- half-size launches back to
+// back leave most of the chip idle, and every all-reduce cost two cross-stream edges.  All-reduces run in their lane's stream
+// where RCCL takes them (one communicator, calls in one host order on every rank); on a context without a communicator (rank
+// processes sharing a device: validation) every peer-to-peer all-reduce additionally waits for the one issued before it in
+// either lane, because the comm blocks serve one all-reduce at a time.  Lane B keeps its own V^T buffer (A's keys transposed from the cache + its own columns
+// from the epilogue) and K-slice scratch, so no buffer is written by one lane while the other reads it.  Same kernels and
+// rounding points as the serial schedule; a half may take another GEMM tile configuration than the whole prompt (K-slice sums in
+// another order), so the schedules agree to bf16 rounding, not bit for bit.  Capturable: lane_stream forks from and joins the
+// caller's stream through events.
+int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, const int32_t* pos, const int32_t* slot,
+                             const int32_t* kstart, bool fuse_rope, hipStream_t s) {
+    emu_ctx* cx = m->ctx;
+    const emu_llama_cfg& c = m->cfg;
+    const int H = c.hidden, Hl = c.heads_local, D = c.head_dim, HD = Hl * D, Fl = c.ffn_local;
+    const int epi_res = cx->tp_rank == 0 ? EPI_RESID : EPI_NONE;        // the residual enters the all-reduce once
+    const float scale = 1.0f / sqrtf((float)D);
+    const size_t kv_layer = (size_t)Hl * m->s_max * D;                  // one batch element
+    const int spad = (M + 63) / 64 * 64;
+    const int l_end = m->l1 < 0 ? c.layers : m->l1;
+    if (l_end <= m->l0) return 0;
+    int Ma = (M / 2 + 128) / 256 * 256;
+    if (Ma < 256) Ma = 256;
+    if (Ma > M - 256) Ma = (M - 256) / 256 * 256;
+    const int r0[2] = {0, Ma}, rows[2] = {Ma, M - Ma};
+    hipStream_t lane[2] = {s, cx->lane_stream};
+    bf16_t* vt[2] = {w.vt, w.vt2};
+    float* sk[2] = {w.splitk, w.splitk2};
+    hipEvent_t eStart = cx->ar_ev[0], eKV = cx->ar_ev[1], eDone = cx->ar_ev[2];
+    hipEvent_t* ePrev = cx->ar_ev + 3;   // [lane]  the lane's latest peer-to-peer all-reduce is through (an event is only ever recorded on
+    int prev_lane = -1;                  //         ONE stream: one event recorded on both streams of a capture crashed hipGraphInstantiate)
+#define HIPTRY(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return fail(cx, -5, #expr); } } while (0)
+    auto lane_allreduce = [&](int h, bf16_t* buf, size_t n) -> int {
+        const bool by_rccl = cx->comm && !(cx->p2p_on && n * sizeof(bf16_t) <= EMU_P2P_SLOT_BYTES);   // emu_allreduce_bf16's own choice
+        if (by_rccl) return emu_allreduce_bf16(cx, buf, n, reinterpret_cast<emu_stream_t>(lane[h]));
+        // the comm blocks serve ONE all-reduce at a time: every peer-to-peer all-reduce waits for the one issued before it (host order,
+        // the same on every rank), whichever lane that was in
+        if (prev_lane >= 0 && prev_lane != h) HIPTRY(hipStreamWaitEvent(lane[h], ePrev[prev_lane], 0));
+        TRY(cx, emu_allreduce_bf16(cx, buf, n, reinterpret_cast<emu_stream_t>(lane[h])));
+        HIPTRY(hipEventRecord(ePrev[h], lane[h]));
+        prev_lane = h;
+        return 0;
+    };
+    HIPTRY(hipEventRecord(eStart, s));                                   // inputs (and whatever the caller queued before) are ready
+    HIPTRY(hipStreamWaitEvent(lane[1], eStart, 0));
+    for (int l = m->l0; l < l_end; ++l) {
+        const emu_llama::Layer& L = m->layers[l];
+        if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
+        bf16_t* kc = m->kcache + l * kv_layer;
+        bf16_t* vc = m->vcache + l * kv_layer;
+        for (int h = 0; h < 2; ++h) {                                    // host order A(l), B(l), A(l + 1), ...: B(l)'s wait sees A(l)'s record
+            hipStream_t ls = lane[h];
+            const int Mh = rows[h], kend = r0[h] + Mh;
+            bf16_t* x = hA + (size_t)r0[h] * H;
+            bf16_t* xn = w.xn + (size_t)r0[h] * H;
+            bf16_t* qkv = w.qkv + (size_t)r0[h] * 3 * HD;
+            bf16_t* att = w.attn + (size_t)r0[h] * HD;
+            bf16_t* act = w.act + (size_t)r0[h] * Fl;
+            bf16_t* hB = w.hB + (size_t)r0[h] * H;
+            // ---- attention
+            TRY(cx, launch_rmsnorm(x, L.ln1, xn, Mh, H, H, H, c.rms_eps, ls));
+            int st = -95;
+            if (fuse_rope) {
+                if (h == 1) {
+                    // lane B's V^T: A's keys of this layer out of the cache (zero behind them), its own columns from the epilogue below
+                    HIPTRY(hipStreamWaitEvent(ls, eKV, 0));
+                    TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, vt[1], 1, Hl, Ma, D, spad};
+                    TRY(cx, launch_transpose_v(tv, ls));
+                }
+                GemmArgs g{xn, L.wqkv, nullptr, nullptr, qkv, Mh, 3 * HD, H, H, H, 0, 3 * HD, EPI_NONE, ConvGeom{0, 0, 0, 0, 0, 0}, nullptr, 0, 0};
+                g.partial = sk[h]; g.partial_floats = w.splitk_floats;
+                g.rope_cos = m->cos; g.rope_sin = m->sin; g.rope_pos = pos + r0[h]; g.rope_slot = slot + r0[h]; g.rope_kc = kc; g.rope_vc = vc;
+                g.rope_hl = Hl; g.rope_smax = m->s_max;
+                g.vt_out = vt[h] + r0[h]; g.vt_col0 = 2 * HD; g.vt_s = Mh; g.vt_spad = spad;   // key index = row index: column r0 + m
+                st = launch_gemm(g, ls);
+                if (st != 0 && st != -95) return fail(cx, st, "emu_llama_forward: qkv projection with the RoPE epilogue");
+                if (st == -95) fuse_rope = false;                        // (before anything of this call was launched fused: lane A, first layer)
+            }
+            if (st == -95) {
+                TRY(cx, linear(xn, L.wqkv, nullptr, nullptr, nullptr, qkv, Mh, 3 * HD, H, H, H, 0, 3 * HD, 0.f, EPI_NONE, ls, nullptr, sk[h], w.splitk_floats));
+                RopeKvArgs r{qkv, m->cos, m->sin, pos + r0[h], slot + r0[h], kc, vc, 1, Mh, Hl, D, m->s_max};
+                TRY(cx, launch_rope_kv(r, ls));
+                if (h == 1) HIPTRY(hipStreamWaitEvent(ls, eKV, 0));
+                TransposeVArgs tv{vc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D, vt[h], 1, Hl, kend, D, spad};
+                TRY(cx, launch_transpose_v(tv, ls));                     // keys [0, kend) key-contiguous, zero up to spad
+            }
+            if (h == 0) HIPTRY(hipEventRecord(eKV, ls));                 // K / V rows [0, Ma) of layer l are in the cache
+            FlashArgs f{qkv, (long)Mh * 3 * HD, (long)D, (long)3 * HD,
+                        kc, (long)Hl * m->s_max * D, (long)m->s_max * D, (long)D,
+                        vt[h], att, (long)Mh * HD, (long)D, (long)HD, kstart,
+                        1, Hl, Mh, kend, spad, D, 1, scale};                 // query i of the half sees keys <= r0 + i
+            TRY(cx, launch_flash_attn(f, ls));
+            TRY(cx, linear(att, L.wo, nullptr, x, nullptr, hB, Mh, H, HD, HD, HD, H, H, 0.f, epi_res, ls, nullptr, sk[h], w.splitk_floats));
+            TRY(cx, lane_allreduce(h, hB, (size_t)Mh * H));
+            // ---- SwiGLU MLP
+            TRY(cx, launch_rmsnorm(hB, L.ln2, xn, Mh, H, H, H, c.rms_eps, ls));
+            TRY(cx, linear(xn, L.wgu, nullptr, nullptr, nullptr, act, Mh, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, ls, nullptr, sk[h], w.splitk_floats));
+            TRY(cx, linear(act, L.wdown, nullptr, hB, nullptr, x, Mh, H, Fl, Fl, Fl, H, H, 0.f, epi_res, ls, nullptr, sk[h], w.splitk_floats));
+            TRY(cx, lane_allreduce(h, x, (size_t)Mh * H));
+        }
+    }
+    HIPTRY(hipEventRecord(eDone, lane[1]));                              // join: the caller's stream owns the residual stream again
+    HIPTRY(hipStreamWaitEvent(s, eDone, 0));
+#undef HIPTRY
+    ++m->ov_forwards;
+    return 0;
 }
 }  // namespace
 
@@ -557,6 +688,25 @@ int emu_llama_set_prefill_fusion(emu_llama* m, int enable) {
     m->prefill_fusion = enable != 0;
     return 0;
 }
+int emu_llama_set_tp_overlap(emu_llama* m, int min_rows) {
+    if (!m || min_rows < 0) return -22;
+    emu_ctx* cx = m->ctx;
+    if (min_rows > 0 && !cx->lane_stream) {                              // created here, never inside a forward (stream capture)
+        if (hipSetDevice(cx->device) != hipSuccess) return fail(cx, -19, "emu_llama_set_tp_overlap: hipSetDevice");
+        if (hipStreamCreateWithFlags(&cx->lane_stream, hipStreamNonBlocking) != hipSuccess) {
+            cx->lane_stream = nullptr;
+            return fail(cx, -12, "emu_llama_set_tp_overlap: hipStreamCreateWithFlags");
+        }
+        for (hipEvent_t& e : cx->ar_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                e = nullptr;
+                return fail(cx, -12, "emu_llama_set_tp_overlap: hipEventCreateWithFlags");
+            }
+    }
+    m->tp_overlap_rows = min_rows > 0 && min_rows < 512 ? 512 : min_rows;   // two halves of at least one 256-row tile each
+    return 0;
+}
+long emu_llama_tp_overlap_count(const emu_llama* m) { return m ? m->ov_forwards : -1; }
 int emu_llama_use_fp8(emu_llama* m, int enable) {
     if (!m) return -22;
     if (enable && m->layers8.size() != (size_t)m->cfg.layers)
@@ -716,6 +866,11 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             return 0;
         }
     }
+    // ---- long prompt under tensor parallelism: two row halves, every all-reduce behind the other half's GEMMs (needs the slot-order
+    // promise: the rows of the one batch element are the whole context in order, so the first half never reads the second's keys)
+    if (tp && m->tp_overlap_rows > 0 && cx->lane_stream && cx->ar_ev[4] && w.vt2 && promise && Bn == 1 && T == ctx && M >= m->tp_overlap_rows &&
+        !m->fp8_prefill && m->kv_share_nb <= 1)
+        return llama_prefill_overlapped(m, w, hA, M, pos, slot, kstart, fuse_rope, s);
     for (int l = m->l0; l < l_end; ++l) {
         const emu_llama::Layer& L = m->layers[l];
         if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");

@@ -164,6 +164,11 @@ class LlamaEngine:
         mode = int(os.environ.get("EMU_DECODE_FUSED", "0"))
         if mode:
             self.set_decode_fused(mode)
+        # tensor parallelism: prompts of >= 1024 rows run as two row halves whose all-reduces travel on a second stream behind the
+        # other half's GEMMs (emu_llama_set_tp_overlap); EMU_TP_OVERLAP=0 keeps the serial schedule, =N sets the threshold
+        self.tp_overlap_rows = 0
+        if ctx.tp_size > 1:
+            self.set_tp_overlap(int(os.environ.get("EMU_TP_OVERLAP", "1024")))
 
     def _mode_changed(self) -> None:
         self.mode_epoch += 1
@@ -197,6 +202,18 @@ class LlamaEngine:
         g, _ = self.decode_fused_stats()
         if g:
             raise EmuHipError(f"fused decode layers: {g} in-kernel wait(s) ran into the time limit; the step's outputs are invalid")
+
+    def set_tp_overlap(self, min_rows: int) -> None:
+        """Tensor-parallel prefill of prompts with at least ``min_rows`` rows (B = 1; clamped up to 512) in two row halves: the
+        all-reduce of one half's o_proj / down_proj partial sums runs on the context's second stream while this stream computes the
+        other half's stage (include/emu_hip.h: emu_llama_set_tp_overlap).  0 = every all-reduce serially between the GEMMs.  Results
+        agree with the serial schedule to bf16 rounding (a half may take another GEMM tile configuration)."""
+        check(lib().emu_llama_set_tp_overlap(self.handle, int(min_rows)), "emu_llama_set_tp_overlap", self.ctx.handle)
+        self.tp_overlap_rows = 0 if min_rows <= 0 else max(512, int(min_rows))
+
+    def tp_overlap_count(self) -> int:
+        """Forwards that took the two-half schedule."""
+        return int(lib().emu_llama_tp_overlap_count(self.handle))
 
     def set_prefill_fusion(self, enable: bool) -> None:
         """Whether ``prefill`` promises the library slot-ordered rows (the fused RoPE / KV-append / V^T / norm epilogues).  The

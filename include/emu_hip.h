@@ -269,6 +269,27 @@ int emu_llama_set_layer_range(emu_llama* m, int l0, int l1);
  * three launches it replaces: bit-identical hidden states and caches); every other call runs the unfused sequence. */
 int emu_llama_set_prefill_fusion(emu_llama* m, int enable);
 
+/* Tensor-parallel prefill with the all-reduces overlapped (the reference has no tensor parallelism: its multi-GPU scheme
+ * is layer placement, Emu2/emu/mixin.py:44-81, Emu2/emu/chat.py:250-283).  min_rows > 0: a B = 1, T == ctx forward under the
+ * slot-order promise (emu_llama_set_prefill_fusion) with at least min_rows rows (clamped up to 512) on a context with tp_size > 1
+ * (or a 1-rank communicator / comm block) cuts the prompt's rows once, at a multiple of 256, into two halves that run as two
+ * CONCURRENT LANES: causal attention makes the first half independent of the second, and the second needs only the first's keys /
+ * values of the same layer, so each half walks all layers as its own chain (norm, qkv, attention, o_proj, all-reduce, norm, gate/up,
+ * down, all-reduce) on its own stream -- the first on the caller's, the second on a stream owned by the context -- with one event
+ * per layer (the first half's K / V rows are in the cache) the only edge between them.  While one lane's partial sums are on the
+ * wire, the other lane's GEMMs have the CUs.  The caller's stream has joined the second one when the call returns (the whole
+ * forward is capturable into one hipGraph).  All-reduces run inside their lane's stream where RCCL takes them; without a
+ * communicator (rank processes sharing a device) every peer-to-peer all-reduce additionally waits for the one issued before it.
+ * Same kernels and rounding points as the serial schedule; results agree to bf16 rounding, not bit for bit (a half-size launch may
+ * take another tile configuration than the whole prompt's).  Cost on ONE GPU with a no-op all-reduce (what the cut itself costs):
+ * +17 % (TP = 8 shard) ... +21 % (TP = 2) per prefill under graph replay; what it hides -- 2 x layers all-reduces of [S, hidden] --
+ * needs a multi-GPU node to be measured.  min_rows = 0 keeps every all-reduce on the caller's stream between the GEMMs.  The first
+ * call with min_rows > 0 creates the stream and events (never inside a forward); the workspace grows by the second lane's V^T and
+ * K-slice scratch (emu_llama_workspace_bytes follows the setting). */
+int emu_llama_set_tp_overlap(emu_llama* m, int min_rows);
+/* forwards that took the two-half schedule since the engine was created (tests, tools) */
+long emu_llama_tp_overlap_count(const emu_llama* m);
+
 /* Decode attention in ONE launch (OFF by default): the last split workgroup of a head to arrive merges the head's splits itself
  * (agent-scope stores / loads of the split states and a relaxed arrival counter: no fence, no spinning) instead of a second,
  * combine launch; same arithmetic, bit-identical outputs.  Measured 0.4 % slower than the two launches on MI355X (three

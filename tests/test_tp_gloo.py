@@ -62,6 +62,63 @@ def test_tp2_gloo_layer_matches_unsharded():
     assert all(err < 1e-4 for _, err in res), res
 
 
+def _lane_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_amd import synth
+        from emu_amd.conf.emu_conf import LlamaCfg
+        from emu_amd.tp import ShardPlan
+        from oracle import emu2_ref as R
+        from tests.tp_ref import sharded_two_lane_prefill
+        heads, D, S, Ma, L = 5, 16, 23, 8, 2                    # 5 heads over 2 ranks -> padded to 6; lanes of 8 and 15 rows
+        l = LlamaCfg(hidden_size=heads * D, intermediate_size=128, num_attention_heads=heads, num_hidden_layers=L)
+        W = synth.synth_state_dict(synth.llama_param_shapes(l, 64), seed=12)
+        cfg = R.LlamaCfg(hidden=l.hidden_size, heads=heads, layers=L, ffn=128, vocab=64)
+        x = torch.randn(1, S, l.hidden_size, generator=torch.Generator().manual_seed(6))
+        pos = torch.arange(S)[None]
+        cos, sin = R.rope_cos_sin(pos, D, 10000.0, torch.float32)
+        plan = ShardPlan(l.hidden_size, heads, D, 128, world, rank)
+        layers = []
+        for i in range(L):
+            pre = f"decoder.lm.model.layers.{i}."
+            packed = plan.pack_layer(*(W[pre + k] for k in ("self_attn.q_proj.weight", "self_attn.k_proj.weight",
+                                                             "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                                                             "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")))
+            layers.append((packed, W[pre + "input_layernorm.weight"], W[pre + "post_attention_layernorm.weight"]))
+        n_ar = [0]
+
+        def allreduce(t):
+            t = t.clone()
+            dist.all_reduce(t)
+            n_ar[0] += 1
+            return t
+        out = sharded_two_lane_prefill(x, layers, plan, cfg, cos, sin, allreduce, Ma)
+        mask = R.build_mask(torch.ones(1, S, dtype=torch.long), S, torch.float32)
+        want = x
+        for i in range(L):
+            want = R.llama_layer(want, W, i, cfg, cos, sin, mask, None)
+        q.put((rank, float((out - want).abs().max()), n_ar[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_gloo_two_lane_prefill_matches_unsharded():
+    """The two-lane prefill schedule (emu_llama_set_tp_overlap) as two real processes over gloo: the prompt's rows cut in two chains,
+    lane B reading lane A's keys / values of the same layer, four all-reduces per layer in the engine's host order (A's two, then
+    B's two) -- reproduces the unsharded oracle stack on all rows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lane_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in procs]
+    [p.join(60) for p in procs]
+    assert sorted(r for r, _, _ in res) == [0, 1]
+    assert all(err < 1e-4 for _, err, _ in res), res
+    assert all(n == 8 for _, _, n in res), res                  # 2 layers x 2 lanes x 2 all-reduces
+
+
 def _img_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

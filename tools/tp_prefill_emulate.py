@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Per-rank PREFILL cost of a TP shard on ONE GPU, serial schedule against the two-half schedule (emu_llama_set_tp_overlap):
+rank 0's 1/tp slice of LLaMA-33B over an S-row prompt with a 1-rank communicator in the loop.  The all-reduce launches are real
+(RCCL: a 1-rank all-reduce is a no-op copy; "p2p": the one-shot kernels in slot-sized chunks), their cross-GPU time is not -- so
+this measures what cutting the prompt into two row halves COSTS in GEMM / attention efficiency (smaller launches, the second
+stream's event edges), which is the price paid for hiding 120 x [S/2, 6656] all-reduces per half on a real node; what it hides
+cannot be measured on one GPU.  Usage: python tools/tp_prefill_emulate.py [tp] [S] [reps] [rccl|p2p]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emu_amd import synth
+from emu_amd.conf.emu_conf import LlamaCfg
+from emu_amd.llama import EmuHipContext, LlamaEngine
+
+tp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1544
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+p2p = len(sys.argv) > 4 and sys.argv[4] == "p2p"
+dev = torch.device("cuda", 0)
+real = EmuHipContext(dev, 0, 1)
+if p2p:
+    real.init_tp(lambda b: b, force=True, allgather_bytes=lambda b: [b], rccl=False)
+else:
+    real.init_tp(lambda b: b, force=True)
+
+
+class ShardView:                      # the engine plans its shard from (tp_rank, tp_size); the communicator is the 1-rank context's
+    def __init__(self, ctx, size):
+        self.__dict__.update(ctx=ctx, tp_rank=0, tp_size=size)
+
+    def __getattr__(self, k):
+        return getattr(self.ctx, k)
+
+
+l = LlamaCfg()
+V = 32274
+eng = LlamaEngine(l, V, ShardView(real, tp))
+eng.load_weights(synth.iter_synth(synth.llama_param_shapes(l, V), seed=0, device=dev, dtype=torch.bfloat16))
+x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
+mask = torch.ones(1, S, dtype=torch.long, device=dev)
+H, F, Hl = l.hidden_size, l.intermediate_size // tp, eng.plan.heads_local
+flops = l.num_hidden_layers * (2.0 * S * H * (3 * Hl * 128 + Hl * 128 + 3 * F) + 2.0 * 2 * Hl * S * S * 128 / 2)
+ar_bytes = 2 * l.num_hidden_layers * S * H * 2
+res = {}
+with torch.no_grad():
+    cap = eng.kv_capacity(S + 64)
+    for name, rows in (("serial", 0), ("two-half", 1024), ("serial", 0), ("two-half", 1024)):
+        eng.set_tp_overlap(rows)
+        for graph in (False, True):
+            n0 = eng.tp_overlap_count()
+            run = lambda: eng.prefill(x, mask, cap)
+            run(); torch.cuda.synchronize()
+            if graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = eng.prefill(x, mask, cap)
+                run = g.replay
+            ts = []
+            for _ in range(reps + 1):
+                torch.cuda.synchronize(); t = time.perf_counter()
+                run()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t) * 1e3)
+            ms = min(ts[1:])
+            res.setdefault((name, graph), []).append(ms)
+            print(f"tp={tp} shard on one GPU, S={S}, {'p2p' if p2p else 'rccl'} 1-rank all-reduce, {name} schedule, {'hipGraph' if graph else 'eager'}: "
+                  f"{ms:.2f} ms per prefill per rank = {flops / ms / 1e9:.0f} TFLOP/s ({2 * l.num_hidden_layers * (2 if rows else 1)} all-reduces of "
+                  f"{ar_bytes / (2 * l.num_hidden_layers) / (2 if rows else 1) / 1e6:.1f} MB; forwards on the two-half schedule: {eng.tp_overlap_count() - n0})", flush=True)
+for graph in (False, True):
+    a, b = min(res[("serial", graph)]), min(res[("two-half", graph)])
+    print(f"summary ({'hipGraph' if graph else 'eager'}): serial {a:.2f} ms, two-half {b:.2f} ms ({(b / a - 1) * 100:+.1f} %); all-reduce bytes per prefill per rank "
+          f"{ar_bytes / 1e9:.2f} GB", flush=True)
