@@ -1,10 +1,10 @@
 #!/usr/bin/env python
-"""Per-rank PREFILL cost of a TP shard on ONE GPU, serial schedule against the two-half schedule (emu_llama_set_tp_overlap):
+"""Per-rank PREFILL cost of a TP shard on ONE GPU, serial schedule against the two-lane schedule (emu_llama_set_tp_overlap):
 rank 0's 1/tp slice of LLaMA-33B over an S-row prompt with a 1-rank communicator in the loop.  The all-reduce launches are real
 (RCCL: a 1-rank all-reduce is a no-op copy; "p2p": the one-shot kernels in slot-sized chunks), their cross-GPU time is not -- so
 this measures what cutting the prompt into two row halves COSTS in GEMM / attention efficiency (smaller launches, the second
 stream's event edges), which is the price paid for hiding 120 x [S/2, 6656] all-reduces per half on a real node; what it hides
-cannot be measured on one GPU.  Usage: python tools/tp_prefill_emulate.py [tp] [S] [reps] [rccl|p2p]"""
+cannot be measured on one GPU.  Usage: python tools/tp_prefill_emulate.py [tp] [S] [reps] [rccl|p2p] [min_rows = 1024]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,7 @@ tp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1544
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 p2p = len(sys.argv) > 4 and sys.argv[4] == "p2p"
+min_rows = int(sys.argv[5]) if len(sys.argv) > 5 else 1024
 dev = torch.device("cuda", 0)
 real = EmuHipContext(dev, 0, 1)
 if p2p:
@@ -44,7 +45,7 @@ ar_bytes = 2 * l.num_hidden_layers * S * H * 2
 res = {}
 with torch.no_grad():
     cap = eng.kv_capacity(S + 64)
-    for name, rows in (("serial", 0), ("two-half", 1024), ("serial", 0), ("two-half", 1024)):
+    for name, rows in (("serial", 0), ("two-lane", min_rows), ("serial", 0), ("two-lane", min_rows)):
         eng.set_tp_overlap(rows)
         for graph in (False, True):
             n0 = eng.tp_overlap_count()
@@ -65,8 +66,8 @@ with torch.no_grad():
             res.setdefault((name, graph), []).append(ms)
             print(f"tp={tp} shard on one GPU, S={S}, {'p2p' if p2p else 'rccl'} 1-rank all-reduce, {name} schedule, {'hipGraph' if graph else 'eager'}: "
                   f"{ms:.2f} ms per prefill per rank = {flops / ms / 1e9:.0f} TFLOP/s ({2 * l.num_hidden_layers * (2 if rows else 1)} all-reduces of "
-                  f"{ar_bytes / (2 * l.num_hidden_layers) / (2 if rows else 1) / 1e6:.1f} MB; forwards on the two-half schedule: {eng.tp_overlap_count() - n0})", flush=True)
+                  f"{ar_bytes / (2 * l.num_hidden_layers) / (2 if rows else 1) / 1e6:.1f} MB; forwards on the two-lane schedule: {eng.tp_overlap_count() - n0})", flush=True)
 for graph in (False, True):
-    a, b = min(res[("serial", graph)]), min(res[("two-half", graph)])
-    print(f"summary ({'hipGraph' if graph else 'eager'}): serial {a:.2f} ms, two-half {b:.2f} ms ({(b / a - 1) * 100:+.1f} %); all-reduce bytes per prefill per rank "
+    a, b = min(res[("serial", graph)]), min(res[("two-lane", graph)])
+    print(f"summary ({'hipGraph' if graph else 'eager'}): serial {a:.2f} ms, two-lane {b:.2f} ms ({(b / a - 1) * 100:+.1f} %); all-reduce bytes per prefill per rank "
           f"{ar_bytes / 1e9:.2f} GB", flush=True)
