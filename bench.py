@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--no-beam", action="store_true", help="skip the extra 5-beam leg (the reference's default decoding mode)")
     p.add_argument("--no-fp8", action="store_true", help="skip the extra fp8-weight decode leg (never the headline value)")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--tp-prefill-leg", type=int, default=0, metavar="S", help="N > 1 only, opt-in: after everything else, time an S-row prefill "
+                   "(e.g. 1544 = BASELINE configs[2]) under the serial all-reduce schedule and as two concurrent lanes (emu_llama_set_tp_overlap); "
+                   "reported in config.tp.prefill_schedules.  Off by default: the two-lane schedule has never run on more than one GPU")
     p.add_argument("--no-legs", action="store_true", help="skip the extra BASELINE-config legs (S=1544 prefill, generate_image, "
                                                           "VAE decode, any-to-image)")
     p.add_argument("--pmc-prefill", type=int, default=0, metavar="N", help="profiling aid for rocprofv3 --pmc passes: load the decoder only, "
@@ -888,6 +891,35 @@ def main():
         except Exception as e:                                  # never lose the headline to an extra leg
             legs = {"note": f"legs failed: {type(e).__name__}: {e}"}
 
+    tp_prefill = None
+    if world > 1 and a.tp_prefill_leg >= 1024:
+        # opt-in (see --tp-prefill-leg): the same S-row prompt under both prefill schedules, every rank's clock, MAX over ranks
+        try:
+            Sx = a.tp_prefill_leg
+            xx = (torch.randn(1, Sx, lcfg.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
+            mm = torch.ones(1, Sx, dtype=torch.long, device=dev)
+            keep = lm.tp_overlap_rows
+            tp_prefill = {"S": Sx, "allreduce_bytes_per_prefill_per_rank": 2 * lcfg.num_hidden_layers * Sx * lcfg.hidden_size * 2}
+            with torch.no_grad():
+                capx = lm.kv_capacity(Sx + 8)
+                for name, rows in (("serial", 0), ("two_lane", 1024)):
+                    lm.set_tp_overlap(rows)
+                    n0 = lm.tp_overlap_count()
+                    lm.prefill(xx, mm, capx)
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        lm.prefill(xx, mm, capx)
+                    sync()
+                    tt = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=rdev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    tp_prefill[name + "_ms"] = float(tt.item())
+                    tp_prefill[name + "_forwards_on_two_lanes"] = lm.tp_overlap_count() - n0
+            lm.set_tp_overlap(keep)
+            ctx.check_p2p()
+        except Exception as e:                                  # never lose the headline to an extra leg
+            tp_prefill = {"note": f"leg failed: {type(e).__name__}: {e}"}
+
     # HBM traffic of the GEMV launches comes from PMC counters (FETCH_SIZE), which a timing run cannot collect itself:
     # the committed pass over THIS command (profiles/r03_gemv_pmc_traffic.json, gfx950-corrected) gives traffic /
     # algorithmic bytes for the same kernels; traffic = that ratio x this run's algorithmic bytes per launch
@@ -931,7 +963,7 @@ def main():
                        "parallelism": f"tp{world}" + (" (ranks sharing one GPU: validation only)" if shared else ""), "allreduce": ("p2p one-shot (<=256 KiB) + rccl" if ctx.p2p else "rccl") if world > 1 else None,
                        "tp": ({"ms_per_token_by_rank": per_rank_ms, "allreduces_per_token": 2 * lcfg.num_hidden_layers,
                                "allreduce_bytes": 2 * lcfg.hidden_size, "weight_bytes_per_token_per_rank": lm.weight_bytes_per_token(),
-                               "prefill_overlap_min_rows": lm.tp_overlap_rows, "prefill_overlap_forwards": lm.tp_overlap_count(),
+                               "prefill_overlap_min_rows": lm.tp_overlap_rows, "prefill_overlap_forwards": lm.tp_overlap_count(), "prefill_schedules": tp_prefill,
                                "note": "one process per GPU; decode: o_proj / down_proj partial sums all-reduced in place on the launch stream; prompts of "
                                        ">= prefill_overlap_min_rows rows: two row halves, each half's all-reduce on a second stream behind the other half's GEMMs"}
                               if world > 1 else None),

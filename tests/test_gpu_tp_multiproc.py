@@ -60,14 +60,16 @@ def test_engine_tp8_true_width_shards():
 def test_bench_two_ranks_sharing_one_gpu():
     """`bench.py --gpus 2` end to end (what the driver launches on a multi-GPU node), at reduced depth, with both ranks on this one
     device (EMU_TP_SHARED_GPU=1: gloo rendezvous, every all-reduce through the peer-to-peer kernels): one JSON line from rank 0
-    carrying the contract's fields, the TP parallelism label, the all-reduce path, and a run marked invalid (reduced depth)."""
+    carrying the contract's fields, the TP parallelism label, the all-reduce path, a run marked invalid (reduced depth), and the opt-in
+    prefill-schedule leg (serial vs two concurrent lanes)."""
     import json
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", EMU_TP_SHARED_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--layers", "2", "--vit-layers", "2", "--no-legs", "--no-denoise", "--no-fp8", "--no-beam", "--no-cpu-baseline"]
+           "--layers", "2", "--vit-layers", "2", "--no-legs", "--no-denoise", "--no-fp8", "--no-beam", "--no-cpu-baseline",
+           "--tp-prefill-leg", "1100"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -76,6 +78,10 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["parallelism"].startswith("tp2") and "p2p" in d["config"]["allreduce"] and d["config"]["valid"] is False
     assert {"roofline", "metric", "unit", "ms_per_step", "higher_is_better", "dtype", "data"} <= set(d)
+    # the opt-in prefill-schedule leg: an 1100-row prompt under the serial all-reduce schedule and as two concurrent lanes
+    ps = d["config"]["tp"]["prefill_schedules"]
+    assert ps["S"] == 1100 and ps["serial_ms"] > 0 and ps["two_lane_ms"] > 0, ps
+    assert ps["serial_forwards_on_two_lanes"] == 0 and ps["two_lane_forwards_on_two_lanes"] == 4, ps
 
 
 def test_p2p_setup_failure_is_refused_not_hung():
