@@ -537,7 +537,13 @@ int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, 
         if (!L.wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
         bf16_t* kc = m->kcache + l * kv_layer;
         bf16_t* vc = m->vcache + l * kv_layer;
-        for (int h = 0; h < 2; ++h) {                                    // host order A(l), B(l), A(l + 1), ...: B(l)'s wait sees A(l)'s record
+        // Host order per layer: A.attention, B.attention, A.mlp, B.mlp -- so B's wait for eKV sees A's record of this layer, and the
+        // all-reduces are issued in the order o_A, o_B, down_A, down_B.  The order matters beyond bookkeeping: all-reduces of one
+        // communicator run in issue order (RCCL makes a call on another stream wait for the stream of the call before it; the
+        // peer-to-peer chain below does the same), so an all-reduce can only wait for work issued ahead of it.  Issued lane by lane
+        // (A's whole layer, then B's), B's first all-reduce would wait for A's second and the lanes would take turns instead of overlapping.
+        for (int stage = 0; stage < 2; ++stage)
+        for (int h = 0; h < 2; ++h) {
             hipStream_t ls = lane[h];
             const int Mh = rows[h], kend = r0[h] + Mh;
             bf16_t* x = hA + (size_t)r0[h] * H;
@@ -546,6 +552,13 @@ int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, 
             bf16_t* att = w.attn + (size_t)r0[h] * HD;
             bf16_t* act = w.act + (size_t)r0[h] * Fl;
             bf16_t* hB = w.hB + (size_t)r0[h] * H;
+            if (stage == 1) {                                            // ---- SwiGLU MLP
+                TRY(cx, launch_rmsnorm(hB, L.ln2, xn, Mh, H, H, H, c.rms_eps, ls));
+                TRY(cx, linear(xn, L.wgu, nullptr, nullptr, nullptr, act, Mh, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, ls, nullptr, sk[h], w.splitk_floats));
+                TRY(cx, linear(act, L.wdown, nullptr, hB, nullptr, x, Mh, H, Fl, Fl, Fl, H, H, 0.f, epi_res, ls, nullptr, sk[h], w.splitk_floats));
+                TRY(cx, lane_allreduce(h, x, (size_t)Mh * H));
+                continue;
+            }
             // ---- attention
             TRY(cx, launch_rmsnorm(x, L.ln1, xn, Mh, H, H, H, c.rms_eps, ls));
             int st = -95;
@@ -581,11 +594,6 @@ int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, 
             TRY(cx, launch_flash_attn(f, ls));
             TRY(cx, linear(att, L.wo, nullptr, x, nullptr, hB, Mh, H, HD, HD, HD, H, H, 0.f, epi_res, ls, nullptr, sk[h], w.splitk_floats));
             TRY(cx, lane_allreduce(h, hB, (size_t)Mh * H));
-            // ---- SwiGLU MLP
-            TRY(cx, launch_rmsnorm(hB, L.ln2, xn, Mh, H, H, H, c.rms_eps, ls));
-            TRY(cx, linear(xn, L.wgu, nullptr, nullptr, nullptr, act, Mh, 2 * Fl, H, H, H, 0, Fl, 0.f, EPI_SWIGLU, ls, nullptr, sk[h], w.splitk_floats));
-            TRY(cx, linear(act, L.wdown, nullptr, hB, nullptr, x, Mh, H, Fl, Fl, Fl, H, H, 0.f, epi_res, ls, nullptr, sk[h], w.splitk_floats));
-            TRY(cx, lane_allreduce(h, x, (size_t)Mh * H));
         }
     }
     HIPTRY(hipEventRecord(eDone, lane[1]));                              // join: the caller's stream owns the residual stream again
