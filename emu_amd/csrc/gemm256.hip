@@ -103,6 +103,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     int wg, ks = 0, nsl = 1;
     if (b < a.full_tiles) {
         wg = xcd_order(b, a.full_tiles);
+        if (a.sup_m) {
+            // 2-D blocks (launch_pp, unsliced plain GEMMs with many row tiles): an XCD's run of the logical order is one sup_m x sup_n
+            // block of tiles walked row-first, so the 32 workgroups it runs at a time share sup_m row tiles of A and a few weight
+            // tiles instead of one weight tile and 32 different row tiles (8192^3: 4.2 GB fetched for 0.27 GB of operands)
+            const int per = a.sup_m * a.sup_n, blk = wg / per, r = wg - blk * per;
+            const int bm = tiles_m / a.sup_m, bi = blk % bm, bj = blk / bm;
+            wg = (bj * a.sup_n + r / a.sup_m) * tiles_m + bi * a.sup_m + r % a.sup_m;
+        }
     } else {
         nsl = a.ksplit;
         const int rest = tiles_m * ((a.N + 255) >> 8) - a.full_tiles;
@@ -762,6 +770,20 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.trace = emu_gemm_trace_get();
     b.stage = stage_ok(b) && !(emu_gemm_tune_get() & 8);
     b.stage_vt = b.stage && stage_vt_ok(b, 256, 256) && !(emu_gemm_tune_get() & (1 << 14));
+    // XCD-aware 2-D tile blocks (gemm.hip::launch_cfg has the rule): unsliced plain GEMMs whose tile count splits evenly over the 8
+    // XCDs; the implicit-GEMM convs keep the column-major strips (one weight tile of K = 9 Cin per strip is what their L2 can hold)
+    b.sup_m = b.sup_n = 0;
+    if (!CONV && b.full_tiles == tiles && tiles % 8 == 0 && !(emu_gemm_tune_get() & (1 << 17)) && (tiles > 256 || !(emu_gemm_tune_get() & (1 << 18)))) {
+        int ext_rows;
+        const int tm = pp_tiles_m(a.M, true, ext_rows), tn = tiles / tm, per = tiles / 8;
+        const int cur_cols = (per + tm - 1) / tm + ((per % tm) ? 1 : 0);
+        long best = (long)(per < tm ? per : tm) + (long)(cur_cols < tn ? cur_cols : tn);
+        for (int sm = 1; sm <= tm; ++sm) {
+            if (tm % sm || per % sm || tn % (per / sm)) continue;
+            const long cost = (long)sm + (long)(per / sm);
+            if (cost < best) { best = cost; b.sup_m = sm; b.sup_n = per / sm; }
+        }
+    }
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
     if (fx & FX_ROPE) {                                 // launch_gemm: EPI_NONE, unsliced, bf16 (launch_v2 checks the plan)

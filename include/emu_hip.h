@@ -77,7 +77,9 @@ void emu_gemm_force_config(int cfg);
  * different XCDs); bit 7: it stores O straight from the accumulator layout; bits 12-13: 1 / 2 = attention always on 4 / 8 waves;
  * bit 14: V^T tiles of a fused qkv projection stored straight from the accumulators instead of through the transposed staging; bit 15:
  * causal attention launches keep the (head, query block) order instead of walking every XCD's heads from the longest query block
- * down; bits 8-11: variant of the thin stream (tools/thin_ab.py). */
+ * down; bits 8-11: variant of the thin stream (tools/thin_ab.py); bit 16: no successor-weight prefetch from inside the GEMM kernels;
+ * bit 17: the 256 x 256 tile keeps the column-major XCD runs instead of 2-D tile blocks per XCD (unsliced plain GEMMs), bit 18: blocks
+ * only for launches of more than one round. */
 void emu_gemm_tune(int mask);
 
 /* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at
