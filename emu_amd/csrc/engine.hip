@@ -497,8 +497,8 @@ int linear_then_rmsnorm(const LlamaWs& w, const bf16_t* A, const bf16_t* W, cons
 // rounding points as the serial schedule; a half may take another GEMM tile configuration than the whole prompt (K-slice sums in
 // another order), so the schedules agree to bf16 rounding, not bit for bit.  Capturable: lane_stream forks from and joins the
 // caller's stream through events.
-int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, const int32_t* pos, const int32_t* slot,
-                             const int32_t* kstart, bool fuse_rope, hipStream_t s) {
+int llama_prefill_lanes(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, const int32_t* pos, const int32_t* slot,
+                        const int32_t* kstart, bool fuse_rope, hipStream_t s) {
     emu_ctx* cx = m->ctx;
     const emu_llama_cfg& c = m->cfg;
     const int H = c.hidden, Hl = c.heads_local, D = c.head_dim, HD = Hl * D, Fl = c.ffn_local;
@@ -515,7 +515,7 @@ int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, 
     hipStream_t lane[2] = {s, cx->lane_stream};
     bf16_t* vt[2] = {w.vt, w.vt2};
     float* sk[2] = {w.splitk, w.splitk2};
-    hipEvent_t eStart = cx->ar_ev[0], eKV = cx->ar_ev[1], eDone = cx->ar_ev[2];
+    hipEvent_t eStart = cx->ar_ev[0], eKV = cx->ar_ev[1];              // (ar_ev[2]: the join in llama_prefill_overlapped)
     hipEvent_t* ePrev = cx->ar_ev + 3;   // [lane]  the lane's latest peer-to-peer all-reduce is through (an event is only ever recorded on
     int prev_lane = -1;                  //         ONE stream: one event recorded on both streams of a capture crashed hipGraphInstantiate)
 #define HIPTRY(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return fail(cx, -5, #expr); } } while (0)
@@ -596,9 +596,18 @@ int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, 
             TRY(cx, lane_allreduce(h, hB, (size_t)Mh * H));
         }
     }
-    HIPTRY(hipEventRecord(eDone, lane[1]));                              // join: the caller's stream owns the residual stream again
-    HIPTRY(hipStreamWaitEvent(s, eDone, 0));
 #undef HIPTRY
+    return 0;
+}
+int llama_prefill_overlapped(emu_llama* m, const LlamaWs& w, bf16_t* hA, int M, const int32_t* pos, const int32_t* slot,
+                             const int32_t* kstart, bool fuse_rope, hipStream_t s) {
+    emu_ctx* cx = m->ctx;
+    const int st = llama_prefill_lanes(m, w, hA, M, pos, slot, kstart, fuse_rope, s);
+    // join, on the error path as well: whatever reached the second lane is ordered ahead of the caller's next launch (and a stream
+    // capture in progress ends with the lane joined); the caller's stream owns the residual stream again
+    const bool joined = hipEventRecord(cx->ar_ev[2], cx->lane_stream) == hipSuccess && hipStreamWaitEvent(s, cx->ar_ev[2], 0) == hipSuccess;
+    if (st != 0) return st;
+    if (!joined) { (void)hipGetLastError(); return fail(cx, -5, "emu_llama_forward: joining the second lane"); }
     ++m->ov_forwards;
     return 0;
 }
@@ -876,7 +885,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     }
     // ---- long prompt under tensor parallelism: two row halves, every all-reduce behind the other half's GEMMs (needs the slot-order
     // promise: the rows of the one batch element are the whole context in order, so the first half never reads the second's keys)
-    if (tp && m->tp_overlap_rows > 0 && cx->lane_stream && cx->ar_ev[4] && w.vt2 && promise && Bn == 1 && T == ctx && M >= m->tp_overlap_rows &&
+    if (tp && m->tp_overlap_rows > 0 && cx->lane_stream && cx->ar_ev[4] && w.vt2 && promise && Bn == 1 && T == ctx && M >= m->tp_overlap_rows && l_end > m->l0 &&
         !m->fp8_prefill && m->kv_share_nb <= 1)
         return llama_prefill_overlapped(m, w, hA, M, pos, slot, kstart, fuse_rope, s);
     for (int l = m->l0; l < l_end; ++l) {
