@@ -854,7 +854,7 @@ int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s) {
     }
     if (a.D == 128) {
         hipLaunchKernelGGL((decode_fused_kernel<128, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        if (!a.arrive) hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        if (!a.arrive && !a.skip_combine) hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
     } else if (a.D == 64) {
         hipLaunchKernelGGL((decode_fused_kernel<64, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
         if (!a.arrive) hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);

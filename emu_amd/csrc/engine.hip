@@ -84,6 +84,21 @@ int linear(const bf16_t* A, const bf16_t* W, const bf16_t* bias, const bf16_t* r
     g.partial = splitk; g.partial_floats = splitk_floats;
     return launch_gemm(g, s);
 }
+// the merged o_proj of a short shard (gemv_merge.hip) under the same GEMV launch profiler as linear()
+int gemv_merge_profiled(const GemvMergeArgs& g, hipStream_t s) {
+    if (!g_prof.on) return launch_gemv_merge(g, s);
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -12;
+        g_prof.ev.emplace_back(a, b);
+    }
+    auto& e = g_prof.ev[g_prof.used++];
+    g_prof.bytes += 2.0 * (double)g.N * (double)g.K;
+    (void)hipEventRecord(e.first, s);
+    const int st = launch_gemv_merge(g, s);
+    (void)hipEventRecord(e.second, s);
+    return st;
+}
 }  // namespace
 
 int emu_ctx_fail(emu_ctx* c, int code, const char* what) { return fail(c, code, what); }
@@ -894,6 +909,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         bf16_t* kc = m->kcache + l * kv_layer;
         bf16_t* vc = m->vcache + l * kv_layer;
         // ---- attention
+        bool merge_o = false;
         const bool f8 = m->fp8_decode && M <= 2;
         // prefill with the fp8 weight set: activations are quantised per row ahead of every GEMM, the block-scaled MFMA
         // runs at twice the bf16 rate (BASELINE configs[4]); needs whole 128-element k tiles
@@ -929,6 +945,14 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
             DecodeFusedArgs a{w.qkv, m->cos, m->sin, pos, slot, kc, vc, w.attn, (long)HD, (long)D, kstart, w.dec,
                               Bn, Hl, D, m->s_max, ctx, scale, m->kv_share_nb, m->kv_share_len};
             if (m->decode_tail && m->arrive && m->kv_share_nb <= 1 && (long)Bn * Hl <= EMU_ARRIVE_INTS) a.arrive = m->arrive;
+            // short shards (a TP = 8 rank's 7 heads), opt-in (emu_gemm_tune bit 19): the o_proj launch merges the attention's splits
+            // itself, no combine launch (gemv_merge.hip).  Bit-identical and measured LEVEL with the two launches (3.15 vs 3.15-3.18 ms
+            // per token of a TP = 8 shard, profiles/r05_tp_emulate_merged_o_proj.log): the merge is a dependent L2 trip inside the
+            // projection, which is what the combine launch cost -- one launch less buys nothing here, like the in-kernel split merge
+            // and the tail all-reduce before it
+            merge_o = M == 1 && !f8 && !a.arrive && m->kv_share_nb <= 1 && gemv_merge_ok(Hl, D, H, (ctx + 127) / 128) &&
+                      (emu_gemm_tune_get() & (1 << 19)) != 0;
+            a.skip_combine = merge_o;
             TRY(cx, launch_decode_fused(a, s));
         } else {
             if (m->kv_share_nb > 1) return fail(cx, -22, "emu_llama_forward: shared-prefix KV rows serve single-token steps only");
@@ -944,6 +968,10 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
                         Bn, Hl, T, ctx, spad, D, 1, scale};
             TRY(cx, launch_flash_attn(f, s));
         }
+        if (merge_o) {
+            GemvMergeArgs g{w.dec, slot, (ctx + 127) / 128, Hl, L.wo, hA, w.hB, H, HD, HD, epi_res, nullptr};
+            TRY(cx, gemv_merge_profiled(g, s));
+        } else
         if (f8) TRY(cx, linear(w.attn, B(L8.wo), nullptr, hA, nullptr, w.hB, M, H, HD, HD, HD, H, H, 0.f, epi_res, s, L8.so));
         else if (f8p) TRY(cx, linear_q8(w, w.attn, HD, m->layers8[l].wo, m->layers8[l].so, hA, w.hB, M, H, HD, H, H, epi_res, s));
         else if (fuse_norm) TRY(cx, linear_then_rmsnorm(w, w.attn, L.wo, hA, w.hB, M, H, HD, epi_res, L.ln2, w.xn, c.rms_eps, true, s));

@@ -22,6 +22,21 @@ struct GemvArgs {
     const float* wscale;    // non-null: W holds OCP fp8 e4m3 bytes [N, ldw] with one fp32 scale per row (K % 16 == 0)
 };
 int launch_gemv(const GemvArgs& a, hipStream_t s);
+// o_proj of a tensor-parallel shard's one-row step with the decode attention's split merge in its prologue (gemv_merge.hip):
+// x = merge of the live splits in decode_fused_kernel's workspace (batch row 0), out = epi(x W^T [+ res]); bit-identical to
+// decode_fused_combine_kernel followed by the wave-form GEMV.  K = H * 128 <= 1024, nsplit <= 8, N >= 1024 (gemv_merge_ok).
+struct GemvMergeArgs {
+    const float* ws;        // [H][nsplit][130] split states of the one batch row (decode_fused_ws_floats layout)
+    const int32_t* slot;    // [1] cache slot of the new token: live splits = slot / 128 + 1
+    int nsplit, H;          // splits the attention launch was sized for, local heads
+    const bf16_t* W;        // [N, ldw]
+    const bf16_t* res;      // [N] (EPI_RESID)
+    bf16_t* out;            // [N]
+    int N, K, ldw, epi;
+    bf16_t* x_out;          // null, or [K]: the merged attention output (what the combine launch would have written)
+};
+bool gemv_merge_ok(int heads, int D, int N, int nsplit);
+int launch_gemv_merge(const GemvMergeArgs& a, hipStream_t s);
 // 2..16 rows through LDS-DMA stages and v_mfma_f32_16x16x32_bf16 (gemv_thin.hip); needs K % 256 == 0, no fused norm, bf16 weights
 bool gemv_thin_ok(const GemvArgs& a);
 int launch_gemv_thin(const GemvArgs& a, hipStream_t s);
@@ -264,6 +279,8 @@ struct DecodeFusedArgs {
     // Non-null (one-row path only): the last split workgroup of a head to arrive merges the head's live splits itself
     // (arrive[b * H + h]: zero between launches, the merging workgroup resets it) -- no decode_fused_combine_kernel launch.
     int* arrive = nullptr;
+    // one-row path: leave the split states in ws and launch no combine -- the consumer merges them itself (launch_gemv_merge)
+    bool skip_combine = false;
 };
 constexpr int DECODE_SHARE_MAX = 8;            // beams per group the shared-prefix path takes
 size_t decode_fused_ws_floats(int B, int H, int D, int ctx_max);

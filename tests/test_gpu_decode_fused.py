@@ -124,6 +124,27 @@ def test_fused_tp_shard_modes(tp):
     eng.ctx.check_p2p()
 
 
+@pytest.mark.parametrize("tp", [1, 8])
+def test_merged_o_proj_equals_combine_launch(tp):
+    """A short attention output (<= 1024 values: a TP = 8 rank's 7 heads, or the 8-head "wave" configuration) lets the o_proj launch merge
+    the decode attention's splits in its own prologue (csrc/gemv_merge.hip, opt-in: emu_gemm_tune bit 19) instead of a combine launch
+    ahead of it: same bits as the two launches, across a 128-key split boundary (contexts 250 ... 262), eager and replayed from a hipGraph."""
+    from emu_amd._lib import lib
+    from emu_amd.conf.emu_conf import LlamaCfg
+    cfg = LlamaCfg(num_hidden_layers=2) if tp > 1 else LlamaCfg(**CFGS["wave"])
+    eng = _engine(cfg, 2048, tp=tp, p2p=tp > 1)
+    try:
+        lib().emu_gemm_tune(0)
+        ref = _run(eng, 0, 250, 12)
+        lib().emu_gemm_tune(1 << 19)
+        _same(ref, _run(eng, 0, 250, 12))
+        _same(ref, _run(eng, 0, 250, 12, graph=True))
+    finally:
+        lib().emu_gemm_tune(0)
+    if tp > 1:
+        eng.ctx.check_p2p()
+
+
 def test_mode_switch_drops_graphs():
     """a captured decode graph must not survive a mode switch (fp8 weights, decode tail, fused layers)."""
     from emu_amd.conf.emu_conf import LlamaCfg
