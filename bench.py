@@ -546,11 +546,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher -- one rank process per GPU under torch.distributed.run, the
+        # form the driver uses (rank 0 prints the ONE JSON line; its stdout / stderr pass through; the exit code is the job's)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (it spawns the ranks itself) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if world > torch.cuda.device_count() and os.environ.get("EMU_TP_SHARED_GPU") != "1":
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} GPU(s) visible (EMU_TP_SHARED_GPU=1 runs all ranks on cuda:0: "
+                         "validation of the data path only, never a measurement)")
     # validation hook, not a measurement: EMU_TP_SHARED_GPU=1 puts every rank on cuda:0 (RCCL refuses that, so gloo rendezvous
     # and the peer-to-peer all-reduce for every message) to run the full-size TP data path on a 1-GPU box
     shared = world > 1 and os.environ.get("EMU_TP_SHARED_GPU") == "1"
@@ -961,11 +976,14 @@ def main():
                                    f"(256 visual tokens) + {a.prompt_tokens}-token prompt (S={S}), greedy, batch 1",
                        "decoder_layers": lcfg.num_hidden_layers, "vit_layers": vcfg.layers,
                        "parallelism": f"tp{world}" + (" (ranks sharing one GPU: validation only)" if shared else ""), "allreduce": ("p2p one-shot (<=256 KiB) + rccl" if ctx.p2p else "rccl") if world > 1 else None,
-                       "tp": ({"ms_per_token_by_rank": per_rank_ms, "allreduces_per_token": 2 * lcfg.num_hidden_layers,
+                       "tp": ({"ms_per_token_by_rank": per_rank_ms, "per_rank_ms_per_token": per_rank_ms, "allreduces_per_token": 2 * lcfg.num_hidden_layers,
+                               "rccl_ranks": 0 if shared else world,
+                               "p2p_form": ("fence-free" if getattr(ctx, "p2p_fence_free", False) else "fenced") if ctx.p2p else None,
                                "allreduce_bytes": 2 * lcfg.hidden_size, "weight_bytes_per_token_per_rank": lm.weight_bytes_per_token(),
                                "prefill_overlap_min_rows": lm.tp_overlap_rows, "prefill_overlap_forwards": lm.tp_overlap_count(), "prefill_schedules": tp_prefill,
-                               "note": "one process per GPU; decode: o_proj / down_proj partial sums all-reduced in place on the launch stream; prompts of "
-                                       ">= prefill_overlap_min_rows rows: two row halves, each half's all-reduce on a second stream behind the other half's GEMMs"}
+                               "note": "one process per GPU; decode: o_proj / down_proj partial sums all-reduced in place on the launch stream (one-shot "
+                                       "peer-to-peer kernel; its fence-free form only after a soak passed on every rank of this job); prefill: serial "
+                                       "all-reduce schedule unless prefill_overlap_min_rows > 0 (opt-in two-lane schedule, EMU_TP_OVERLAP)"}
                               if world > 1 else None),
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "valid": bool(a.layers == 60 and a.vit_layers == 64 and not shared and not a.gemm_tune)},

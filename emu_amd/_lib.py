@@ -77,6 +77,8 @@ _PROTOS = {
     "emu_tp_p2p_open": (i32, [vp, vp, i32]),
     "emu_tp_p2p_allreduce_bf16": (i32, [vp, vp, sz, vp]),
     "emu_tp_p2p_enable": (i32, [vp, i32]),
+    "emu_tp_p2p_set_fenced": (i32, [vp, i32]),
+    "emu_tp_p2p_fenced": (i32, [vp]),
     "emu_tp_p2p_giveups": (C.c_uint, []),
     "emu_linear_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "emu_linear_fused_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(LinearFxC), vp]),
@@ -89,6 +91,7 @@ _PROTOS = {
     "emu_rmsnorm_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "emu_layernorm_q8_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "emu_prefetch": (i32, [vp, sz, i32, vp]),
     "emu_softmax_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_embed_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_scatter_rows_bf16": (i32, [vp, vp, vp, i32, i32, vp]),

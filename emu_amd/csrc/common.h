@@ -124,4 +124,23 @@ __device__ __forceinline__ u32x4 ld_stream(const u32x4* p) { return __builtin_no
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// ---- successor prefetch for the one-row decode path: the weights of the launches that FOLLOW this one on the stream
+// (a decode step knows them).  A span is two runs of 128-byte lines (a run may end at a matrix boundary); worker w of nworkers
+// requests lines w, w + nworkers, ... with one default-policy dword load each -- the line travels HBM -> infinity cache (and the
+// requesting XCD's L2) -- and never waits for them: the results are discarded, s_endpgm waits for the counters anyway.  The
+// destination is an in-out operand so it stays allocated while loads are in flight (gemm_tile.h::prefetch_lines has the story).
+struct PfSpan {
+    const char* p0 = nullptr;
+    const char* p1 = nullptr;
+    uint32_t n0 = 0, n1 = 0;            // lines of each run
+};
+__device__ __forceinline__ void pf_touch(const PfSpan& s, uint32_t worker, uint32_t nworkers) {
+    uint32_t d = 0;
+    for (uint32_t l = worker; l < s.n0; l += nworkers)
+        asm volatile("global_load_dword %0, %1, off" : "+v"(d) : "v"(s.p0 + ((size_t)l << 7)) : "memory");
+    for (uint32_t l = worker; l < s.n1; l += nworkers)
+        asm volatile("global_load_dword %0, %1, off" : "+v"(d) : "v"(s.p1 + ((size_t)l << 7)) : "memory");
+    asm volatile("" :: "v"(d));
+}
+
 #define EMU_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

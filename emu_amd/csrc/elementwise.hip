@@ -361,7 +361,17 @@ __global__ __launch_bounds__(256) void layernorm_q8_kernel(const bf16_t* __restr
         *reinterpret_cast<uint2*>(q + roff + vi * 8) = make_uint2((unsigned)lo, (unsigned)hi);
     }
 }
+// touch [ptr, ptr + bytes) into the infinity cache ahead of the launch that streams it (stand-alone form of common.h::pf_touch)
+__global__ __launch_bounds__(256) void prefetch_kernel(PfSpan sp) { pf_touch(sp, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256); }
 }  // namespace
+int launch_prefetch(const void* ptr, size_t bytes, int workgroups, hipStream_t s) {
+    if (!ptr || workgroups < 1 || (bytes >> 7) > 0xffffffffull) return -22;
+    PfSpan sp;
+    sp.p0 = reinterpret_cast<const char*>(ptr); sp.n0 = (uint32_t)(bytes >> 7);
+    hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, s, sp);
+    EMU_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_softmax_rows(bf16_t* x, const bf16_t* bias, int rows, int cols, int ld, int ld_bias, float scale, hipStream_t s) {
     if (rows < 1 || (cols & 7) || (ld & 7) || (bias && (ld_bias & 7))) return -22;

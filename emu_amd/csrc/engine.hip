@@ -269,6 +269,12 @@ int emu_tp_p2p_enable(emu_ctx* ctx, int on) {
     return 0;
 }
 
+int emu_tp_p2p_set_fenced(emu_ctx* ctx, int fenced) {
+    if (!ctx || !ctx->p2p) return -22;
+    emu_p2p_set_fenced(ctx->p2p, fenced);
+    return 0;
+}
+int emu_tp_p2p_fenced(const emu_ctx* ctx) { return ctx && ctx->p2p ? emu_p2p_fenced(ctx->p2p) : -1; }
 unsigned int emu_tp_p2p_giveups(void) { return emu_p2p_giveups_read(); }
 
 int emu_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s) {
@@ -336,6 +342,7 @@ int emu_layernorm_q8_bf16(const void* x, const void* w, const void* b, const voi
     return launch_layernorm_q8(B(x), B(w), B(b), B(res), reinterpret_cast<bf16_t*>(y), reinterpret_cast<uint8_t*>(q), scale, rows, cols,
                                eps, S(s));
 }
+int emu_prefetch(const void* ptr, size_t bytes, int workgroups, emu_stream_t s) { return launch_prefetch(ptr, bytes, workgroups, S(s)); }
 int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s) {
     return launch_softmax_rows(B(x), B(bias), rows, cols, ld, ld_bias, scale, S(s));
 }
@@ -406,6 +413,7 @@ struct emu_llama {
     int kv_batch = 0, s_max = 0;
     int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
     int l0 = 0, l1 = -1;                         // emu_llama_set_layer_range: layers [l0, l1) run (l1 < 0: all)
+    bool fuse_norm_on = false;                   // sticky: o_proj / down_proj K-slice sums apply the RMSNorm behind them (M > 16, no TP)
     bool prefill_fusion = false;                 // emu_llama_set_prefill_fusion: RoPE + KV append + V^T in the qkv GEMM's epilogue (one-shot: the next T > 1 forward consumes it)
     // decode attention without the combine launch (emu_llama_set_decode_tail, off by default): per (row, head) arrival counters of
     // the split workgroups (zero between launches; owned here: EMU_ARRIVE_INTS ints of device memory)
@@ -718,6 +726,7 @@ int emu_llama_set_decode_tail(emu_llama* m, int enable) {
 int emu_llama_set_prefill_fusion(emu_llama* m, int enable) {
     if (!m) return -22;
     m->prefill_fusion = enable != 0;
+    m->fuse_norm_on = enable != 0;               // sticky part: the K-slice sum + RMSNorm fusion (independent of the slot order)
     return 0;
 }
 int emu_llama_set_tp_overlap(emu_llama* m, int min_rows) {
@@ -754,7 +763,13 @@ int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head
     return 0;
 }
 int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max) {
-    if (!m || batch < 1 || s_max < 1) return -22;
+    if (!m) return -22;
+    if (!kcache && !vcache) {                    // detach: the caller freed the caches; every later forward fails with -22 until new ones are set
+        m->kcache = m->vcache = nullptr; m->kv_batch = m->s_max = 0;
+        m->kv_share_nb = m->kv_share_len = 0;
+        return 0;
+    }
+    if (!kcache || !vcache || batch < 1 || s_max < 1) return -22;
     m->kcache = B(kcache); m->vcache = B(vcache); m->kv_batch = batch; m->s_max = s_max;
     m->kv_share_nb = m->kv_share_len = 0;
     return 0;
@@ -780,7 +795,12 @@ size_t emu_llama_workspace_bytes(const emu_llama* m, int Bn, int T) {
 int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* pos, const int32_t* slot,
                       const int32_t* kstart, const int32_t* ctx_dev, int ctx, void* workspace, size_t ws_bytes,
                       emu_stream_t s_) {
-    if (!m || !hidden || !pos || !slot) return -22;
+    if (!m) return -22;
+    // the slot-order promise (emu_llama_set_prefill_fusion) is per call: every T > 1 entry consumes it, whatever happens below -- an
+    // early return must not leave it armed for an unrelated caller
+    const bool promise = m->prefill_fusion;
+    if (T > 1) m->prefill_fusion = false;
+    if (!hidden || !pos || !slot) return -22;
     emu_ctx* cx = m->ctx;
     const emu_llama_cfg& c = m->cfg;
     if (!m->kcache || Bn != m->kv_batch) return fail(cx, -22, "emu_llama_forward: KV cache not set for this batch size");
@@ -803,13 +823,14 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     // never written on that path: zeroed once per call (the attention kernel multiplies them by masked probabilities).
     // The promise is per call: it is consumed here, so a later emu_llama_forward with rows in another slot order (any caller that did
     // not renew it) runs the unfused sequence, which honours slot[] everywhere.
-    const bool promise = m->prefill_fusion;
-    if (T > 1) m->prefill_fusion = false;
     bool fuse_rope = promise && Bn == 1 && T > 16 && T == ctx && D == 128 && !(HD & 255) && !m->fp8_prefill && m->kv_share_nb <= 1;
     if (fuse_rope && hipMemsetAsync(w.vt, 0, (size_t)HD * spad * 2, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
     // (prefill fusion, no tensor parallelism: the K-slice sums of o_proj / down_proj apply the RMSNorm that follows them; for
     // down_proj that is the NEXT layer's input norm, so a layer may find its normalised rows in w.xn already)
-    const bool fuse_norm = promise && !tp && M > 16 && !m->fp8_prefill;
+    // The K-slice sum + RMSNorm fusion does not depend on the slot order: it follows the sticky capability (fuse_norm_on: set with the
+    // first promise, cleared by emu_llama_set_prefill_fusion(0)), so M > 16 rows of single-token steps (beam / contrastive search
+    // with B * beams > 16) keep the fused path they had before the promise became one-shot.
+    const bool fuse_norm = m->fuse_norm_on && !tp && M > 16 && !m->fp8_prefill;
     bool xn_ready = false;
     // ---- one-row step with bf16 weights: whole layers per launch (decode_layer.hip), same bits as the launches below
     if (m->decode_fused && T == 1 && Bn == 1 && D == 128 && !m->fp8_decode && m->kv_share_nb <= 1 && l_end > m->l0 && m->dl_cnt) {
@@ -832,7 +853,7 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
         if (ok && tp && cx->p2p) {
             long long lim = 0;
             const bool view = emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &lim);
-            in_kernel_ar = view && cx->p2p_on && m->decode_fused == 2;
+            in_kernel_ar = view && cx->p2p_on && m->decode_fused == 2 && emu_p2p_fenced(cx->p2p) == 0;   // the in-launch all-reduce is the fence-free form only
             if (!in_kernel_ar) d.tp_n = 0;
             if (view && lim > d.limit_ticks) d.limit_ticks = lim;  // a lagging peer holds every downstream wait: the peer bound applies
             ok = decode_layers_ok(d);
@@ -848,14 +869,15 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
                     const emu_llama::Layer& L = m->layers[l];
                     t[l] = {L.wqkv, L.wo, L.wgu, L.wdown, L.ln1, L.ln2};
                 }
-                if (hipMemcpy(m->dl_table, t.data(), sizeof(DecodeLayerPtrs) * c.layers, hipMemcpyHostToDevice) != hipSuccess)
+                if (hipStreamSynchronize(s) != hipSuccess ||        // fused launches still in flight on s read the table
+                    hipMemcpy(m->dl_table, t.data(), sizeof(DecodeLayerPtrs) * c.layers, hipMemcpyHostToDevice) != hipSuccess)
                     return fail(cx, -5, "emu_llama_forward: weight table upload");
                 m->dl_dirty = false;
             }
             for (int l = m->l0; l < l_end; ++l)
                 if (!m->layers[l].wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
             if (hipMemsetAsync(m->dl_cnt, 0, m->dl_cnt_bytes, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
-            if (tp && m->decode_fused == 3 && cx->p2p_on && emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &d.limit_ticks)) {
+            if (tp && m->decode_fused == 3 && cx->p2p_on && emu_p2p_fenced(cx->p2p) == 0 && emu_p2p_view(cx->p2p, d.tp_block, &d.tp_seq, &d.tp_n, &d.tp_rank, &d.limit_ticks)) {
                 // mode 3: the weight streams with an RMSNorm in front stay stand-alone launches; the attention (split merge by the
                 // head's last split) and the two row-sharded projections run as single-role launches whose LAST workgroup to arrive
                 // runs the all-reduce -- nobody waits inside a launch except that one workgroup for its peers, so rank processes that

@@ -375,6 +375,8 @@ int launch_add_silu(const bf16_t* a, const bf16_t* b, bf16_t* sum_out, bf16_t* s
 // out[r, :] = table[step[0], :] for r < rows
 int launch_gather_step_row(const bf16_t* table, const int32_t* step, bf16_t* out, int rows, int cols, hipStream_t s);
 
+// stand-alone successor prefetch (common.h::pf_touch): [ptr, ptr + bytes) -> infinity cache, workgroups x 256 threads
+int launch_prefetch(const void* ptr, size_t bytes, int workgroups, hipStream_t s);
 // in-place row softmax of x [rows, ld] over the first `cols` columns: x = bf16(softmax(float(x) * scale))
 // (materialised-score attention for head dims the flash kernel does not cover: the VAE mid block, D = 512)
 // per-row fp8 e4m3fn quantisation: scale[n] = amax_n / 448 (1 for an all-zero row), q = rne(w / scale)
@@ -393,5 +395,7 @@ EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out);          // nullptr
 int emu_p2p_open(EmuP2p* p, const void* handles);                      // n x 64 bytes, rank order (own entry ignored)
 void emu_p2p_destroy(EmuP2p* p);
 void emu_p2p_set_timeout_ms(EmuP2p* p, int ms);
+void emu_p2p_set_fenced(EmuP2p* p, int fenced);                        // 1 (default): system-scope fences around the exchange; 0: fence-free form
+int emu_p2p_fenced(const EmuP2p* p);
 int emu_p2p_allreduce(EmuP2p* p, bf16_t* x, size_t n, hipStream_t s);  // in place; > one slot goes through in chunks
 unsigned int emu_p2p_giveups_read();

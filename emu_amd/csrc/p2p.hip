@@ -34,6 +34,7 @@ struct P2pPeers {
     char* block[EMU_P2P_MAX_RANKS];                 // every rank's comm block as mapped in THIS process (own block included)
     int n, rank;
     long long limit_ticks;                          // wait bound in s_memrealtime ticks (100 MHz)
+    int fenced;                                     // 1: the exchange is bracketed by two system-scope fences (see the kernel)
 };
 
 // piece g of a message: elements [g * P2P_PIECE, (g + 1) * P2P_PIECE), one 16-byte vector per lane of workgroup g, which runs
@@ -55,10 +56,16 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
     const int e0 = g * P2P_PIECE + tid * 8;                                 // my 8 elements
     const size_t off = (size_t)slot * EMU_P2P_SLOT_BYTES + (size_t)e0 * 2;
     const bool full = e0 + 8 <= n, part = e0 < n;
-    // The exchange carries no cache-wide fence (round 5; the first version bracketed it with two __threadfence_system(), ~3.5 us each
-    // of the launch's 6.8): the slot is written with system-scope (sc0 sc1, write-through) stores whose acknowledgement the wave waits
-    // for before the flag goes out, and read with system-scope loads, which no cache level serves -- MI355X_MICROARCH.md's
-    // "{sc0 sc1 stores and loads both sides}" form, the one csrc/decode_layer.hip's in-launch all-reduce uses as well.
+    // Two forms of the exchange, chosen per launch (P2pPeers::fenced):
+    //  * fenced (the default of a fresh comm block): the HIP memory model's own release / acquire -- __threadfence_system() between
+    //    the payload stores and the flag, and again between the last flag poll and the payload loads.  ~3.5 us each of a 6.8 us launch.
+    //  * fence-free (round 5): no cache-wide operation at all.  The slot is written with system-scope (sc0 sc1, write-through) stores
+    //    whose acknowledgement the wave waits for before the flag goes out, and read with system-scope loads, which no cache level
+    //    serves -- MI355X_MICROARCH.md's "{sc0 sc1 stores and loads both sides}" form.  That rests on gfx950's write-through / ack
+    //    behaviour, not on the memory model, and ranks that share one GPU (every run this repository has had) share an L2 and never
+    //    exercise xGMI -- so the host switches it on only after a SOAK of this form passed on every rank of the job it is about to
+    //    serve (emu_amd/llama.py::_init_p2p: hundreds of back-to-back all-reduces of sequence-dependent data, every word checked).
+    // Both forms use the same sc0 sc1 stores and loads, so the fences are purely additional ordering.
     const __amdgpu_buffer_rsrc_t rmine = __builtin_amdgcn_make_buffer_rsrc(p.block[p.rank], 0, (uint32_t)(2 * EMU_P2P_SLOT_BYTES), 0x00020000);
     // ---- 1. publish my piece
     if (part) {
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
         __builtin_amdgcn_raw_buffer_store_b128(v, rmine, (uint32_t)off, 0, 17);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's share has reached the system's point of coherence
+    if (p.fenced) __threadfence_system();                                  // release
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flag_of(p.block[p.rank], slot, g), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // ---- 2. wait for every rank's piece of this sequence number
@@ -84,6 +92,7 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    if (p.fenced) __threadfence_system();                                  // acquire (every wave: the loads below are its own)
     __syncthreads();
     // ---- 3. sum in rank order, fp32
     if (part) {
@@ -116,6 +125,7 @@ struct EmuP2p {
     unsigned long long* seq = nullptr;              // device-side sequence counters, one per piece (plain device memory)
     int n = 0, rank = 0;
     long long limit_ticks = 10LL * 100000000LL;     // 10 s
+    int fenced = 1;                                 // emu_p2p_set_fenced: the memory-model form until the host's soak cleared the other
 };
 
 EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out) {
@@ -175,7 +185,7 @@ int emu_p2p_allreduce(EmuP2p* p, bf16_t* x, size_t n, hipStream_t s) {
         if (!p->block[r]) return -107;                                     // peers not mapped yet
     P2pPeers peers;
     for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r) peers.block[r] = r < p->n ? p->block[r] : nullptr;
-    peers.n = p->n; peers.rank = p->rank; peers.limit_ticks = p->limit_ticks;
+    peers.n = p->n; peers.rank = p->rank; peers.limit_ticks = p->limit_ticks; peers.fenced = p->fenced;
     const size_t chunk = EMU_P2P_SLOT_BYTES / 2;                           // elements per slot
     for (size_t o = 0; o < n; o += chunk) {
         const int m = (int)(n - o < chunk ? n - o : chunk);
@@ -194,6 +204,8 @@ bool emu_p2p_view(EmuP2p* p, char** block8, unsigned long long** seq, int* n, in
     return true;
 }
 
+void emu_p2p_set_fenced(EmuP2p* p, int fenced) { if (p) p->fenced = fenced != 0; }
+int emu_p2p_fenced(const EmuP2p* p) { return p ? p->fenced : -1; }
 void emu_p2p_set_timeout_ms(EmuP2p* p, int ms) { if (p && ms > 0) p->limit_ticks = (long long)ms * 100000LL; }
 
 unsigned int emu_p2p_giveups_read() {

@@ -93,6 +93,8 @@ class EmuModel:
         # library's vectorised search, the one the golden fixtures can pin (LlamaEngine.beam_search_generate)
         self.hf_semantics = "4.31"
 
+    _warned_431 = False          # one warning per process: the default beam mode has no library vector (generate_ids)
+
     # ------------------------------------------------------------------ nn.Module-like surface
     def device(self, module=None):
         return self.ctx.device
@@ -212,6 +214,12 @@ class EmuModel:
             min_len = max(int(min_len), int(min_new_tokens)) if sem == "4.31" else int(min_new_tokens)
         elif sem != "4.31":
             min_len = max(int(min_len) - S, 0)
+        if num_beams > 1 and sem == "4.31" and min_len < 1:
+            # 4.31's BeamHypotheses.add scores an EOS hypothesis over hyp.shape[-1] ** length_penalty with the EOS excluded: a
+            # hypothesis that ends at the first step (cur == 0) has length 0 (0 ** lp), a case that release only avoids through its
+            # min_length = 1 default; the restatement here does not define it either (checked before any device work)
+            raise ValueError("beam search under hf_semantics='4.31' needs min_len >= 1 (an EOS hypothesis of length 0 is scored over "
+                             "0 ** length_penalty in that release); pass min_len >= 1 or hf_semantics='5.x'")
         x = self._prompt_embeds(input_ids, image, self.n_query, IMAGE_TOKEN_ID)
         if video is not None:
             x = self._prompt_embeds(input_ids, video, self.v_query, gIMG_TOKEN_ID, embeds=x)
@@ -224,12 +232,15 @@ class EmuModel:
                                                         int(top_k), min_len, repetition_penalty, eos_id=eos,
                                                         pad_id=PAD_TOKEN_ID)
         if num_beams > 1:
-            if sem == "4.31" and min_len < 1:
-                # 4.31's BeamHypotheses.add scores an EOS hypothesis over hyp.shape[-1] ** length_penalty with the EOS excluded: a
-                # hypothesis that ends at the first step has length 0 (0 ** lp), a case that release only avoids through its
-                # min_length = 1 default; the restatement here does not define it either
-                raise ValueError("beam search under hf_semantics='4.31' needs min_len >= 1 (an EOS hypothesis of length 0 is scored over "
-                                 "0 ** length_penalty in that release); pass min_len >= 1 or hf_semantics='5.x'")
+            if sem == "4.31" and not EmuModel._warned_431:
+                # honesty in code, not only in INTEGRATION.md: this is the DEFAULT mode (emu.py:163-172: 5 beams, length_penalty -1)
+                EmuModel._warned_431 = True
+                import warnings
+                warnings.warn("emu_amd: beam search under hf_semantics='4.31' (the transformers release the reference pins) follows a "
+                              "RESTATEMENT of that release's BeamSearchScorer: no vector from the 4.31 library itself exists in "
+                              "tests/golden/ (the library is not installable offline).  hf_semantics='5.x' is the mode pinned to the "
+                              "installed library's ids; the two differ only where a hypothesis ends on EOS (INTEGRATION.md).",
+                              stacklevel=2)
             return self.decoder.lm.beam_search_generate(x.view(B, S, -1), attention_mask, num_beams, max_new_tokens, min_len,
                                                         length_penalty, eos_id=eos, pad_id=PAD_TOKEN_ID,
                                                         do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,

@@ -46,6 +46,7 @@ class EmuHipContext:
             torch.cuda.set_device(self.device)
         self.tp_rank, self.tp_size = tp_rank, tp_size
         self.p2p = False
+        self.p2p_fence_free = False
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         check(lib().emu_ctx_create(idx, tp_rank, tp_size, C.byref(h)), "emu_ctx_create")
@@ -102,11 +103,52 @@ class EmuHipContext:
             ok = ok and L.emu_tp_p2p_giveups() == 0
         ok = all(x == b"1" for x in allgather_bytes(b"1" if ok else b"0"))
         if ok:
+            # the self-test above ran the FENCED form (system-scope release / acquire: the memory model's guarantee).  The fence-free
+            # form (3.3 instead of 6.8 us per decode all-reduce) rests on write-through + acknowledgement behaviour instead, so it is
+            # switched on only after a soak of it passed on EVERY rank of this very job (real xGMI links where the ranks have their
+            # own GPUs); EMU_P2P_FENCE_FREE=0 keeps the fenced form, =1 skips the soak (tools on one GPU).
+            want_ff = os.environ.get("EMU_P2P_FENCE_FREE", "auto")
+            ff = want_ff == "1"
+            if want_ff == "auto":
+                check(L.emu_tp_p2p_set_fenced(self.handle, 0), "emu_tp_p2p_set_fenced", self.handle)
+                ff = self._soak_p2p()
+                ff = all(x == b"1" for x in allgather_bytes(b"1" if ff else b"0"))
+                if not ff and self.tp_rank == 0:
+                    import warnings
+                    warnings.warn("fence-free peer-to-peer all-reduce failed its soak; keeping the fenced form")
+            check(L.emu_tp_p2p_set_fenced(self.handle, 0 if ff else 1), "emu_tp_p2p_set_fenced", self.handle)
+            self.p2p_fence_free = ff
             check(L.emu_tp_p2p_enable(self.handle, 1), "emu_tp_p2p_enable", self.handle)
         elif self.tp_rank == 0:
             import warnings
             warnings.warn("peer-to-peer all-reduce self-test failed; tensor-parallel all-reduces stay on RCCL")
         return ok
+
+    def _soak_p2p(self, iters: int = 384) -> bool:
+        """Back-to-back all-reduces of sequence- and rank-dependent vectors in the CURRENT form of the exchange, one host
+        synchronisation at the end, every word of every result checked against the closed form (small integers: exact in bf16).
+        Both slots are reused ~190 times each with no host gap between uses -- the window in which a late write-through or a
+        stale read would surface -- and two slot-sized (256 KiB) messages exercise all 32 pieces."""
+        L, n, dev = lib(), 6656, self.device
+        i = torch.arange(n, device=dev, dtype=torch.int64)
+        k = torch.arange(iters, device=dev, dtype=torch.int64)[:, None]
+        val = lambda r: ((i * 7 + k * 3 + r * 5) % 16).to(torch.float32)
+        x = val(self.tp_rank).to(BF16).contiguous()
+        want = sum(val(r) for r in range(self.tp_size)).to(BF16)
+        s = ops.stream(dev)
+        ok = True
+        for j in range(iters):
+            ok = ok and L.emu_tp_p2p_allreduce_bf16(self.handle, x[j].data_ptr(), n, s) == 0
+        nb = 128 * 1024
+        ib = torch.arange(nb, device=dev, dtype=torch.int64)
+        big = [((ib * 3 + j + self.tp_rank * 11) % 8).to(BF16) for j in range(2)]
+        for j in range(2):
+            ok = ok and L.emu_tp_p2p_allreduce_bf16(self.handle, big[j].data_ptr(), nb, s) == 0
+        torch.cuda.synchronize(dev)
+        ok = ok and bool(torch.equal(x, want))
+        for j in range(2):
+            ok = ok and bool(torch.equal(big[j], sum(((ib * 3 + j + r * 11) % 8).to(torch.float32) for r in range(self.tp_size)).to(BF16)))
+        return ok and L.emu_tp_p2p_giveups() == 0
 
     def check_p2p(self) -> None:
         """Raise if a device-side wait of the P2P all-reduce ever timed out (the sums since then are invalid)."""
@@ -164,11 +206,14 @@ class LlamaEngine:
         mode = int(os.environ.get("EMU_DECODE_FUSED", "0"))
         if mode:
             self.set_decode_fused(mode)
-        # tensor parallelism: prompts of >= 1024 rows run as two row halves whose all-reduces travel on a second stream behind the
-        # other half's GEMMs (emu_llama_set_tp_overlap); EMU_TP_OVERLAP=0 keeps the serial schedule, =N sets the threshold
+        # tensor parallelism: the two-lane prefill (prompts of >= N rows run as two row halves whose all-reduces travel behind the
+        # other half's GEMMs, emu_llama_set_tp_overlap) is OPT-IN: EMU_TP_OVERLAP=N (e.g. 1024) or set_tp_overlap(N).  What it costs
+        # is measured (+17...21 % per rank under graph replay, +40...47 % eager, profiles/r05_tp_prefill_two_lane_per_rank_cost.log);
+        # what it hides is an estimate until a multi-GPU node has run it (bench.py --tp-prefill-leg collects that evidence), and it
+        # issues RCCL all-reduces of one communicator from two streams, which no run has exercised against a real ring.
         self.tp_overlap_rows = 0
-        if ctx.tp_size > 1:
-            self.set_tp_overlap(int(os.environ.get("EMU_TP_OVERLAP", "1024")))
+        if ctx.tp_size > 1 and int(os.environ.get("EMU_TP_OVERLAP", "0")) > 0:
+            self.set_tp_overlap(int(os.environ["EMU_TP_OVERLAP"]))
 
     def _mode_changed(self) -> None:
         self.mode_epoch += 1
@@ -368,7 +413,11 @@ class LlamaEngine:
             cur = slots.pop(k, None)
             if cur is not None and self.kcache is cur[0]:      # the engine's current cache goes: the next prefill allocates anew
                 self.kcache = self.vcache = None
-                self.kv_batch = self.s_max = 0
+        if self.kcache is None:
+            # the library must not keep pointers into memory the allocator may hand out again: detach, so that a forward / step /
+            # regress call before the next alloc_kv fails with -22 instead of writing K / V into freed memory
+            self.kv_batch = self.s_max = 0
+            check(lib().emu_llama_set_kv(self.handle, None, None, 0, 0), "emu_llama_set_kv", self.ctx.handle)
         self._mode_changed()
 
     def set_kv_share(self, rows_per_prompt: int, shared_slots: int) -> None:

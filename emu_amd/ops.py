@@ -309,3 +309,11 @@ def softmax_rows_(x, scale: float = 1.0, bias=None):
     check(lib().emu_softmax_rows_bf16(_p(x), _p(bias), x.shape[0], x.shape[1], x.stride(0),
                                       bias.stride(0) if bias is not None else 0, float(scale), stream(x)), "emu_softmax_rows_bf16")
     return x
+
+
+def prefetch(t: torch.Tensor, workgroups: int = 256, nbytes: Optional[int] = None):
+    """Touch the first ``nbytes`` (default: all) of a contiguous tensor into the infinity cache; see emu_prefetch."""
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("prefetch needs a contiguous GPU tensor")
+    n = t.numel() * t.element_size() if nbytes is None else int(nbytes)
+    check(lib().emu_prefetch(_p(t), n, int(workgroups), stream(t)), "emu_prefetch")

@@ -52,6 +52,12 @@ int emu_tp_p2p_create(emu_ctx* ctx, void* handle64_out);
 int emu_tp_p2p_open(emu_ctx* ctx, const void* handles, int timeout_ms);
 int emu_tp_p2p_allreduce_bf16(emu_ctx* ctx, void* buf, size_t n, emu_stream_t s);
 int emu_tp_p2p_enable(emu_ctx* ctx, int on);
+/* The exchange has two forms: fenced = 1 (the state of a fresh comm block) brackets it with system-scope release / acquire fences --
+ * the HIP memory model's own guarantee --; fenced = 0 relies on write-through stores + acknowledgement and cache-bypassing loads alone
+ * (3.3 instead of 6.8 us per 13 KB all-reduce).  The host selects 0 only after a soak of that form passed on every rank of the job
+ * (emu_amd/llama.py::_init_p2p).  emu_tp_p2p_fenced: the current form (-1: no comm block). */
+int emu_tp_p2p_set_fenced(emu_ctx* ctx, int fenced);
+int emu_tp_p2p_fenced(const emu_ctx* ctx);
 unsigned int emu_tp_p2p_giveups(void);
 
 /* Optional fp32 scratch for split-K GEMMs / convolutions issued through the primitives below (emu_linear_bf16,
@@ -183,6 +189,12 @@ int emu_layernorm_q8_bf16(const void* x, const void* w, const void* b, const voi
  * bf16 bias [rows, cols] (relative-position bias + causal mask), T5Attention of Emu1's CausalFormer
  * (Emu1/models/modeling_t5.py:629-666) */
 int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s);
+/* Touch [ptr, ptr + bytes) -- the weight matrix of a launch that FOLLOWS on the stream -- into the 256 MB infinity cache with
+ * `workgroups` x 256 threads, one dword per 128-byte line, nothing waited for.  The stand-alone form of the successor prefetch the
+ * one-row decode step carries inside its own launches (emu_llama_set_decode_prefetch): the reference's nn.Linear weights
+ * (transformers LlamaDecoderLayer reached from Emu2/emu/emu.py:213-229) are read once per token, and every kernel of a layer that
+ * leaves HBM idle (attention, split merge, all-reduce) pulls the next projection's rows on-die meanwhile.  tools / tests. */
+int emu_prefetch(const void* ptr, size_t bytes, int workgroups, emu_stream_t s);
 /* embed_tokens (emu.py:119,193) and the masked row overwrite text_embeds[ids == IMAGE] = ... (emu.py:202-203) */
 int emu_embed_gather_bf16(const int32_t* ids, const void* table, void* out, int n_tok, int hidden, int vocab,
                           emu_stream_t s);
@@ -250,6 +262,7 @@ int emu_llama_set_head_fp8(emu_llama* m, const void* lm_head8, const float* lm_s
 int emu_llama_use_fp8(emu_llama* m, int enable);
 int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed,
                        const void* rope_cos, const void* rope_sin);
+/* kcache == vcache == NULL detaches the caches (the caller freed them): emu_llama_forward answers -22 until new ones are set. */
 int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max);
 /* Beam search (the reference's default decoding mode: lm.generate(num_beams=5), Emu2/emu/emu.py:163-172,213-229; transformers
  * replicates the prompt's cache per beam with expand_inputs / _reorder_cache).  Here cache rows come in groups of `beams`

@@ -84,6 +84,29 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert ps["serial_forwards_on_two_lanes"] == 0 and ps["two_lane_forwards_on_two_lanes"] == 4, ps
 
 
+def test_bench_spawns_its_own_ranks():
+    """Exactly `python bench.py --gpus 2 --steps 4 --warmup 1` (no torch.distributed.run in front: the driver's BENCH form applied to
+    N > 1): bench.py becomes the launcher, rank 0 prints the ONE JSON line, the exit code is the job's.  Both ranks on this one device
+    (EMU_TP_SHARED_GPU=1), reduced depth so the test stays short; the line says which form of the peer-to-peer exchange the soak
+    selected."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EMU_TP_SHARED_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--layers", "2", "--vit-layers", "2", "--no-legs", "--no-denoise", "--no-fp8", "--no-beam", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["value"] > 0
+    tp = d["config"]["tp"]
+    assert len(tp["per_rank_ms_per_token"]) == 2 and tp["allreduces_per_token"] == 2 * 2 and tp["p2p_form"] in ("fence-free", "fenced")
+
+
 def test_p2p_setup_failure_is_refused_not_hung():
     """Corrupted IPC handles: the peer-to-peer path must come up disabled on every rank without hanging; with no RCCL communicator
     to fall back on (ranks sharing one GPU) init_tp raises."""

@@ -94,7 +94,7 @@ def test_two_half_schedule_matches_serial(tp, S, comm):
     V = 2048
     eng = LlamaEngine(cfg, V, _ShardView(real, tp))
     eng.load_weights(synth.iter_synth(synth.llama_param_shapes(cfg, V), seed=3, device=dev, dtype=BF16))
-    assert eng.tp_overlap_rows == 1024                    # the default under tensor parallelism
+    assert eng.tp_overlap_rows == 0                       # opt-in since round 6 (EMU_TP_OVERLAP / set_tp_overlap)
     g = torch.Generator().manual_seed(7)
     x = (torch.randn(1, S, cfg.hidden_size, generator=g) * 0.1).to(BF16).to(dev)
     mask = torch.ones(1, S, dtype=torch.long, device=dev)          # on the device: the capture below must not copy from the host

@@ -676,3 +676,35 @@ def test_effective_min_len_per_release():
         pytest.skip("transformers internals not importable")
     if "min_length - inputs_tensor.shape[1]" not in src.replace("generation_config.", ""):
         pytest.skip("the installed transformers words the correction differently")
+
+
+def test_default_beam_mode_is_announced_and_its_cur0_eos_case_is_refused():
+    """The DEFAULT decoding mode (emu.py:163-172: 5 beams, length_penalty -1) runs under hf_semantics='4.31', a restatement with no
+    library vector: EmuModel.generate_ids says so once per process, and refuses the one case the restatement does not define -- an
+    EOS hypothesis that ends at cur == 0 (4.31 scores it over 0 ** length_penalty; reachable only with min_len < 1) -- before any
+    device work.  '5.x' (pinned by tests/golden/generate_beam_eos_tiny.npz) takes min_len 0."""
+    import types
+    import warnings
+    from emu_amd.emu import EmuModel
+    calls = []
+
+    class _LM:
+        def beam_search_generate(self, x, mask, nb, max_new, min_len, lp, **kw):
+            calls.append((nb, min_len, kw["hf_semantics"]))
+            return torch.zeros(x.shape[0], 1, dtype=torch.long)
+
+    me = types.SimpleNamespace(hf_semantics="4.31", n_query=4, v_query=4, use_graph=False, decoder=types.SimpleNamespace(lm=_LM()),
+                               _prompt_embeds=lambda ids, image, nq, tok, embeds=None: torch.zeros(ids.numel(), 8))
+    ids, mask = torch.ones(1, 5, dtype=torch.long), torch.ones(1, 5, dtype=torch.long)
+    with pytest.raises(ValueError, match="min_len >= 1"):
+        EmuModel.generate_ids(me, ids, mask, num_beams=5, min_len=0)
+    assert not calls                                                    # refused before the prompt was even embedded
+    EmuModel._warned_431 = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        EmuModel.generate_ids(me, ids, mask, num_beams=5)
+        EmuModel.generate_ids(me, ids, mask, num_beams=5)
+    assert sum("RESTATEMENT" in str(x.message) for x in w) == 1          # once per process
+    assert calls == [(5, 1, "4.31")] * 2
+    EmuModel.generate_ids(me, ids, mask, num_beams=5, min_len=0, hf_semantics="5.x")
+    assert calls[-1] == (5, 0, "5.x")
