@@ -112,6 +112,7 @@ _PROTOS = {
     "emu_llama_set_head_fp8": (i32, [vp, vp, vp]),
     "emu_llama_use_fp8": (i32, [vp, i32]),
     "emu_llama_set_head": (i32, [vp, vp, vp, vp, vp, vp]),
+    "emu_llama_set_head_shard": (i32, [vp, i32, i32]),
     "emu_llama_set_kv": (i32, [vp, vp, vp, i32, i32]),
     "emu_llama_set_kv_share": (i32, [vp, i32, i32]),
     "emu_beam_step_bf16": (i32, [vp, lng, lng, i32, i32, i32, i32, i32, vp, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

@@ -638,14 +638,16 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = lane / LPK, dl = lane % LPK, d0 = dl * 8;
-    const int slot = a.slot[b], ctx = slot + 1;
+    // slot, position and left-padding bound are requested together: the early exit below needs the slot only, but a load behind the
+    // branch would be a second dependent trip in front of the cos / sin rows (round 6: three trips -> two)
+    const int slot = a.slot[b], pos = a.pos[b];
+    const int kstart = a.kstart ? a.kstart[b] : 0;
+    const int ctx = slot + 1;
     const int k0 = split * DF_CHUNK;
     if (k0 >= ctx) return;                             // split beyond the live context: no work, not counted
-    const int kstart = a.kstart ? a.kstart[b] : 0;
     // beams of one prompt: slots [0, share_len) live in the group's first row b0 only
     const int b0 = SHARE ? b - b % a.share_nb : b;
     const int nshare = SHARE ? a.share_len : 0;
-    const int pos = a.pos[b];
     const bf16_t* row = a.qkv + (size_t)b * 3 * a.H * D;
     const bf16_t* qh = row + (size_t)h * D;
     const bf16_t* kh = qh + (size_t)a.H * D;
@@ -801,12 +803,42 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(const DecodeFusedArgs
     }
 }
 
-template <int D>
+// NS > 0 (round 6): the launch is pure latency -- slot -> live count -> maxima -> states were three dependent trips -- so every split
+// state the launch was SIZED for (nsplit <= NS) is requested up front together with the slot, and the live count only selects among
+// values that are already on their way (a dead split's words are stale or never written: loaded, never used).  Same arithmetic in the
+// same order as the loop form (NS = 0: more splits than the unrolled forms hold), bit-identical.
+template <int D, int NS>
 __global__ void decode_fused_combine_kernel(const float* ws, const int32_t* slot, bf16_t* o, long o_sb, long o_sh, int H,
                                             int nsplit) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const int nlive = (slot[b] + DF_CHUNK) / DF_CHUNK;             // ceil((slot + 1) / DF_CHUNK): dead splits wrote nothing
     const float* w = ws + ((size_t)b * H + h) * nsplit * (D + 2);
+    if constexpr (NS > 0) {
+        const int sl = slot[b];
+        float mv[NS], nv[NS], lv[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sc = s < nsplit ? s : nsplit - 1;            // clamped, not predicated: one batch of loads, no branch
+            mv[s] = w[sc * (D + 2) + D];
+            nv[s] = w[sc * (D + 2) + d];
+            lv[s] = w[sc * (D + 2) + D + 1];
+        }
+        const int nlive = (sl + DF_CHUNK) / DF_CHUNK;
+        float m = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) m = s < nlive ? fmaxf(m, mv[s]) : m;
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < nlive) {
+                const float f = (mv[s] == -INFINITY) ? 0.f : __expf(mv[s] - m);
+                num = fmaf(f, nv[s], num);
+                den = fmaf(f, lv[s], den);
+            }
+        }
+        o[(size_t)b * o_sb + (size_t)h * o_sh + d] = f2bf(den > 0.f ? num / den : 0.f);
+        return;
+    }
+    const int nlive = (slot[b] + DF_CHUNK) / DF_CHUNK;             // ceil((slot + 1) / DF_CHUNK): dead splits wrote nothing
     float m = -INFINITY;
     for (int s = 0; s < nlive; ++s) m = fmaxf(m, w[s * (D + 2) + D]);
     float num = 0.f, den = 0.f;
@@ -818,6 +850,16 @@ __global__ void decode_fused_combine_kernel(const float* ws, const int32_t* slot
         den = fmaf(f, w[s * (D + 2) + D + 1], den);
     }
     o[(size_t)b * o_sb + (size_t)h * o_sh + d] = f2bf(den > 0.f ? num / den : 0.f);
+}
+template <int D>
+void launch_combine(const DecodeFusedArgs& a, int ns, hipStream_t s) {
+    const dim3 grid(a.H, a.B), block(D);
+    if (ns <= 8 && !(emu_gemm_tune_get() & (1 << 20)))
+        hipLaunchKernelGGL((decode_fused_combine_kernel<D, 8>), grid, block, 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+    else if (ns <= 16 && !(emu_gemm_tune_get() & (1 << 20)))
+        hipLaunchKernelGGL((decode_fused_combine_kernel<D, 16>), grid, block, 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+    else
+        hipLaunchKernelGGL((decode_fused_combine_kernel<D, 0>), grid, block, 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
 }
 }  // namespace
 
@@ -847,17 +889,17 @@ int launch_decode_fused(const DecodeFusedArgs& a, hipStream_t s) {
             else EMU_SHARE_CASE(64, 8);
         } else return -22;
 #undef EMU_SHARE_CASE
-        if (a.D == 128) hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
-        else hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        if (a.D == 128) launch_combine<128>(a, ns, s);
+        else launch_combine<64>(a, ns, s);
         EMU_CHECK_LAUNCH();
         return 0;
     }
     if (a.D == 128) {
         hipLaunchKernelGGL((decode_fused_kernel<128, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        if (!a.arrive && !a.skip_combine) hipLaunchKernelGGL(decode_fused_combine_kernel<128>, dim3(a.H, a.B), dim3(128), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        if (!a.arrive && !a.skip_combine) launch_combine<128>(a, ns, s);
     } else if (a.D == 64) {
         hipLaunchKernelGGL((decode_fused_kernel<64, 0>), dim3(ns, a.H, a.B), dim3(256), 0, s, a, ns);
-        if (!a.arrive) hipLaunchKernelGGL(decode_fused_combine_kernel<64>, dim3(a.H, a.B), dim3(64), 0, s, a.ws, a.slot, a.o, a.o_sb, a.o_sh, a.H, ns);
+        if (!a.arrive) launch_combine<64>(a, ns, s);
     } else return -22;
     EMU_CHECK_LAUNCH();
     return 0;

@@ -409,6 +409,9 @@ struct emu_llama {
     bool fp8_decode = false;
     bool fp8_prefill = false;      // emu_llama_use_fp8(m, 2): W8A8 GEMMs for prefill rows as well
     const bf16_t *final_norm = nullptr, *lm_head = nullptr, *embed = nullptr, *cos = nullptr, *sin = nullptr;
+    // tensor parallelism: lm_head holds rows [head_row0, head_row0 + head_rows) of the vocabulary only (emu_llama_set_head_shard);
+    // head_rows < 0: the whole matrix
+    int head_row0 = 0, head_rows = -1;
     bf16_t *kcache = nullptr, *vcache = nullptr;
     int kv_batch = 0, s_max = 0;
     int kv_share_nb = 0, kv_share_len = 0;       // emu_llama_set_kv_share: beams of a prompt share its cache slots
@@ -762,6 +765,13 @@ int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head
     m->final_norm = B(final_norm); m->lm_head = B(lm_head); m->embed = B(embed); m->cos = B(rope_cos); m->sin = B(rope_sin);
     return 0;
 }
+int emu_llama_set_head_shard(emu_llama* m, int row0, int rows) {
+    if (!m) return -22;
+    if (rows < 0) { m->head_row0 = 0; m->head_rows = -1; return 0; }
+    if (row0 < 0 || rows < 1 || row0 + rows > m->cfg.vocab) return fail(m->ctx, -22, "emu_llama_set_head_shard: rows outside the vocabulary");
+    m->head_row0 = row0; m->head_rows = rows;
+    return 0;
+}
 int emu_llama_set_kv(emu_llama* m, void* kcache, void* vcache, int batch, int s_max) {
     if (!m) return -22;
     if (!kcache && !vcache) {                    // detach: the caller freed the caches; every later forward fails with -22 until new ones are set
@@ -1060,6 +1070,32 @@ int emu_llama_logits(emu_llama* m, const void* hidden, int ldh, int M, void* log
                      size_t ws_bytes, emu_stream_t s) {
     if (!m || !m->lm_head || !m->final_norm) return -22;
     const emu_llama_cfg& c = m->cfg;
+    if (m->head_rows >= 0) {
+        // vocabulary-sharded head (tensor parallelism): this rank streams its rows of lm_head only (4035 of 32 274 at TP = 8:
+        // 54 MB instead of 430 MB per token) into its own columns of the caller's [M, vocab] rows, every other column zero, and one
+        // all-reduce makes the rows whole on every rank -- each logit is computed by exactly one rank and summed with zeros, so the
+        // result is bit-identical to the replicated head and every consumer (arg-max, beam scorer, samplers) stays as it is.
+        emu_ctx* cx = m->ctx;
+        bf16_t* lg = B(logits);
+        const int N = m->head_rows, n0 = m->head_row0;
+        if (hipMemsetAsync(lg, 0, ((size_t)(M - 1) * ld + c.vocab) * sizeof(bf16_t), S(s)) != hipSuccess)
+            return fail(cx, -5, "emu_llama_logits: hipMemsetAsync");
+        if (m->fp8_decode && M <= 2 && m->lm_head8) {             // the e4m3 copy covers the same rows (quantised from the shard)
+            TRY(cx, linear(B(hidden), B(m->lm_head8), nullptr, nullptr, m->final_norm, lg + n0, M, N, c.hidden, ldh, c.hidden, 0, ld,
+                           c.rms_eps, EPI_NONE, S(s), m->lm_scale8));
+        } else if (M == 1 || (M <= 8 && ws_bytes < (size_t)M * c.hidden * 2)) {
+            TRY(cx, linear(B(hidden), m->lm_head, nullptr, nullptr, m->final_norm, lg + n0, M, N, c.hidden, ldh, c.hidden, 0, ld,
+                           c.rms_eps, EPI_NONE, S(s)));
+        } else {
+            if (ws_bytes < (size_t)M * c.hidden * 2) return fail(cx, -12, "emu_llama_logits: workspace too small");
+            TRY(cx, launch_rmsnorm(B(hidden), m->final_norm, B(workspace), M, c.hidden, ldh, c.hidden, c.rms_eps, S(s)));
+            TRY(cx, linear(B(workspace), m->lm_head, nullptr, nullptr, nullptr, lg + n0, M, N, c.hidden, c.hidden, c.hidden, 0, ld, 0.f,
+                           EPI_NONE, S(s)));
+        }
+        if (ld == c.vocab) return emu_allreduce_bf16(cx, lg, (size_t)M * c.vocab, s);
+        for (int r = 0; r < M; ++r) TRY(cx, emu_allreduce_bf16(cx, lg + (size_t)r * ld, (size_t)c.vocab, s));
+        return 0;
+    }
     if (m->fp8_decode && M <= 2 && m->lm_head8)
         return linear(B(hidden), B(m->lm_head8), nullptr, nullptr, m->final_norm, B(logits), M, c.vocab, c.hidden, ldh,
                       c.hidden, 0, ld, c.rms_eps, EPI_NONE, S(s), m->lm_scale8);

@@ -49,13 +49,17 @@ __device__ __forceinline__ unsigned long long* flag_of(char* block, int slot, in
 __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned long long* seq_counter, bf16_t* x, int n) {
     __shared__ unsigned long long s_sh;
     const int tid = threadIdx.x, g = blockIdx.x;
+    const int e0 = g * P2P_PIECE + tid * 8;                                 // my 8 elements
+    const bool full = e0 + 8 <= n, part = e0 < n;
+    // my share of the partial vector is requested BEFORE the sequence counter makes its round trip through LDS (round 6: the two
+    // loads were two dependent trips of a launch that is nothing but dependent trips)
+    u32x4 mine = {0u, 0u, 0u, 0u};
+    if (full) mine = ld16(x + e0);
     if (tid == 0) { s_sh = seq_counter[g] + 1; seq_counter[g] = s_sh; }   // launches of one stream are ordered: no race
     __syncthreads();
     const unsigned long long s = s_sh;
     const int slot = (int)(s & 1);
-    const int e0 = g * P2P_PIECE + tid * 8;                                 // my 8 elements
     const size_t off = (size_t)slot * EMU_P2P_SLOT_BYTES + (size_t)e0 * 2;
-    const bool full = e0 + 8 <= n, part = e0 < n;
     // Two forms of the exchange, chosen per launch (P2pPeers::fenced):
     //  * fenced (the default of a fresh comm block): the HIP memory model's own release / acquire -- __threadfence_system() between
     //    the payload stores and the flag, and again between the last flag poll and the payload loads.  ~3.5 us each of a 6.8 us launch.
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
     // ---- 1. publish my piece
     if (part) {
         u32x4 v;
-        if (full) v = ld16(x + e0);
+        if (full) v = mine;
         else {
             bf16_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int j = 0; e0 + j < n; ++j) t[j] = x[e0 + j];

@@ -54,6 +54,12 @@ class ShardPlan:
         f0 = self.tp_rank * self.ffn_local
         return f0, f0 + self.ffn_local
 
+    def vocab_range(self, vocab: int):
+        """Rows [r0, r1) of lm_head this rank streams: ceil(vocab / tp) rows per rank (32 274 -> 4035 at TP = 8, the last rank 4029)."""
+        per = -(-vocab // self.tp_size)
+        r0 = min(self.tp_rank * per, vocab)
+        return r0, min(r0 + per, vocab)
+
     # ---- packing ------------------------------------------------------------------------------------
     def _head_rows(self, w: torch.Tensor) -> torch.Tensor:
         """Rows of a [H*D, hidden] projection that belong to this rank's heads, zero rows for padding."""

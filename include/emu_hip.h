@@ -260,6 +260,11 @@ int emu_llama_set_layer_fp8(emu_llama* m, int layer, const void* wqkv8, const fl
                             const float* sdown);
 int emu_llama_set_head_fp8(emu_llama* m, const void* lm_head8, const float* lm_scale);
 int emu_llama_use_fp8(emu_llama* m, int enable);
+/* Vocabulary-sharded lm_head under tensor parallelism (the reference's lm_head is lm.lm_head of LlamaForCausalLM reached
+ * from Emu2/emu/emu.py:213-229): the lm_head pointer of emu_llama_set_head holds rows [row0, row0 + rows) of the vocabulary only;
+ * emu_llama_logits fills this rank's columns of the caller's [M, vocab] rows, zeroes the others and all-reduces the rows, so every
+ * rank ends with the full, bit-identical logits.  rows < 0 = whole matrix (the default). */
+int emu_llama_set_head_shard(emu_llama* m, int row0, int rows);
 int emu_llama_set_head(emu_llama* m, const void* final_norm, const void* lm_head, const void* embed,
                        const void* rope_cos, const void* rope_sin);
 /* kcache == vcache == NULL detaches the caches (the caller freed them): emu_llama_forward answers -22 until new ones are set. */

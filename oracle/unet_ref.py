@@ -288,13 +288,13 @@ def denoise(latents: Tensor, prompt_embeds: Tensor, W: Weights, steps: int = 50,
     multiplied by init_noise_sigma (:126-127)."""
     sch = EulerSchedule().set_timesteps(steps)
     time_ids = torch.tensor(list(original_size) + list(crop) + [height, width], dtype=torch.long)
-    time_ids = torch.cat([time_ids, time_ids], dim=0)                          # 1-D, length 12 (:108-110)
+    time_ids = torch.cat([time_ids, time_ids], dim=0).to(latents.device)       # 1-D, length 12 (:108-110)
     text_embeds = prompt_embeds.mean(dim=1)                                    # (:113)
     x = latents
     hist = []
     for i, t in enumerate(sch.timesteps):
         inp = sch.scale_model_input(torch.cat([x] * 2), i)
-        eps = unet_forward(inp, t, prompt_embeds, text_embeds, time_ids, W, cfg)
+        eps = unet_forward(inp, t.to(latents.device), prompt_embeds, text_embeds, time_ids, W, cfg)
         e_c, e_u = eps.chunk(2)
         eps = e_u + guidance * (e_c - e_u)
         x = sch.step(eps, i, x)

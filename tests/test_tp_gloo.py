@@ -159,3 +159,40 @@ def test_vit_image_parallel_over_two_ranks():
     for rank, r in res:
         assert all(ok for ok, _ in r.values()), (rank, r)
         assert {n: k for n, (_, k) in r.items()} == {1: 1, 2: 1, 3: 2, 4: 2, 5: 3}, r       # images encoded per rank
+
+
+def _vocab_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_amd.tp import ShardPlan
+        V, H, M = 37, 48, 3                                      # 37 rows over 2 ranks: 19 + 18 (the last rank is short, as 32 274 / 8 is)
+        g = torch.Generator().manual_seed(21)
+        head = (torch.randn(V, H, generator=g) * 0.3).to(torch.bfloat16)
+        x = torch.randn(M, H, generator=g).to(torch.bfloat16)
+        plan = ShardPlan(80, 5, 16, 128, world, rank)
+        r0, r1 = plan.vocab_range(V)
+        # what emu_llama_logits does with a sharded head: own columns of zeroed [M, V] rows, then one sum all-reduce
+        rows = torch.zeros(M, V, dtype=torch.bfloat16)
+        rows[:, r0:r1] = (x.float() @ head[r0:r1].float().t()).to(torch.bfloat16)
+        full32 = rows.float()
+        dist.all_reduce(full32)                                  # gloo has no bf16 sum; every column has ONE non-zero addend: exact
+        want = (x.float() @ head.float().t()).to(torch.bfloat16)
+        q.put((rank, (r0, r1), bool(torch.equal(full32.to(torch.bfloat16), want)), int(full32.argmax(-1)[0]), int(want.float().argmax(-1)[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_gloo_vocab_sharded_head_is_bit_identical():
+    """SURVEY 8e's vocabulary-sharded lm_head (ShardPlan.vocab_range + the zero-fill / all-reduce of emu_llama_logits) as two real
+    processes: every logit is computed by exactly one rank and summed with zeros, so the rows come out bit-identical to the
+    replicated head on every rank -- arg-max, beam scorer and samplers stay as they are."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vocab_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(60) for p in procs]
+    assert [r[1] for r in res] == [(0, 19), (19, 37)]
+    assert all(r[2] and r[3] == r[4] for r in res), res

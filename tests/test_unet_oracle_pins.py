@@ -163,6 +163,38 @@ def test_transformer_2d_twin_matches_and_keys_load_strict():
         assert close(got, want), float((got - want).abs().max())
 
 
+def test_twins_at_the_true_width_one_block_of_each_kind():
+    """The same twins at the reference's TRUE configuration (unet/config.json: 1280 channels, 20 heads x 64, cross-attention dim
+    1792, GEGLU 1280 -> 10240, ten BasicTransformerBlocks per Transformer2DModel at the 32 x 32 level; 640 channels, 10 heads, depth 2
+    at 64 x 64): one ResnetBlock2D of each shape class (plain, channel-changing with the 1x1 shortcut, the widest skip-concat input)
+    and one Transformer2DModel of each level, on a small spatial extent (the arithmetic per token does not depend on it).  The oracle's
+    weight dict must load strict=True under the diffusers key names of the TRUE shapes and give the twin's outputs."""
+    cfg = U.UNetCfg()
+    shapes = U.unet_param_shapes(cfg)
+    for p, cin, cout in (("mid_block.resnets.0.", 1280, 1280), ("down_blocks.2.resnets.0.", 640, 1280), ("up_blocks.0.resnets.0.", 2560, 1280),
+                         ("up_blocks.2.resnets.2.", 640, 320)):
+        W = _weights(shapes, p, seed=31)
+        W = {k: (v * (1.0 / max(1, v[0].numel()) ** 0.5 / 0.2) if v.dim() > 1 else v) for k, v in W.items()}   # fan-in scale
+        twin = ResnetBlock2D(cin, cout, cfg.temb_dim)
+        twin.load_state_dict(_sub(W, p), strict=True)
+        x, temb = torch.randn(2, cin, 3, 4), torch.randn(2, cfg.temb_dim)
+        with torch.no_grad():
+            want = twin(x, temb)
+        got = U.resnet_block(x, temb, W, p, cfg)
+        assert close(got, want, 1e-4), (p, float((got - want).abs().max()))
+    for p, c, heads, depth in (("down_blocks.1.attentions.1.", 640, 10, 2), ("mid_block.attentions.0.", 1280, 20, 10)):
+        W = _weights(shapes, p, seed=32)
+        W = {k: (v * (1.0 / max(1, v[0].numel()) ** 0.5 / 0.2) if v.dim() > 1 else v) for k, v in W.items()}   # fan-in scale: O(1) through 10 blocks
+        twin = Transformer2DModel(c, cfg.cross_dim, heads, depth)
+        twin.load_state_dict(_sub(W, p), strict=True)
+        x, ctx = torch.randn(2, c, 3, 4), torch.randn(2, 64, cfg.cross_dim)
+        with torch.no_grad():
+            want = twin(x, ctx)
+        got = U.transformer_2d(x, ctx, W, p, depth, heads, cfg)
+        assert got.shape == want.shape == (2, c, 3, 4)
+        assert close(got, want, 2e-4), (p, float((got - want).abs().max()))
+
+
 def test_attention_twin_against_nn_multihead_attention():
     """The restated attention also equals torch.nn.MultiheadAttention (a third implementation) on shared weights."""
     c, heads = 128, 2
