@@ -160,7 +160,7 @@ def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
         t_head = (time.perf_counter() - t0) / m
     tok_s = 1.0 / (60 * t_layer + t_head)
     dn = "fp32" if dtype == torch.float32 else "bf16"
-    port = {"value": tok_s, "unit": "tokens/s", "cores": th, "kind": "port",
+    port = {"value": tok_s, "unit": "tokens/s", "cores": th, "kind": "port", "layer_ms": t_layer * 1e3,
             "sample": f"1 true-shape LLaMA-33B decoder layer x{n} + lm_head x{m} ({dn}, ctx {ctx_len}, batch 1) on {th} of "
                       f"{ncpu} host threads (fastest of a dtype/thread calibration); tokens/s = 1/(60*{t_layer * 1e3:.1f} ms "
                       f"+ {t_head * 1e3:.1f} ms)"}
@@ -169,7 +169,7 @@ def cpu_baseline(seconds: float, ctx_len: int, vocab: int):
     try:
         t_ref, n_ref = _reference_layer_time(W, dtype, cfg, ctx_len, k0, v0, x0, seconds * 0.5)
         ref_tok_s = 1.0 / (60 * t_ref + t_head)
-        return {"value": ref_tok_s, "unit": "tokens/s", "cores": th, "kind": "reference",
+        return {"value": ref_tok_s, "unit": "tokens/s", "cores": th, "kind": "reference", "layer_ms": t_ref * 1e3,
                 "sample": f"transformers {__import__('transformers').__version__} LlamaDecoderLayer (eager attention, DynamicCache with {ctx_len} "
                           f"cached positions) at the LLaMA-33B shape x{n_ref} + lm_head x{m} ({dn}, batch 1) on {th} of {ncpu} host threads; "
                           f"tokens/s = 1/(60*{t_ref * 1e3:.1f} ms + {t_head * 1e3:.1f} ms)",
@@ -302,11 +302,47 @@ def cpu_baseline_legs(seconds: float, threads: int, S: int):
         else:
             t2 = 2 * t1
             how = f"one forward of the cond half (batch 1) = {t1:.1f} s, doubled for the CFG pair"
+        del W
+        # ---- VAE decode (restated AutoencoderKL decoder, oracle/vae_ref.py), the whole 1024 x 1024 image once
+        try:
+            from oracle import vae_ref as V
+            vc_ = V.VaeCfg()
+            Wv = _filled(V.vae_decoder_param_shapes(vc_))
+            z = torch.randn(1, 4, 128, 128, generator=g)
+            t0 = time.perf_counter()
+            V.decode_latents(z, Wv, vc_)
+            tv = time.perf_counter() - t0
+            out["vae"] = {"value": tv * 1e3, "unit": "ms", "cores": threads, "kind": "port", "higher_is_better": False,
+                          "sample": f"restated AutoencoderKL.decode (oracle/vae_ref.decode_latents: diffusers is not installable here), latents "
+                                    f"[1, 4, 128, 128] -> 1024 x 1024, ONE call (cold), fp32 on {threads} of {ncpu} host threads"}
+            del Wv
+        except Exception as e:
+            out["vae"] = {"value": None, "unit": "ms", "cores": threads, "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         out["denoise"] = {"value": 1.0 / t2, "unit": "steps/s", "cores": threads, "kind": "port",
                           "sample": f"restated SDXL-style UNet (2.53 B parameters, oracle/unet_ref.unet_forward: diffusers 0.24 is not installable "
                                     f"here, so the port is the reference arithmetic), 128 x 128 latents, 64 context tokens, fp32 on {threads} of "
                                     f"{ncpu} host threads: {how}; guidance + Euler update are negligible beside it"}
     return out
+
+
+def vae_decode_flops(h: int = 128, chans=(128, 256, 512, 512), layers: int = 2, latent: int = 4) -> float:
+    """Algorithmic FLOPs of AutoencoderKL.decode for an h x h latent (vae/config.json): 3x3 convs 2 * pixels * Cout * 9 * Cin, the mid
+    block's one-head attention over h^2 tokens (4 projections + QK^T + PV), 1x1 shortcuts; norms / activations excluded.
+    10.47 TFLOP at h = 128 (a 1024 x 1024 image)."""
+    conv = lambda px, ci, co, k=9: 2.0 * px * co * k * ci
+    top = chans[-1]
+    px = h * h
+    f = conv(px, latent, top) + 2 * 2 * conv(px, top, top) + 4 * 2.0 * px * top * top + 4.0 * px * px * top
+    rev, cur = list(reversed(chans)), chans[-1]
+    for i, c in enumerate(rev):
+        for j in range(layers + 1):
+            cin = cur if j == 0 else c
+            f += conv(px, cin, c) + conv(px, c, c) + (conv(px, cin, c, 1) if cin != c else 0.0)
+        cur = c
+        if i < len(rev) - 1:
+            px *= 4
+            f += conv(px, c, c)
+    return f + conv(px, chans[0], 3)
 
 
 VIT_FLOPS_PER_IMAGE = 9.39e12       # BASELINE.md section 2 / SURVEY 8d: EVA-CLIP 64 blocks x 1025 tokens x 1792
@@ -491,14 +527,24 @@ def config_legs(m, lm, ctx, dev, vcfg, lcfg, img, unet_eng):
             out["generate_image"] = {"config": "emu.py:92-153, KV-cached: 21-token prefill + 63 steps (project_down -> project_up "
                                                "-> 60 layers), 64 visual embeddings out", "ms": t_gi * 1e3,
                                      "ms_per_step": t_gi * 1e3 / 64, "weight_stream_GBps": 63 * wb / t_gi / 1e9,
-                                     "frac_of_hbm_peak": 63 * wb / t_gi / HBM_PEAK, "finite": bool(torch.isfinite(emb.float()).all())}
+                                     "frac_of_hbm_peak": 63 * wb / t_gi / HBM_PEAK, "finite": bool(torch.isfinite(emb.float()).all()),
+                                     "weight_bytes_per_step": wb,
+                                     "roofline": {"bound": "hbm", "achieved": 63 * wb / t_gi / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                                  "frac": 63 * wb / t_gi / HBM_PEAK, "traffic": None,
+                                                  "note": "63 cached steps x the decoder's weight bytes over the WHOLE call (the 21-token "
+                                                          "prefill and the 64 project_down / project_up pairs included in the time)"}}
             # ---- VAE decode + any-to-image end to end
             vcfg_ = VaeCfg()
             vae = VaeDecoder(vcfg_, ctx)
             vae.load_state_dict(synth.synth_state_dict(vae_decoder_param_shapes(vcfg_), seed=1), strict=True)
             z = torch.randn(1, 4, 128, 128, device=dev).to(torch.bfloat16)
             t_vae, _ = timed(lambda: vae.decode_latents(z))
-            out["vae_decode"] = {"config": "AutoencoderKL.decode, latents [1,4,128,128] -> 1024x1024", "ms": t_vae * 1e3}
+            vf = vae_decode_flops()
+            out["vae_decode"] = {"config": "AutoencoderKL.decode, latents [1,4,128,128] -> 1024x1024", "ms": t_vae * 1e3,
+                                 "roofline": {"bound": "mfma", "achieved": vf / t_vae / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                                              "frac": vf / t_vae / MFMA_BF16_PEAK, "flops": vf, "traffic": None,
+                                              "note": "whole decode against the bf16 MFMA peak; the 1024^2 x 128-channel level is HBM-heavy "
+                                                      "(0.5 GB of activations per conv) and GroupNorm takes three passes"}}
             if unet_eng is not None:
                 neg = torch.randint(3, 32000, (1, 1), generator=g)
 
@@ -1031,6 +1077,18 @@ def main():
                     res["denoise"]["cpu_baseline"] = cl["denoise"]
                 res["extra"]["vit_cpu_baseline"] = cl["vit"]
                 res["extra"]["prefill_cpu_baseline"] = cl["prefill"]
+                if legs is not None and "vae_decode" in legs:
+                    legs["vae_decode"]["cpu_baseline"] = cl["vae"]
+                lay = res["cpu_baseline"].get("layer_ms")
+                if legs is not None and "generate_image" in legs and lay:
+                    # the KV-cached form on the host: 63 single-row steps of 60 layers (the decode baseline's measured layer; its
+                    # 770-position cache over-prices the 21..84-position attention by < 1 %) + the 21-row prefill at >= one step's cost
+                    legs["generate_image"]["cpu_baseline"] = {
+                        "value": 64 * 60 * lay, "unit": "ms", "cores": th, "kind": res["cpu_baseline"].get("kind", "port"),
+                        "higher_is_better": False,
+                        "sample": f"64 x 60 x the decode baseline's measured decoder layer ({lay:.1f} ms) = the KV-cached form of emu.py:92-153 "
+                                  "(63 cached steps + a 21-row prefill counted as one step); the reference's own uncached algorithm "
+                                  "(64 forwards over a growing sequence, 215.9 TFLOP) would cost ~50 x that"}
             except Exception as e:
                 res["extra"]["legs_cpu_baseline_note"] = f"failed: {type(e).__name__}: {e}"
         print(json.dumps(res), flush=True)

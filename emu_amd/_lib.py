@@ -46,6 +46,12 @@ class LinearFxC(C.Structure):
                 ("cross_scale", f32)]
 
 
+class ChainOpC(C.Structure):
+    """emu_chain_op (include/emu_hip.h): one projection of an emu_gemv_chain_bf16 launch."""
+    _fields_ = [("W", vp), ("N", i32), ("K", i32), ("gain", vp), ("eps", f32), ("epi", i32), ("res", vp), ("x", vp),
+                ("x_from_prev", i32), ("out", vp)]
+
+
 class ProfRowC(C.Structure):
     """emu_prof_row (include/emu_hip.h)."""
     _fields_ = [("klass", C.c_char * 16), ("M", i32), ("N", i32), ("K", i32), ("tag", i32), ("launches", i32),
@@ -92,6 +98,8 @@ _PROTOS = {
     "emu_layernorm_bf16": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "emu_layernorm_q8_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "emu_prefetch": (i32, [vp, sz, i32, vp]),
+    "emu_gemv_chain_granule_bytes": (sz, [C.POINTER(ChainOpC), i32]),
+    "emu_gemv_chain_bf16": (i32, [vp, C.POINTER(ChainOpC), i32, vp, sz, vp, vp]),
     "emu_softmax_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, f32, vp]),
     "emu_embed_gather_bf16": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "emu_scatter_rows_bf16": (i32, [vp, vp, vp, i32, i32, vp]),

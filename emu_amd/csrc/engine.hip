@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -341,6 +342,49 @@ int emu_layernorm_q8_bf16(const void* x, const void* w, const void* b, const voi
     if (!x || !w || !b || !q || !scale) return -22;
     return launch_layernorm_q8(B(x), B(w), B(b), B(res), reinterpret_cast<bf16_t*>(y), reinterpret_cast<uint8_t*>(q), scale, rows, cols,
                                eps, S(s));
+}
+static int chain_out_len(const emu_chain_op& o) { return o.epi == EPI_SWIGLU ? o.N / 2 : o.N; }
+size_t emu_gemv_chain_granule_bytes(const emu_chain_op* ops, int nops) {
+    size_t b = 0;
+    for (int i = 0; ops && i + 1 < nops; ++i)
+        if (ops[i + 1].x_from_prev) b += align_up((size_t)chain_out_len(ops[i]) * 4);
+    return b;
+}
+int emu_gemv_chain_bf16(emu_ctx* ctx, const emu_chain_op* ops, int nops, void* granules, size_t granule_bytes, unsigned int* err,
+                        emu_stream_t s_) {
+    if (!ctx || !ops || nops < 1 || nops > ENG_MAX_OPS || !err) return -22;
+    const size_t need = emu_gemv_chain_granule_bytes(ops, nops);
+    if (need > granule_bytes || (need && !granules)) return fail(ctx, -12, "emu_gemv_chain_bf16: granule buffer too small");
+    hipStream_t s = S(s_);
+    EngArgs a{};
+    a.nops = nops; a.err = err; a.limit_ticks = 200000000LL;           // 2 s
+    if (const char* e = getenv("EMU_ENGINE_TIMEOUT_MS")) { const long ms = atol(e); if (ms > 0) a.limit_ticks = ms * 100000LL; }   // tools
+    if (const char* e = getenv("EMU_ENGINE_LOADERS")) a.nload = atoi(e);
+    if (const char* e = getenv("EMU_ENGINE_DBG")) a.dbg = atoi(e);
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -5;
+    a.ncu = ncu;
+    char* gp = reinterpret_cast<char*>(granules);
+    size_t off = 0;
+    for (int i = 0; i < nops; ++i) {
+        const emu_chain_op& c = ops[i];
+        EngOp& o = a.op[i];
+        o.W = B(c.W); o.N = c.N; o.K = c.K; o.gain = B(c.gain); o.eps = c.eps; o.epi = c.epi; o.res = B(c.res);
+        o.vw = emu_gemv_partition(c.N, c.K, c.gain != nullptr, c.epi);
+        o.x_src = c.x_from_prev ? 1 : 0;
+        o.xg = B(c.x);
+        if (c.x_from_prev) {
+            if (i == 0 || chain_out_len(ops[i - 1]) != c.K) return fail(ctx, -22, "emu_gemv_chain_bf16: op input is not the previous op's output");
+            o.xgran = a.op[i - 1].ogran;
+        }
+        const bool to_next = i + 1 < nops && ops[i + 1].x_from_prev;
+        o.out_dst = to_next ? 1 : 0;
+        o.out = B(c.out);
+        if (to_next) { o.ogran = reinterpret_cast<uint32_t*>(gp + off); off += align_up((size_t)chain_out_len(c) * 4); }
+    }
+    if (need && hipMemsetAsync(granules, 0, need, s) != hipSuccess) return fail(ctx, -5, "emu_gemv_chain_bf16: hipMemsetAsync");
+    const int st = launch_decode_engine(a, s);
+    return st == 0 || st == -95 ? st : fail(ctx, st, "emu_gemv_chain_bf16");
 }
 int emu_prefetch(const void* ptr, size_t bytes, int workgroups, emu_stream_t s) { return launch_prefetch(ptr, bytes, workgroups, S(s)); }
 int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s) {

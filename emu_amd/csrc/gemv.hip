@@ -996,6 +996,13 @@ int emu_gemv_rows_per_block_multi(int N) {
     return R;
 }
 
+int emu_gemv_partition(int N, int K, bool norm, int epi) {
+    // try_launch_wave's conditions (M = 1, bf16): no fused norm, EPI_NONE / EPI_RESID, K <= 2560, N >= 1024
+    const int kitw = ((K >> 3) + 63) / 64;
+    if (!norm && (epi == EPI_NONE || epi == EPI_RESID) && kitw <= 5 && N >= 1024) return 1;
+    return 4;                                  // gemv_rt_kernel and gemv_kernel alike: thread t owns 16-byte columns t, t + 256, ...
+}
+
 int launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.M < 1 || a.M > 16 || (a.K & 7) || a.N < 1) return -22;
     if (a.epi == EPI_SWIGLU && (a.N & 1)) return -22;

@@ -331,6 +331,42 @@ int launch_decode_layers(DecodeLayersArgs a, hipStream_t s);
 // the comm blocks / sequence counters of an opened EmuP2p for DecodeLayersArgs::tp_* (false: peers not mapped)
 bool emu_p2p_view(EmuP2p* p, char** block8, unsigned long long** seq, int* n, int* rank, long long* limit_ticks);
 
+// ---- persistent weight-streaming engine for chains of one-row GEMVs (decode_engine.hip): one launch, one resident workgroup per CU
+// (loader wave + three consumer waves on an LDS ring), op outputs handed between CUs through 4-byte {tag, bf16} granules
+constexpr int ENG_MAX_OPS = 6;
+struct EngOp {
+    const bf16_t* W;                           // [N, K] row-major, K contiguous, K <= 6656
+    int N, K;
+    const bf16_t* gain;                        // RMSNorm gain [K] (fused prologue on the activation vector) or null
+    float eps;
+    int epi;                                   // EPI_NONE / EPI_RESID / EPI_SWIGLU (rows (2j, 2j + 1) = (gate_j, up_j))
+    const bf16_t* res;                         // [N] (EPI_RESID)
+    int vw;                                    // launch_gemv's column partition for this shape: 4 (block kernels) or 1 (wave kernel)
+    int x_src;                                 // 0: xg, a bf16 vector written BEFORE this launch; 1: xgran, granules of an earlier op of this launch
+    const bf16_t* xg;
+    const uint32_t* xgran;
+    int out_dst;                               // 0: out, plain bf16 (read by a LATER launch); 1: ogran, granules (zero at launch)
+    bf16_t* out;
+    uint32_t* ogran;
+    // set by launch_decode_engine: units (rows, or (gate, up) pairs) per CU = q (+ 1 for the first rem CUs), whole rows per 16 KiB fill,
+    // bytes / LDS-DMA instructions per fill, fills that go to one consumer together, fills per CU (q / q + 1 units)
+    int q, rem, rps, fill_bytes, ni, grp, nfills_lo, nfills_hi;
+};
+struct EngArgs {
+    EngOp op[ENG_MAX_OPS];
+    int nops;
+    unsigned* err;                             // give-up counter (device)
+    long long limit_ticks;                     // bound of every wait, 100 MHz ticks
+    int ncu;                                   // workgroups = CUs of the device (all must be resident)
+    int nload;                                 // loader waves per workgroup: 1 or 2 (0 = default)
+    int dbg;                                   // tools: bit 0 = consumers acknowledge fills without multiplying (loader ceiling)
+    int nslot, xbytes;                         // set by launch_decode_engine
+};
+int launch_decode_engine(EngArgs a, hipStream_t s);
+// which column partition launch_gemv's kernel uses for a one-row bf16 GEMV of this shape (the engine mirrors it bit for bit):
+// 1 = gemv_wave_kernel (one wave per row), 4 = the 256-thread block kernels
+int emu_gemv_partition(int N, int K, bool norm, int epi);
+
 // One beam-search step on the device (beam.hip): see emu_beam_step_bf16 in include/emu_hip.h
 struct BeamStepArgs {
     const bf16_t* logits;                      // row of (prompt b, beam j) = logits + b * ld_prompt + j * ld_beam

@@ -317,3 +317,37 @@ def prefetch(t: torch.Tensor, workgroups: int = 256, nbytes: Optional[int] = Non
         raise ValueError("prefetch needs a contiguous GPU tensor")
     n = t.numel() * t.element_size() if nbytes is None else int(nbytes)
     check(lib().emu_prefetch(_p(t), n, int(workgroups), stream(t)), "emu_prefetch")
+
+
+def gemv_chain(ctx_handle, specs, err: Optional[torch.Tensor] = None):
+    """A chain of one-row projections in ONE persistent launch (emu_gemv_chain_bf16; csrc/decode_engine.hip).  ``specs``: list of
+    dicts with keys w [N, K], x ([1, K] or None = the previous op's output), gain, eps, epi, res, out (None when the next op takes
+    the output).  Returns (outputs list with None for handed-over ones, err counter tensor).  Raises EmuHipError(-95) for shapes the
+    engine does not cover."""
+    import ctypes as C
+    from ._lib import ChainOpC
+    n = len(specs)
+    arr = (ChainOpC * n)()
+    keep, outs = [], []
+    dev = specs[0]["w"].device
+    for i, sp in enumerate(specs):
+        w = sp["w"]; _req(w, "w")
+        N, K = w.shape
+        epi = int(sp.get("epi", EPI_NONE))
+        x = sp.get("x")
+        nxt_takes = i + 1 < n and specs[i + 1].get("x") is None
+        out = None
+        if not nxt_takes:
+            out = sp.get("out")
+            if out is None:
+                out = torch.empty(1, N // 2 if epi == EPI_SWIGLU else N, device=dev, dtype=BF16)
+        outs.append(out)
+        gain, res = sp.get("gain"), sp.get("res")
+        arr[i] = ChainOpC(_p(w), N, K, _p(gain), float(sp.get("eps", 0.0)), epi, _p(res), _p(x), 0 if x is not None else 1, _p(out))
+        keep += [w, x, gain, res, out]
+    nb = lib().emu_gemv_chain_granule_bytes(arr, n)
+    gran = torch.empty(max(nb, 16), device=dev, dtype=torch.uint8)
+    if err is None:
+        err = torch.zeros(1, device=dev, dtype=torch.int32)
+    check(lib().emu_gemv_chain_bf16(ctx_handle, arr, n, gran.data_ptr(), gran.numel(), err.data_ptr(), stream(dev)), "emu_gemv_chain_bf16")
+    return outs, err, (gran, keep)

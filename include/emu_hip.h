@@ -189,6 +189,26 @@ int emu_layernorm_q8_bf16(const void* x, const void* w, const void* b, const voi
  * bf16 bias [rows, cols] (relative-position bias + causal mask), T5Attention of Emu1's CausalFormer
  * (Emu1/models/modeling_t5.py:629-666) */
 int emu_softmax_rows_bf16(void* x, const void* bias, int rows, int cols, int ld, int ld_bias, float scale, emu_stream_t s);
+/* A chain of one-row projections  y_i = epi_i(W_i . norm_i(x_i))  in ONE persistent launch (emu_amd/csrc/decode_engine.hip: a loader
+ * wave per CU streams every op's weights through an LDS ring ahead of the activations, op outputs cross the chip as 4-byte
+ * granules): the LlamaDecoderLayer linears of a decode step (transformers, reached from Emu2/emu/emu.py:213-229) between two
+ * all-reduces of a tensor-parallel shard.  x_i is either a bf16 vector written before the call (x_from_prev = 0) or the output of
+ * op i - 1 (x_from_prev = 1; that op's output then exists only as granules in `granules`, caller-owned device memory of
+ * emu_gemv_chain_granule_bytes(ops, nops) bytes, zeroed by this call).  Bit-identical to the same ops through emu_linear_bf16.
+ * K <= 6656, N >= 2 x CUs, at most 6 ops; -95 = shape not covered (use the launches); err: device counter of bounded waits that gave
+ * up (non-zero = invalid results).  Needs the device to itself (one resident workgroup per CU). */
+typedef struct {
+    const void* W; int N, K;
+    const void* gain; float eps;       /* fused RMSNorm on the input vector, or NULL */
+    int epi;                           /* EMU_EPI_NONE / EMU_EPI_RESID / EMU_EPI_SWIGLU */
+    const void* res;                   /* [N] for EMU_EPI_RESID */
+    const void* x;                     /* [K] input vector (x_from_prev = 0) */
+    int x_from_prev;
+    void* out;                         /* [N] (SWIGLU: N / 2) bf16, or NULL when the next op takes it (x_from_prev = 1 there) */
+} emu_chain_op;
+size_t emu_gemv_chain_granule_bytes(const emu_chain_op* ops, int nops);
+int emu_gemv_chain_bf16(emu_ctx* ctx, const emu_chain_op* ops, int nops, void* granules, size_t granule_bytes, unsigned int* err,
+                        emu_stream_t s);
 /* Touch [ptr, ptr + bytes) -- the weight matrix of a launch that FOLLOWS on the stream -- into the 256 MB infinity cache with
  * `workgroups` x 256 threads, one dword per 128-byte line, nothing waited for.  The stand-alone form of the successor prefetch the
  * one-row decode step carries inside its own launches (emu_llama_set_decode_prefetch): the reference's nn.Linear weights

@@ -169,7 +169,7 @@ def test_true_width_unet_at_the_bench_latent_128(true_unet):
     assert torch.equal(b.cpu(), c.cpu())
 
 
-LATENT_TOL_50_STEPS = 6e-2     # stated tolerance on image latents (north_star): rel. L2 of the final latents after the WHOLE loop
+LATENT_TOL_50_STEPS = 4e-2     # stated tolerance on image latents (north_star): rel. L2 of the final latents after the WHOLE loop (measured 0.0244; 0.0082 after 10 steps)
 
 
 def test_fifty_step_loop_latents_at_128_against_the_restated_loop(true_unet):
