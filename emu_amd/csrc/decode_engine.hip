@@ -37,7 +37,7 @@ constexpr int ENG_MAXJ = 13;                       // 16-byte column vectors per
 constexpr int ENG_FLAGS = 256;                     // bytes of LDS words behind the ring and the activation buffer
 constexpr int AUX_SC1 = 16;
 // LDS words (index into the flags block)
-constexpr int F_READY = 0, F_DONE = 16, F_XREADY = 32, F_CONSDONE = 33, F_GATHER = 34;
+constexpr int F_READY = 0, F_DONE = 16, F_XREADY = 32, F_CONSDONE = 33, F_GATHER = 34, F_XPARTS = 35;
 
 typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
 
@@ -95,10 +95,12 @@ struct Spin {
     }
 };
 
-// tools (EngArgs::dbg bit 1): per-CU timeline, 8 x u64 of wall_clock64 behind the give-up counter (err + 2 as u64)
+// tools (EngArgs::dbg bit 1): per-CU timeline, 32 x u64 of wall_clock64 behind the give-up counter (err + 2 as u64): 0 entry, 1 first /
+// 2 last fill issued, 3 loader done, 4 + op: activation vector ready, 10 + op: consumer 0 done with the op, 16 + op: the last consumer
+// done with the op (last writer), 22 + op: consumer 0's sweep of the op's input complete
 __device__ __forceinline__ void eng_trace(const EngArgs& a, int slot) {
     if ((a.dbg & 2) && (threadIdx.x & 63) == 0)
-        reinterpret_cast<unsigned long long*>(a.err)[1 + (size_t)blockIdx.x * 8 + slot] = (unsigned long long)wall_clock64();
+        reinterpret_cast<unsigned long long*>(a.err)[1 + (size_t)blockIdx.x * 32 + slot] = (unsigned long long)wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------------------- loader
@@ -172,7 +174,7 @@ __device__ __forceinline__ void loader_wave(const EngArgs& a, int wave, int nloa
             ++npend;
             // while this CU gathers an activation vector the stream is thinned to one fill in flight (MI355X_MICROARCH.md, gather-pass:
             // a sweep queued behind the CU's own refill burst takes 1.0-1.7 us per pass instead of 0.3-0.65)
-            const bool thin = (a.dbg & 4) ? false : lds_ld(flags_addr + F_GATHER * 4) == 2;
+            const bool thin = (a.dbg & 0x1000) ? true : ((a.dbg & 4) ? false : lds_ld(flags_addr + F_GATHER * 4) == 2);
             // fills in flight per loader: all loaders together must leave ring slots for landed fills (a full ring of requests whose
             // consumers wait for an older fill of ANOTHER loader is a deadlock: measured, bounded by the time-out)
             int lag = (a.dbg & 0x100) ? 4 : ((a.dbg & 0x200) ? 2 : ((a.dbg & 0x800) ? 1 : ENG_LAG));
@@ -191,69 +193,132 @@ __device__ __forceinline__ void loader_wave(const EngArgs& a, int wave, int nloa
 // row in flight at once); VW4 = the launch kernels' column partition (see the header).
 template <int JX, bool VW4>
 __device__ __forceinline__ void consume_op(const EngArgs& a, const EngOp& o, int oi, int c, int ncons, int& gbase, char* ring, char* xbuf,
-                                           lds_u32* fl, Spin& sp) {
+                                           char* xraw, uint32_t seq0, lds_u32* fl, Spin& sp) {
     const int lane = threadIdx.x & 63, cu = blockIdx.x, nslot = a.nslot;
     int row0, nrows, nfills;
     cu_rows(o, cu, row0, nrows, nfills);
     const int K = o.K, KV = K >> 3, rps = o.rps, grp = o.grp;
     u32x4* xb = reinterpret_cast<u32x4*>(xbuf);
-    // ---------------------------------------------------------------- activation vector -> LDS (consumer 0), then release
-    if (c == 0) {
-        while (fl[F_CONSDONE] < (uint32_t)(ncons * oi)) {               // the other consumers are done with the previous op's vector
-            if (sp.give_up(a)) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        u32x4 gv[JX];
-        if (o.gain) {
+    // ---------------------------------------------------------------- activation vector -> LDS, then release
+    // Vectors written before the launch: consumer 0 loads them.  Vectors of this launch (granules): EVERY consumer wave sweeps its
+    // share of the array (chunks of 256 granules, c, c + ncons, ...) as soon as it is done with the previous op -- one round trip per
+    // wave instead of four sequential 8 KiB passes of one wave (7-9 us per edge, measured) -- and parks the values in registers until
+    // all consumers of this CU have left the previous vector; consumer 0 finishes (sum copy, RMSNorm) and releases.
+    u32x4 gv[JX];
+    if (c == 0 && o.gain) {
 #pragma unroll
-            for (int j = 0; j < JX; ++j) { const int vi = lane + 64 * j; gv[j] = ld16(o.gain + (size_t)(vi < KV ? vi : KV - 1) * 8); }
-        }
-        if (o.x_src == 0) {                              // written by the launch before this one: plain loads
+        for (int j = 0; j < JX; ++j) { const int vi = lane + 64 * j; gv[j] = ld16(o.gain + (size_t)(vi < KV ? vi : KV - 1) * 8); }
+    }
+    const int per = (K + (int)gridDim.x - 1) / (int)gridDim.x, e0 = cu * per;         // this CU's share of the vector
+    if (o.x_src == 0) {
+        if (c == 0) {
+            while (fl[F_CONSDONE] < (uint32_t)(ncons * oi)) {
+                if (sp.give_up(a)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
             u32x4 xl[JX];
 #pragma unroll
             for (int j = 0; j < JX; ++j) { const int vi = lane + 64 * j; xl[j] = ld16(o.xg + (size_t)(vi < KV ? vi : KV - 1) * 8); }
             if (oi == 0 && lane == 0) fl[F_GATHER] = 1;  // the requests are in the queue: the loader may start
 #pragma unroll
             for (int j = 0; j < JX; ++j) { const int vi = lane + 64 * j; xb[vi] = vi < KV ? xl[j] : u32x4{0u, 0u, 0u, 0u}; }
-        } else {                                         // granules of an op of THIS launch: sweep until every tag is set
-            if (lane == 0) fl[F_GATHER] = 2;             // thin the loader meanwhile
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(o.xgran), 0, (uint32_t)K * 4, 0x00020000);
-            const int nch = (K + 255) >> 8;              // chunks of 256 granules (1 KiB, one load instruction)
-            for (int ch0 = 0; ch0 < nch; ch0 += 8) {     // 8 KiB passes
-                u32x4 gr[8];
+        }
+    } else {
+        if (c == 0 && lane == 0) fl[F_GATHER] = 2;       // thin the loader while this CU gathers
+        if (o.x_src == 2 && c == 0) {
+            // tensor-parallel sum of my share: every rank's partial granules of this all-reduce (tag = its number), summed in
+            // rank order in fp32 and rounded once -- p2p_allreduce_kernel's arithmetic -- then published like any op output
+            const uint32_t arn = seq0 + (uint32_t)o.ar_k, tag = (arn & 0x7fffu) | 0x8000u;
+            const size_t aoff = (size_t)(arn & (ENG_AR_BUFS - 1)) * ENG_AR_MAXLEN * 4;
+            for (int l0 = 0; l0 < per; l0 += 64) {
+                const int e = e0 + l0 + lane;
+                const bool mine = l0 + lane < per && e < K;
+                uint32_t v[EMU_ENG_MAX_RANKS];
                 for (;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)          // beyond the array: zeros (descriptor bound)
-                        gr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)((ch0 + k) * 1024 + lane * 16), 0, AUX_SC1);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int e0 = (ch0 + k) * 256 + lane * 4;
-                        ok &= (e0 + 0 >= K) || (gr[k].x >> 16) != 0;
-                        ok &= (e0 + 1 >= K) || (gr[k].y >> 16) != 0;
-                        ok &= (e0 + 2 >= K) || (gr[k].z >> 16) != 0;
-                        ok &= (e0 + 3 >= K) || (gr[k].w >> 16) != 0;
+                    for (int r = 0; r < EMU_ENG_MAX_RANKS; ++r) {
+                        v[r] = 0;
+                        if (r < a.tp_n && mine) {
+                            v[r] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(a.comm[r] + aoff) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            ok &= (v[r] >> 16) == tag;
+                        }
                     }
                     if (__all(ok) || sp.give_up(a)) break;
-                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_s_sleep(2);
                 }
+                float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (ch0 + k < nch) {                 // 4 values = 8 bytes at element (ch0 + k) * 256 + lane * 4
-                        uint2 pk;
-                        pk.x = (gr[k].x & 0xffffu) | (gr[k].y << 16);
-                        pk.y = (gr[k].z & 0xffffu) | (gr[k].w << 16);
-                        reinterpret_cast<uint2*>(xbuf)[(ch0 + k) * 64 + lane] = pk;
-                    }
+                for (int r = 0; r < EMU_ENG_MAX_RANKS; ++r)
+                    if (r < a.tp_n) acc += bf2f((bf16_t)(v[r] & 0xffffu));
+                if (mine) __hip_atomic_store(o.xgran + e, 0x10000u | f2bf(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(o.xgran), 0, (uint32_t)K * 4, 0x00020000);
+        const int nch = (K + 255) >> 8;                  // chunks of 256 granules (1 KiB, one load instruction)
+        constexpr int MYCH = 6;                          // chunks per wave and pass: 26 chunks (K = 6656) over 5 consumers in one pass
+        bool vacated = false;
+        for (int k0 = 0; c + k0 * ncons < nch; k0 += MYCH) {
+            u32x4 gr[MYCH];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < MYCH; ++k)           // beyond the array: zeros (descriptor bound)
+                    gr[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)((c + (k0 + k) * ncons) * 1024 + lane * 16), 0, AUX_SC1);
+#pragma unroll
+                for (int k = 0; k < MYCH; ++k) {
+                    const int e = (c + (k0 + k) * ncons) * 256 + lane * 4;
+                    ok &= (e + 0 >= K) || (gr[k].x >> 16) != 0;
+                    ok &= (e + 1 >= K) || (gr[k].y >> 16) != 0;
+                    ok &= (e + 2 >= K) || (gr[k].z >> 16) != 0;
+                    ok &= (e + 3 >= K) || (gr[k].w >> 16) != 0;
+                }
+                if (__all(ok) || sp.give_up(a)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (c == 0 && k0 == 0) eng_trace(a, 22 + oi);
+            while (!vacated && fl[F_CONSDONE] < (uint32_t)(ncons * oi)) {   // every consumer of this CU has left the previous vector
+                if (sp.give_up(a)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            vacated = true;
+#pragma unroll
+            for (int k = 0; k < MYCH; ++k) {
+                const int ch = c + (k0 + k) * ncons;
+                if (ch < nch) {                          // 4 values = 8 bytes at element ch * 256 + lane * 4 (zeros beyond K)
+                    uint2 pk;
+                    pk.x = (gr[k].x & 0xffffu) | (gr[k].y << 16);
+                    pk.y = (gr[k].z & 0xffffu) | (gr[k].w << 16);
+                    reinterpret_cast<uint2*>(xbuf)[ch * 64 + lane] = pk;
                 }
             }
-            for (int e = K + lane; e < JX * 512; e += 64) reinterpret_cast<bf16_t*>(xbuf)[e] = 0;     // columns K .. JX * 512
+        }
+        while (!vacated && fl[F_CONSDONE] < (uint32_t)(ncons * oi)) {       // (a wave without a chunk of its own)
+            if (sp.give_up(a)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (c == ncons - 1)
+            for (int e = nch * 256 + lane; e < JX * 512; e += 64) reinterpret_cast<bf16_t*>(xbuf)[e] = 0;   // columns beyond the last chunk
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(fl + F_XPARTS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (c == 0) {
+        while (fl[F_XPARTS] < (uint32_t)(ncons * (oi + 1))) {           // every wave's share of the vector is in LDS
+            if (sp.give_up(a)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (o.x_src != 0) {
             if (lane == 0) fl[F_GATHER] = 1;
+            if (o.sum_out)                               // the vector as plain bf16 for later launches: this CU's share
+                for (int l = lane; l < per && e0 + l < K; l += 64) o.sum_out[e0 + l] = reinterpret_cast<const bf16_t*>(xbuf)[e0 + l];
+        }
+        if (o.keep_raw) {                                // a later op's residual reads the un-normalised vector from LDS
+#pragma unroll
+            for (int j = 0; j < JX; ++j) reinterpret_cast<u32x4*>(xraw)[lane + 64 * j] = xb[lane + 64 * j];
         }
         if (o.gain) {
             // RMSNorm with the launch kernels' arithmetic: thread t of their 256 owns columns t, t + 256, ...; its sum of squares runs
             // over its columns in order, the four waves' DPP sums are added in wave order
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             float sw[4] = {0.f, 0.f, 0.f, 0.f};
             u32x4 xr[JX];
 #pragma unroll
@@ -280,7 +345,7 @@ __device__ __forceinline__ void consume_op(const EngArgs& a, const EngOp& o, int
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (lane == 0) fl[F_XREADY] = (uint32_t)(oi + 1);
-        if (oi == 0) eng_trace(a, 4);
+        eng_trace(a, 4 + oi);
     }
     while (fl[F_XREADY] < (uint32_t)(oi + 1)) {
         if (sp.give_up(a)) break;
@@ -302,7 +367,6 @@ __device__ __forceinline__ void consume_op(const EngArgs& a, const EngOp& o, int
                 if (sp.give_up(a)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (c == 0 && oi == 0 && gi == 0 && fi == 0) eng_trace(a, 5);
             const char* sb = ring + (size_t)slot * ENG_SLOT;
             const int row_f = f * rps;                                      // first row of the fill (CU-local)
             const int nrow_f = (a.dbg & 1) ? 0 : (nrows - row_f < rps ? nrows - row_f : rps);
@@ -359,25 +423,30 @@ __device__ __forceinline__ void consume_op(const EngArgs& a, const EngOp& o, int
             } else if (lane < nrow_f) {
                 const int n = row0 + row_f + lane;
                 float v = bfround(myval);
-                if (o.epi == EPI_RESID) v = v + bf2f(o.res[n]);
+                if (o.epi == EPI_RESID) v = v + bf2f(o.res_src == 1 ? reinterpret_cast<const bf16_t*>(xraw)[n] : o.res[n]);
                 const bf16_t ov = f2bf(v);
                 if (o.out_dst == 0) o.out[n] = ov;
-                else __hip_atomic_store(o.ogran + n, 0x10000u | ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (o.out_dst == 1) __hip_atomic_store(o.ogran + n, 0x10000u | ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {                                   // my partial sum of this launch's ar_k-th all-reduce: system scope (peer GPUs read it)
+                    const uint32_t arn = seq0 + (uint32_t)o.ar_k, tag = (arn & 0x7fffu) | 0x8000u;
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(a.comm[a.tp_rank] + (size_t)(arn & (ENG_AR_BUFS - 1)) * ENG_AR_MAXLEN * 4);
+                    __hip_atomic_store(dst + n, (tag << 16) | ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }
     gbase += nfills;
-    if (c == 0 && oi == 0) eng_trace(a, 6);
-    if (c == ncons - 1 && oi == a.nops - 1) eng_trace(a, 7);
+    if (c == 0) eng_trace(a, 10 + oi);
+    eng_trace(a, 16 + oi);
     if (lane == 0)                                       // done with this op's activation vector
         __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(fl + F_CONSDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <bool VW4>
 __device__ __forceinline__ void consume_op_jx(int jx, const EngArgs& a, const EngOp& o, int oi, int c, int ncons, int& gbase, char* ring,
-                                              char* xbuf, lds_u32* fl, Spin& sp) {
+                                              char* xbuf, char* xraw, uint32_t seq0, lds_u32* fl, Spin& sp) {
     switch (jx) {
-#define EMU_J(J) case J: consume_op<J, VW4>(a, o, oi, c, ncons, gbase, ring, xbuf, fl, sp); break;
+#define EMU_J(J) case J: consume_op<J, VW4>(a, o, oi, c, ncons, gbase, ring, xbuf, xraw, seq0, fl, sp); break;
         EMU_J(1) EMU_J(2) EMU_J(3) EMU_J(4) EMU_J(5) EMU_J(6) EMU_J(7) EMU_J(8) EMU_J(9) EMU_J(10) EMU_J(11) EMU_J(12) EMU_J(13)
 #undef EMU_J
         default: break;
@@ -394,10 +463,16 @@ __global__ __launch_bounds__(ENG_THREADS, 1) void decode_engine_kernel(const Eng
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* ring = smem;
     char* xbuf = smem + (size_t)a.nslot * ENG_SLOT;
-    lds_u32* fl = (lds_u32*)(__attribute__((address_space(3))) char*)(xbuf + a.xbytes);
+    char* xraw = xbuf + a.xbytes;
+    lds_u32* fl = (lds_u32*)(__attribute__((address_space(3))) char*)(xraw + a.xbytes);
     const uint32_t flags_addr = (uint32_t)(size_t)fl;
     if (tid < ENG_FLAGS / 4) fl[tid] = 0;
+    // all-reduces this CU has been through before this launch (the same number on every CU of every rank: they run the same launches
+    // in the same order): numbers this launch's all-reduces, i.e. their tags and comm arrays.  Every wave reads it ahead of the
+    // barrier, one lane advances it behind the barrier.
+    const uint32_t seq0 = a.seq ? a.seq[blockIdx.x] : 0u;
     __syncthreads();
+    if (a.seq && a.n_ar && tid == 0) a.seq[blockIdx.x] = seq0 + (uint32_t)a.n_ar;
     const int nload = a.nload;                           // loader waves (1 or 2); the others consume
     if (wave < nload) { loader_wave(a, wave, nload, ring, flags_addr); return; }
     const int c = wave - nload, ncons = ENG_THREADS / 64 - nload;        // consumer 0 also gathers the activation vectors
@@ -406,14 +481,14 @@ __global__ __launch_bounds__(ENG_THREADS, 1) void decode_engine_kernel(const Eng
     for (int oi = 0; oi < a.nops; ++oi) {
         const EngOp& o = a.op[oi];
         const int jx = ((o.K >> 3) + 63) >> 6;
-        if (o.vw == 4) consume_op_jx<true>(jx, a, o, oi, c, ncons, gbase, ring, xbuf, fl, sp);
-        else consume_op_jx<false>(jx, a, o, oi, c, ncons, gbase, ring, xbuf, fl, sp);
+        if (o.vw == 4) consume_op_jx<true>(jx, a, o, oi, c, ncons, gbase, ring, xbuf, xraw, seq0, fl, sp);
+        else consume_op_jx<false>(jx, a, o, oi, c, ncons, gbase, ring, xbuf, xraw, seq0, fl, sp);
     }
 }
 
 }  // namespace
 
-size_t decode_engine_lds_bytes(const EngArgs& a) { return (size_t)a.nslot * ENG_SLOT + a.xbytes + ENG_FLAGS; }
+size_t decode_engine_lds_bytes(const EngArgs& a) { return (size_t)a.nslot * ENG_SLOT + 2 * (size_t)a.xbytes + ENG_FLAGS; }
 
 int launch_decode_engine(EngArgs a, hipStream_t s) {
     if (a.nops < 1 || a.nops > ENG_MAX_OPS || !a.err || a.ncu < 1 || a.nload < 0 || a.nload > 6) return -22;
@@ -425,9 +500,15 @@ int launch_decode_engine(EngArgs a, hipStream_t s) {
         if (o.epi != EPI_NONE && o.epi != EPI_RESID && o.epi != EPI_SWIGLU) return -22;
         if (o.epi == EPI_SWIGLU && (o.N & 1)) return -22;
         if (o.K * 2 > ENG_MAXJ * 1024) return -95;       // rows longer than 13 KiB would need segments: not built (K <= 6656)
-        if (o.x_src == 0 ? !o.xg : !o.xgran) return -22;
-        if (o.out_dst == 0 ? !o.out : !o.ogran) return -22;
-        if (o.epi == EPI_RESID && !o.res) return -22;
+        if (o.x_src < 0 || o.x_src > 2 || o.out_dst < 0 || o.out_dst > 2 || (o.x_src == 0 ? !o.xg : !o.xgran)) return -22;
+        if (o.out_dst == 0 ? !o.out : (o.out_dst == 1 && !o.ogran)) return -22;
+        if (o.epi == EPI_RESID && o.res_src == 0 && !o.res) return -22;
+        if (o.x_src == 2 || o.out_dst == 2) {            // an all-reduce of this launch: the ranks' comm areas and the counters
+            if (a.tp_n < 1 || a.tp_n > EMU_ENG_MAX_RANKS || a.tp_rank < 0 || a.tp_rank >= a.tp_n || !a.seq || o.ar_k < 0 || o.ar_k >= a.n_ar) return -22;
+            if ((o.x_src == 2 ? o.K : o.N) > ENG_AR_MAXLEN || a.n_ar > ENG_AR_BUFS / 2) return -22;
+            for (int r = 0; r < a.tp_n; ++r)
+                if (!a.comm[r]) return -22;
+        }
         // fill geometry (the same for every CU): whole rows per 16 KiB slot; a (gate, up) pair of one-row fills goes to one consumer
         const int unit = o.epi == EPI_SWIGLU ? 2 : 1, units = o.N / unit, rowb = o.K * 2;
         o.q = units / a.ncu; o.rem = units % a.ncu;
@@ -442,7 +523,7 @@ int launch_decode_engine(EngArgs a, hipStream_t s) {
         kmax = o.K > kmax ? o.K : kmax;
     }
     a.xbytes = ((kmax + 511) / 512) * 1024;              // whole 64-lane vector rows
-    int nslot = (160 * 1024 - a.xbytes - ENG_FLAGS) / ENG_SLOT;
+    int nslot = (160 * 1024 - 2 * a.xbytes - ENG_FLAGS) / ENG_SLOT;
     if (nslot > 8) nslot = 8;
     if (nslot < 4) return -22;
     a.nslot = nslot;

@@ -476,6 +476,10 @@ struct emu_llama {
     unsigned* dl_err = nullptr;                  // give-up counter
     long dl_forwards = 0;                        // fused forwards issued (tests: the path under test is the one that ran)
     unsigned long long* dl_trace = nullptr;      // emu_llama_set_decode_trace (tools; -DEMU_TRACE twin library only)
+    // mode 4: the persistent weight-streaming engine (decode_engine.hip), one launch per layer between the attention launches
+    uint32_t* eng_gran = nullptr;                // granule arrays of all layers (zeroed at the head of every forward)
+    size_t eng_gran_bytes = 0;
+    long eng_forwards = 0;
     // tensor-parallel prefill in two row halves whose all-reduces run on the context's second stream (emu_llama_set_tp_overlap)
     int tp_overlap_rows = 0;                     // 0: off; else the smallest prompt (rows) that takes the two-half schedule
     long ov_forwards = 0;                        // forwards that took it (tests, tools)
@@ -707,6 +711,7 @@ void emu_llama_destroy(emu_llama* m) {
     if (m && m->dl_table) (void)hipFree(m->dl_table);
     if (m && m->dl_cnt) (void)hipFree(m->dl_cnt);
     if (m && m->dl_err) (void)hipFree(m->dl_err);
+    if (m && m->eng_gran) (void)hipFree(m->eng_gran);
     delete m;
 }
 
@@ -722,7 +727,14 @@ int emu_llama_set_decode_fused(emu_llama* m, int enable, int layers_per_launch) 
             return fail(m->ctx, -12, "emu_llama_set_decode_fused: device allocation");
         m->dl_dirty = true;
     }
-    m->decode_fused = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
+    if (enable == 4 && !m->eng_gran) {
+        const emu_llama_cfg& c = m->cfg;
+        // per layer: the summed post-attention stream (hidden), the SwiGLU product (ffn_local), the summed layer output (hidden)
+        m->eng_gran_bytes = (size_t)c.layers * (align_up((size_t)c.hidden * 4) * 2 + align_up((size_t)c.ffn_local * 4));
+        if (hipMalloc(reinterpret_cast<void**>(&m->eng_gran), m->eng_gran_bytes) != hipSuccess)
+            return fail(m->ctx, -12, "emu_llama_set_decode_fused: device allocation");
+    }
+    m->decode_fused = enable < 0 ? 0 : (enable > 4 ? 4 : enable);
     m->dl_per_launch = layers_per_launch;
     return 0;
 }
@@ -886,8 +898,78 @@ int emu_llama_forward(emu_llama* m, void* hidden, int Bn, int T, const int32_t* 
     // with B * beams > 16) keep the fused path they had before the promise became one-shot.
     const bool fuse_norm = m->fuse_norm_on && !tp && M > 16 && !m->fp8_prefill;
     bool xn_ready = false;
+    // ---- one-row step with bf16 weights on the persistent weight-streaming engine (decode_engine.hip; mode 4): per layer the attention
+    // launches, then ONE launch for  o_proj -> all-reduce -> RMSNorm + gate/up (SwiGLU) -> down -> all-reduce -> RMSNorm + the NEXT
+    // layer's qkv projection, the weight stream running ahead of the four hand-offs; same bits as the launches below.  Tensor-parallel
+    // shards with rows of at most 13 KiB (TP >= 4) whose ranks have the device to themselves; anything else takes the launches.
+    if (m->decode_fused == 4 && T == 1 && Bn == 1 && D == 128 && !m->fp8_decode && m->kv_share_nb <= 1 && l_end > m->l0 && m->eng_gran && m->dl_err &&
+        tp && cx->p2p && cx->p2p_on && emu_p2p_fenced(cx->p2p) == 0 && H <= 6656 && HD <= 6656 && Fl <= 6656 && !(H & 7) && !(Fl & 7)) {
+        EngArgs e{};
+        unsigned int* eseq = nullptr;
+        int en = 0, er = 0;
+        int ncu = 0;
+        if (emu_p2p_engine_view(cx->p2p, e.comm, &eseq, &en, &er) && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cx->device) == hipSuccess &&
+            3 * HD >= 2 * ncu && H >= 2 * ncu && Fl >= ncu && ncu <= 1024) {
+            e.tp_n = en; e.tp_rank = er; e.seq = eseq; e.err = m->dl_err; e.limit_ticks = 200000000LL; e.ncu = ncu;
+            if (const char* ev = getenv("EMU_ENGINE_TIMEOUT_MS")) { const long ms = atol(ev); if (ms > 0) e.limit_ticks = ms * 100000LL; }
+            if (const char* ev = getenv("EMU_ENGINE_LOADERS")) e.nload = atoi(ev);
+            for (int l = m->l0; l < l_end; ++l)
+                if (!m->layers[l].wqkv) return fail(cx, -22, "emu_llama_forward: layer weights not set");
+            if (hipMemsetAsync(m->eng_gran, 0, m->eng_gran_bytes, s) != hipSuccess) return fail(cx, -5, "emu_llama_forward: hipMemsetAsync");
+            const size_t gH = align_up((size_t)H * 4), gF = align_up((size_t)Fl * 4);
+            const bool res_here = epi_res == EPI_RESID;           // rank 0 adds the residuals (they enter the all-reduce once)
+            // the first layer's qkv projection is a launch of its own
+            TRY(cx, linear(hA, m->layers[m->l0].wqkv, nullptr, nullptr, m->layers[m->l0].ln1, w.qkv, 1, 3 * HD, H, H, H, 0, 3 * HD, c.rms_eps, EPI_NONE, s));
+            for (int l = m->l0; l < l_end; ++l) {
+                const emu_llama::Layer& L = m->layers[l];
+                bf16_t* kc = m->kcache + l * kv_layer;
+                bf16_t* vc = m->vcache + l * kv_layer;
+                DecodeFusedArgs da{w.qkv, m->cos, m->sin, pos, slot, kc, vc, w.attn, (long)HD, (long)D, kstart, w.dec, Bn, Hl, D, m->s_max, ctx, scale, 0, 0};
+                TRY(cx, launch_decode_fused(da, s));
+                const bool last = l + 1 == l_end;
+                char* gl = reinterpret_cast<char*>(m->eng_gran) + (size_t)(l - 0) * (2 * gH + gF);
+                uint32_t* g_hb = reinterpret_cast<uint32_t*>(gl);
+                uint32_t* g_act = reinterpret_cast<uint32_t*>(gl + gH);
+                uint32_t* g_ha = reinterpret_cast<uint32_t*>(gl + gH + gF);
+                int k = 0;
+                EngOp& o0 = e.op[k++];                          // o_proj: partial sums of the post-attention stream
+                o0 = EngOp{};
+                o0.W = L.wo; o0.N = H; o0.K = HD; o0.epi = res_here ? EPI_RESID : EPI_NONE; o0.res = hA; o0.res_src = 0;
+                o0.vw = emu_gemv_partition(H, HD, false, epi_res); o0.x_src = 0; o0.xg = w.attn; o0.out_dst = 2; o0.ar_k = 0;
+                EngOp& o1 = e.op[k++];                          // all-reduce -> RMSNorm -> gate / up -> SwiGLU
+                o1 = EngOp{};
+                o1.W = L.wgu; o1.N = 2 * Fl; o1.K = H; o1.gain = L.ln2; o1.eps = c.rms_eps; o1.epi = EPI_SWIGLU;
+                o1.vw = emu_gemv_partition(2 * Fl, H, true, EPI_SWIGLU); o1.x_src = 2; o1.xgran = g_hb; o1.ar_k = 0; o1.keep_raw = 1;
+                o1.out_dst = 1; o1.ogran = g_act;
+                EngOp& o2 = e.op[k++];                          // down: partial sums of the layer output (+ the summed stream on rank 0)
+                o2 = EngOp{};
+                o2.W = L.wdown; o2.N = H; o2.K = Fl; o2.epi = res_here ? EPI_RESID : EPI_NONE; o2.res_src = 1;
+                o2.vw = emu_gemv_partition(H, Fl, false, epi_res); o2.x_src = 1; o2.xgran = g_act;
+                if (!last) {
+                    o2.out_dst = 2; o2.ar_k = 1;
+                    EngOp& o3 = e.op[k++];                      // all-reduce -> RMSNorm -> the NEXT layer's qkv projection
+                    o3 = EngOp{};
+                    const emu_llama::Layer& Ln = m->layers[l + 1];
+                    o3.W = Ln.wqkv; o3.N = 3 * HD; o3.K = H; o3.gain = Ln.ln1; o3.eps = c.rms_eps; o3.epi = EPI_NONE;
+                    o3.vw = emu_gemv_partition(3 * HD, H, true, EPI_NONE); o3.x_src = 2; o3.xgran = g_ha; o3.ar_k = 1; o3.sum_out = hA;
+                    o3.out_dst = 0; o3.out = w.qkv;
+                    e.n_ar = 2;
+                } else {
+                    o2.out_dst = 0; o2.out = hA;                // the last layer's output leaves as this rank's partial sums
+                    e.n_ar = 1;
+                }
+                e.nops = k;
+                const int st = launch_decode_engine(e, s);
+                if (st) return fail(cx, st, "emu_llama_forward: decode engine launch");
+                if (last) TRY(cx, emu_allreduce_bf16(cx, hA, (size_t)H, s_));
+            }
+            ++m->eng_forwards;
+            ++m->dl_forwards;
+            return 0;
+        }
+    }
     // ---- one-row step with bf16 weights: whole layers per launch (decode_layer.hip), same bits as the launches below
-    if (m->decode_fused && T == 1 && Bn == 1 && D == 128 && !m->fp8_decode && m->kv_share_nb <= 1 && l_end > m->l0 && m->dl_cnt) {
+    if (m->decode_fused && m->decode_fused != 4 && T == 1 && Bn == 1 && D == 128 && !m->fp8_decode && m->kv_share_nb <= 1 && l_end > m->l0 && m->dl_cnt) {
         DecodeLayersArgs d{};
         d.table = m->dl_table; d.hA = hA; d.hB = w.hB; d.qkv = w.qkv; d.attn = w.attn; d.act = w.act; d.ws = w.dec;
         d.cos = m->cos; d.sin = m->sin; d.pos = pos; d.slot = slot; d.kstart = kstart;

@@ -330,10 +330,16 @@ bool decode_layers_ok(const DecodeLayersArgs& a);
 int launch_decode_layers(DecodeLayersArgs a, hipStream_t s);
 // the comm blocks / sequence counters of an opened EmuP2p for DecodeLayersArgs::tp_* (false: peers not mapped)
 bool emu_p2p_view(EmuP2p* p, char** block8, unsigned long long** seq, int* n, int* rank, long long* limit_ticks);
+// the engine area of every mapped comm block (decode_engine.hip's in-launch all-reduce) and this rank's per-CU counters
+bool emu_p2p_engine_view(EmuP2p* p, char** area8, unsigned int** seq, int* n, int* rank);
 
 // ---- persistent weight-streaming engine for chains of one-row GEMVs (decode_engine.hip): one launch, one resident workgroup per CU
 // (loader wave + three consumer waves on an LDS ring), op outputs handed between CUs through 4-byte {tag, bf16} granules
 constexpr int ENG_MAX_OPS = 6;
+constexpr int EMU_ENG_MAX_RANKS = 8;
+constexpr int ENG_AR_BUFS = 4;                 // comm arrays per rank, reused round-robin (an array is rewritten four all-reduces later)
+constexpr int ENG_AR_MAXLEN = 8192;            // granules per comm array
+constexpr size_t EMU_P2P_ENG_BYTES = (size_t)ENG_AR_BUFS * ENG_AR_MAXLEN * 4;   // engine area at the end of every P2P comm block
 struct EngOp {
     const bf16_t* W;                           // [N, K] row-major, K contiguous, K <= 6656
     int N, K;
@@ -342,12 +348,21 @@ struct EngOp {
     int epi;                                   // EPI_NONE / EPI_RESID / EPI_SWIGLU (rows (2j, 2j + 1) = (gate_j, up_j))
     const bf16_t* res;                         // [N] (EPI_RESID)
     int vw;                                    // launch_gemv's column partition for this shape: 4 (block kernels) or 1 (wave kernel)
-    int x_src;                                 // 0: xg, a bf16 vector written BEFORE this launch; 1: xgran, granules of an earlier op of this launch
+    // input vector: 0 = xg, a bf16 vector written BEFORE this launch; 1 = xgran, granules of an earlier op of this launch;
+    // 2 = the tensor-parallel SUM of an earlier op's partial outputs: every CU reduces its share of the ranks' comm arrays (ar_k-th
+    // all-reduce of the launch) in rank order (p2p.hip's arithmetic), publishes it to xgran, and gathers xgran like case 1
+    int x_src;
     const bf16_t* xg;
-    const uint32_t* xgran;
-    int out_dst;                               // 0: out, plain bf16 (read by a LATER launch); 1: ogran, granules (zero at launch)
+    uint32_t* xgran;
+    bf16_t* sum_out;                           // x_src 1 / 2: the gathered vector also goes here as plain bf16 (read by LATER launches), or null
+    int keep_raw;                              // the gathered (un-normalised) vector stays in LDS for a later op's residual (res_src = 1)
+    // output vector: 0 = out, plain bf16 (read by a LATER launch); 1 = ogran, granules (zero at launch); 2 = this rank's comm array
+    // of the ar_k-th all-reduce of the launch (partial sums, read by every rank's reducers)
+    int out_dst;
     bf16_t* out;
     uint32_t* ogran;
+    int ar_k;                                  // out_dst 2 / x_src 2: which all-reduce of this launch
+    int res_src;                               // EPI_RESID: 0 = res (global, written before this launch); 1 = the vector kept by keep_raw
     // set by launch_decode_engine: units (rows, or (gate, up) pairs) per CU = q (+ 1 for the first rem CUs), whole rows per 16 KiB fill,
     // bytes / LDS-DMA instructions per fill, fills that go to one consumer together, fills per CU (q / q + 1 units)
     int q, rem, rps, fill_bytes, ni, grp, nfills_lo, nfills_hi;
@@ -358,7 +373,12 @@ struct EngArgs {
     unsigned* err;                             // give-up counter (device)
     long long limit_ticks;                     // bound of every wait, 100 MHz ticks
     int ncu;                                   // workgroups = CUs of the device (all must be resident)
-    int nload;                                 // loader waves per workgroup: 1 or 2 (0 = default)
+    // tensor parallelism (tp_n >= 1 with all-reduce ops): every rank's engine area inside its P2P comm block (p2p.hip), ENG_AR_BUFS
+    // arrays of ar_len granules used round-robin by the all-reduces in launch order (a per-CU device counter numbers them: the tag)
+    char* comm[EMU_ENG_MAX_RANKS];
+    int tp_n, tp_rank, n_ar, ar_len;
+    unsigned int* seq;                         // [ncu] all-reduces this CU has been through (device memory, owned by the comm block's creator)
+    int nload;                                 // loader waves per workgroup (0 = default)
     int dbg;                                   // tools: bit 0 = consumers acknowledge fills without multiplying (loader ceiling)
     int nslot, xbytes;                         // set by launch_decode_engine
 };

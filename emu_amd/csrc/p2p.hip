@@ -122,11 +122,17 @@ __global__ __launch_bounds__(512) void p2p_allreduce_kernel(P2pPeers p, unsigned
 
 }  // namespace
 
+static size_t emu_p2p_engine_offset() {
+    return (2 * EMU_P2P_SLOT_BYTES + 2 * P2P_PIECES * sizeof(unsigned long long) + 255) / 256 * 256;
+}
+constexpr int EMU_ENG_SEQ_WORDS = 1024;           // per-CU all-reduce counters of the engine (>= CUs of any device)
+
 struct EmuP2p {
     char* mine = nullptr;                           // my comm block (device memory owned by this object)
     char* block[EMU_P2P_MAX_RANKS] = {};
     bool opened[EMU_P2P_MAX_RANKS] = {};
     unsigned long long* seq = nullptr;              // device-side sequence counters, one per piece (plain device memory)
+    unsigned int* eng_seq = nullptr;                // decode_engine.hip: all-reduces every CU has been through (plain device memory)
     int n = 0, rank = 0;
     long long limit_ticks = 10LL * 100000000LL;     // 10 s
     int fenced = 1;                                 // emu_p2p_set_fenced: the memory-model form until the host's soak cleared the other
@@ -136,7 +142,7 @@ EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out) {
     if (n < 1 || n > EMU_P2P_MAX_RANKS || rank < 0 || rank >= n) return nullptr;
     EmuP2p* p = new EmuP2p();
     p->n = n; p->rank = rank;
-    const size_t bytes = 2 * EMU_P2P_SLOT_BYTES + 2 * P2P_PIECES * sizeof(unsigned long long);
+    const size_t bytes = emu_p2p_engine_offset() + EMU_P2P_ENG_BYTES;      // [slot 0 | slot 1 | flags | engine area (decode_engine.hip)]
     void* ptr = nullptr;
     // uncached (what RCCL uses for its own peer-visible buffers on gfx94x/gfx950), else fine-grained, else plain device memory:
     // the kernel's system-scope release / acquire pairs are sufficient for any of the three.
@@ -149,7 +155,8 @@ EmuP2p* emu_p2p_create(int rank, int n, void* handle64_out) {
     }
     p->mine = reinterpret_cast<char*>(ptr);
     if (hipMemset(p->mine, 0, bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&p->seq), P2P_PIECES * 8) != hipSuccess ||
-        hipMemset(p->seq, 0, P2P_PIECES * 8) != hipSuccess) { emu_p2p_destroy(p); return nullptr; }
+        hipMemset(p->seq, 0, P2P_PIECES * 8) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&p->eng_seq), EMU_ENG_SEQ_WORDS * 4) != hipSuccess ||
+        hipMemset(p->eng_seq, 0, EMU_ENG_SEQ_WORDS * 4) != hipSuccess) { emu_p2p_destroy(p); return nullptr; }
     (void)hipDeviceSynchronize();
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle is 64 bytes");
     hipIpcMemHandle_t h;
@@ -180,6 +187,7 @@ void emu_p2p_destroy(EmuP2p* p) {
         if (p->opened[r]) (void)hipIpcCloseMemHandle(p->block[r]);
     if (p->mine) (void)hipFree(p->mine);
     if (p->seq) (void)hipFree(p->seq);
+    if (p->eng_seq) (void)hipFree(p->eng_seq);
     delete p;
 }
 
@@ -205,6 +213,15 @@ bool emu_p2p_view(EmuP2p* p, char** block8, unsigned long long** seq, int* n, in
         if (!p->block[r]) return false;
     for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r) block8[r] = r < p->n ? p->block[r] : nullptr;
     *seq = p->seq; *n = p->n; *rank = p->rank; *limit_ticks = p->limit_ticks;
+    return true;
+}
+
+bool emu_p2p_engine_view(EmuP2p* p, char** area8, unsigned int** seq, int* n, int* rank) {
+    if (!p || !p->eng_seq) return false;
+    for (int r = 0; r < p->n; ++r)
+        if (!p->block[r]) return false;
+    for (int r = 0; r < EMU_P2P_MAX_RANKS; ++r) area8[r] = r < p->n ? p->block[r] + emu_p2p_engine_offset() : nullptr;
+    *seq = p->eng_seq; *n = p->n; *rank = p->rank;
     return true;
 }
 

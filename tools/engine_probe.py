@@ -87,3 +87,29 @@ t_e = timeit(lambda i: chain(i, err), iters)
 mb = (2 * Fl * H + H * Fl) * 2 / 1e6
 print(f"tp{tp} gate/up -> down       {mb:6.1f} MB | two launches {t_l:6.1f} us {mb / t_l:5.2f} TB/s | one engine launch {t_e:6.1f} us {mb / t_e:5.2f} TB/s | "
       f"{'bits equal' if same else 'BITS DIFFER max ' + str(float((outs[1].float() - want.float()).abs().max()))} | give-ups {int(err.item())}", flush=True)
+
+# a whole layer's projections (all-reduces as plain hand-offs): o_proj -> gate/up -> down -> next qkv, one launch vs four
+ws_o, xo, _, res_o, _ = mats["o+res"]
+ws_q, _, gq, _, _ = mats["qkv+norm"]
+
+
+def four(i):
+    h = ops.linear(xo, ws_o[i % len(ws_o)], res=res_o, epi=ops.EPI_RESID)
+    a_ = ops.linear(h, ws_g[i % len(ws_g)], norm_w=gg, eps=1e-6, epi=ops.EPI_SWIGLU)
+    h2 = ops.linear(a_, ws_d[i % len(ws_d)], res=res_d, epi=ops.EPI_RESID)
+    return ops.linear(h2, ws_q[i % len(ws_q)], norm_w=gq, eps=1e-6)
+
+
+lchain = lambda i, err=None: ops.gemv_chain(ctx.handle, [dict(w=ws_o[i % len(ws_o)], x=xo, epi=ops.EPI_RESID, res=res_o),
+                                                         dict(w=ws_g[i % len(ws_g)], x=None, gain=gg, eps=1e-6, epi=ops.EPI_SWIGLU),
+                                                         dict(w=ws_d[i % len(ws_d)], x=None, epi=ops.EPI_RESID, res=res_d),
+                                                         dict(w=ws_q[i % len(ws_q)], x=None, gain=gq, eps=1e-6, epi=ops.EPI_NONE)], err=err)
+want = four(0)
+outs, err, _ = lchain(0)
+torch.cuda.synchronize()
+same = torch.equal(outs[3], want)
+t_l = timeit(four, iters)
+t_e = timeit(lambda i: lchain(i, err), iters)
+mb = (H * HD + 2 * Fl * H + H * Fl + 3 * HD * H) * 2 / 1e6
+print(f"tp{tp} o -> gate/up -> down -> qkv {mb:6.1f} MB | four launches {t_l:6.1f} us {mb / t_l:5.2f} TB/s | one engine launch {t_e:6.1f} us {mb / t_e:5.2f} TB/s | "
+      f"{'bits equal' if same else 'BITS DIFFER max ' + str(float((outs[3].float() - want.float()).abs().max()))} | give-ups {int(err.item())}", flush=True)

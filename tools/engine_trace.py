@@ -25,14 +25,18 @@ specs = {"qkv": [dict(w=r(3 * HD, H, scale=0.02), x=r(1, H), gain=r(H), eps=1e-6
          "gu": [dict(w=r(2 * Fl, H, scale=0.02), x=r(1, H), gain=r(H), eps=1e-6, epi=ops.EPI_SWIGLU)],
          "down": [dict(w=r(H, Fl, scale=0.02), x=r(1, Fl), epi=ops.EPI_RESID, res=r(1, H))]}
 specs["mlp"] = [specs["gu"][0], dict(w=specs["down"][0]["w"], x=None, epi=ops.EPI_RESID, res=specs["down"][0]["res"])]
-names = ["entry", "first fill issued", "last fill issued", "loader done", "x ready (op 0)", "first fill consumed", "op 0 done (cons 0)", "last consumer done"]
+# a whole layer's projections as one chain (the all-reduces as plain hand-offs): o_proj -> gate/up -> down -> the next layer's qkv
+specs["layer"] = [specs["o"][0], dict(w=specs["gu"][0]["w"], x=None, gain=specs["gu"][0]["gain"], eps=1e-6, epi=ops.EPI_SWIGLU),
+                  dict(w=specs["down"][0]["w"], x=None, epi=ops.EPI_RESID, res=specs["down"][0]["res"]),
+                  dict(w=specs["qkv"][0]["w"], x=None, gain=specs["qkv"][0]["gain"], eps=1e-6, epi=ops.EPI_NONE)]
+names = ["entry", "first fill issued", "last fill issued", "loader done"] + [f"x ready (op {i})" for i in range(6)] + [f"op {i} done (consumer 0)" for i in range(6)] + [f"op {i} done (last consumer)" for i in range(6)] + [f"op {i} input swept (consumer 0)" for i in range(6)]
 for rep in range(3):
-    err = torch.zeros(2 + 8 * 512, device=dev, dtype=torch.int64)
+    err = torch.zeros(2 + 32 * 512, device=dev, dtype=torch.int64)
     for w in flush:
         ops.linear(xf, w)
     ops.gemv_chain(ctx.handle, specs[case], err=err.view(torch.int32))
     torch.cuda.synchronize()
-    t = err[1:1 + 8 * 256].view(256, 8).cpu().double()
+    t = err[1:1 + 32 * 256].view(256, 32).cpu().double()
     t0 = t[:, 0].min()
     print(f"--- {case} tp{tp} run {rep}: give-ups {int(err.view(torch.int32)[0])}")
     for k, nm in enumerate(names):

@@ -3,7 +3,7 @@
 loop (the all-reduce launches are real, their cross-GPU latency is not).  With a third argument "p2p" the all-reduces are the
 one-shot peer-to-peer kernel (csrc/p2p.hip) with one rank instead.  Usage: python tools/tp_emulate.py [tp] [steps] [p2p|rccl] [modes, e.g. 0,1,2]
 (modes: emu_llama_set_decode_fused -- 0 launches, 1 fused layers cut at the all-reduces, 2 all-reduce inside the launch, 3 the all-reduce in the
-tail of the o_proj / down_proj launches; tp = 1: 0,1)"""
+tail of the o_proj / down_proj launches, 4 the persistent weight-streaming engine (csrc/decode_engine.hip); tp = 1: 0,1)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,7 +43,8 @@ x = (torch.randn(1, S, l.hidden_size, device=dev) * 0.1).to(torch.bfloat16)
 mask = torch.ones(1, S, dtype=torch.long)
 modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2, 3]
 names = {0: "launches (8 per layer)", 1: "fused, cut at the all-reduces (4 launches per layer)", 2: "fused, all-reduce inside (1 launch per token)",
-         3: "tail all-reduce (5 launches per layer: qkv | attention | o_proj + all-reduce | gate/up | down + all-reduce)"}
+         3: "tail all-reduce (5 launches per layer: qkv | attention | o_proj + all-reduce | gate/up | down + all-reduce)",
+         4: "persistent engine (3 launches per layer: attention | combine | o_proj -> all-reduce -> gate/up -> down -> all-reduce -> next qkv)"}
 with torch.no_grad():
     hidden, kstart, next_pos = eng.prefill(x, mask, eng.kv_capacity(S + steps + 24))
     cur = ops.argmax(eng.logits(hidden[:, -1, :]), suppress_id=2)
