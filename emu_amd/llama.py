@@ -231,8 +231,12 @@ class LlamaEngine:
         launch (csrc/decode_layer.hip: ``layers_per_launch`` layers, 0 = all) instead of six launches + two all-reduces per layer;
         bit-identical to the launches.  Under tensor parallelism 1 = cut at the all-reduces (four launches per layer), 2 = all-reduces
         inside the launch over the P2P comm blocks (one GPU per rank), 3 = stand-alone launches whose last workgroup runs the
-        all-reduce in its tail (attention, o_proj, down_proj as single-role launches: five per layer, safe on a shared device).  OFF by default: measured slower than the launches (see
-        __init__; EMU_DECODE_FUSED=1|2 in the environment switches it on).  Invalidates captured decode graphs."""
+        all-reduce in its tail (attention, o_proj, down_proj as single-role launches: five per layer, safe on a shared device);
+        4 = the persistent weight-streaming engine (csrc/decode_engine.hip: the attention launches, then ONE launch per layer for
+        o_proj -> all-reduce -> gate/up -> down -> all-reduce -> the next layer's qkv; tensor-parallel shards with rows of at most
+        13 KiB, i.e. TP >= 4, over the P2P comm blocks, one GPU per rank; anything else silently keeps the launches).  OFF by default:
+        every mode measured slower than the launches (see __init__; EMU_DECODE_FUSED=<mode> in the environment switches one on).
+        Invalidates captured decode graphs."""
         check(lib().emu_llama_set_decode_fused(self.handle, int(enable), int(layers_per_launch)), "emu_llama_set_decode_fused",
               self.ctx.handle)
         self.decode_fused = int(enable)

@@ -353,6 +353,12 @@ int emu_llama_set_decode_tail(emu_llama* m, int enable);
  * ITSELF (modes 1 and 2; also mode 1's cut layers wait inside their launches): processes that share a GPU can starve each other's producer workgroups of CU slots (observed with eight rank processes on
  * one device: a time-out, then garbage and a non-zero give-up count).  Every in-kernel wait is bounded in wall-clock time (2 s, or
  * the peer-to-peer time-out where longer).
+ * enable == 4: the persistent weight-streaming engine (emu_amd/csrc/decode_engine.hip; see emu_gemv_chain_bf16): per layer the
+ * attention launches, then ONE launch  o_proj -> all-reduce -> RMSNorm + gate/up (SwiGLU) -> down -> all-reduce -> RMSNorm + the next
+ * layer's qkv projection, whose loader waves stream the layer's weights through an LDS ring ahead of the four hand-offs and whose
+ * all-reduces run over the ranks' comm arrays (tags numbered by a per-CU device counter).  Tensor-parallel shards whose rows are at
+ * most 13 KiB (hidden, heads_local * 128, ffn_local <= 6656: TP >= 4 at the LLaMA-33B shape) with the fence-free P2P path on; anything
+ * else keeps the launches.  Same bits as the launches; needs every rank on its own GPU and the device to itself.
  * The first fused forward after a weight change uploads a pointer table and must therefore run outside stream capture (-16).
  * Replaces: the per-layer module calls of the LlamaDecoderLayer loop (Emu2/emu/emu.py:133-138, :213-229) and the device hops of
  * Emu2/emu/mixin.py:44-81. */
