@@ -985,7 +985,7 @@ def main():
     # the committed pass over THIS command (profiles/r03_gemv_pmc_traffic.json, gfx950-corrected) gives traffic /
     # algorithmic bytes for the same kernels; traffic = that ratio x this run's algorithmic bytes per launch
     traffic, traffic_src = None, "no PMC pass over the GEMV sources committed"
-    for rnd in ("r05", "r03"):                               # the newest committed pass whose kernel sources are these
+    for rnd in ("r06", "r05", "r03"):                               # the newest committed pass whose kernel sources are these
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_gemv_pmc_traffic.json")))
         except Exception:
@@ -999,7 +999,7 @@ def main():
         traffic_src = f"profiles/{rnd}_gemv_pmc_traffic.json is STALE (taken on other kernel sources: re-run tools/pmc_traffic.sh); traffic not reported"
 
     prefill_traffic, prefill_traffic_src = None, "no PMC pass over the GEMM sources committed"
-    for rnd in ("r05", "r04", "r03"):                        # the newest committed pass whose kernel sources are these
+    for rnd in ("r06", "r05", "r04", "r03"):                        # the newest committed pass whose kernel sources are these
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_prefill_gemm_pmc_traffic.json")))
         except Exception:
@@ -1011,6 +1011,10 @@ def main():
             break
         prefill_traffic_src = f"profiles/{rnd}_prefill_gemm_pmc_traffic.json is STALE (other kernel sources): traffic not reported"
     if rank == 0:
+        for what, val, src in (("roofline.traffic", traffic, traffic_src), ("prefill_roofline.traffic", prefill_traffic, prefill_traffic_src)):
+            if val is None:                                     # loud, but never at the price of the line itself
+                log(f"WARNING: {what} is not reported -- {src}.  Re-run tools/pmc_traffic.sh / tools/pmc_prefill_traffic.sh on the final sources and "
+                    "commit their output under profiles/.")
         prefill_flops = lcfg.num_hidden_layers * (2 * S * (4 * lcfg.hidden_size ** 2 + 3 * lcfg.hidden_size * lcfg.intermediate_size)
                                                    + 2 * S * S * lcfg.hidden_size)
         res = {
