@@ -815,7 +815,7 @@ def main():
     # ---- extra leg (never the headline): same decode loop over the fp8 e4m3 weight stream (BASELINE.json configs[5]'s
     # weight-only quantised serving mode); prefill + KV cache stay bf16
     fp8 = None
-    if not a.no_fp8:
+    if not a.no_fp8 and world == 1:                             # extra legs run on one GPU only: an N > 1 run carries the headline and nothing that could stall it
         try:
             t0 = time.time()
             lm.use_fp8(True)
@@ -941,8 +941,20 @@ def main():
     # ---- second half of the metric: SDXL-style UNet denoise (BASELINE.json configs[3]), replicas only across GPUs
     denoise = None
     if not a.no_denoise:
-        denoise_leg.no_fp8 = a.no_fp8
-        denoise = denoise_leg(ctx, dev, a.denoise_steps, world, dist if world > 1 else None, a.unet_fusion)
+        # across GPUs this leg runs REPLICAS: every rank times its own loop with no collective inside (a rank that fails
+        # must not leave the others in a barrier), then one all_gather_object that every rank reaches
+        denoise_leg.no_fp8 = a.no_fp8 or world > 1
+        try:
+            denoise = denoise_leg(ctx, dev, a.denoise_steps, 1, None, a.unet_fusion)
+        except Exception as e:
+            denoise = {"value": None, "per_gpu": None, "note": f"denoise leg failed on rank {rank}: {type(e).__name__}: {e}"}
+        if world > 1:
+            box = [None] * world
+            dist.all_gather_object(box, {"per_gpu": denoise.get("per_gpu"), "ms_per_step": denoise.get("ms_per_step")})
+            rates = [b.get("per_gpu") for b in box]
+            denoise["per_rank_ms_per_step"] = [b.get("ms_per_step") for b in box]
+            denoise["value"] = sum(r for r in rates if r) if all(rates) else None
+            denoise["scaling"] = "replicas only (independent images per GPU; value = sum over the ranks' own rates)"
 
     legs = None
     if not a.no_legs and world == 1:

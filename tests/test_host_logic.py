@@ -708,3 +708,30 @@ def test_default_beam_mode_is_announced_and_its_cur0_eos_case_is_refused():
     assert calls == [(5, 1, "4.31")] * 2
     EmuModel.generate_ids(me, ids, mask, num_beams=5, min_len=0, hf_semantics="5.x")
     assert calls[-1] == (5, 0, "5.x")
+
+
+def test_round6_bench_line_has_no_stale_traffic_and_every_leg_its_objects():
+    """The round-6 line (`python bench.py` on the final sources, profiles/r06_bench_tp1_final.json): the contract's fields, `roofline.traffic` and
+    `prefill_roofline.traffic` from PMC passes that hash-match the sources they were quoted for (neither None nor STALE), and `roofline` +
+    `cpu_baseline` on the headline, the denoise leg and the VAE / generate_image legs."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r06_bench_tp1_final.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["dtype"] == "bf16" and d["vs_baseline"] is None and d["config"]["valid"] is True
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["traffic"] is not None and "STALE" not in r["traffic_source"] and "r06_gemv_pmc_traffic" in r["traffic_source"]
+    assert 0.99 < r["traffic"] / r["bytes_per_launch"] < 1.05 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    pr = d["extra"]["prefill_roofline"]
+    assert pr["traffic"] is not None and "STALE" not in pr["traffic_source"] and "r06_prefill_gemm_pmc_traffic" in pr["traffic_source"]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["denoise"]["roofline"]["bound"] == "mfma" and d["denoise"]["cpu_baseline"]["value"] > 0
+    for leg, bound in (("vae_decode", "mfma"), ("generate_image", "hbm")):
+        L = d["legs"][leg]
+        assert L["roofline"]["bound"] == bound and 0 < L["roofline"]["frac"] < 1, leg
+        assert L["cpu_baseline"]["value"] > 0 and L["cpu_baseline"]["sample"], leg
+    assert abs(d["legs"]["vae_decode"]["roofline"]["flops"] - 10.47e12) < 0.01e12
