@@ -132,6 +132,10 @@ __device__ __forceinline__ void loader_wave(const EngArgs& a, int wave, int nloa
             if (g >= nslot) {                            // the slot's previous fill (g - nslot) must have been consumed
                 const uint32_t need = (uint32_t)(g - nslot + 1);
                 while (lds_ld(flags_addr + (F_DONE + slot) * 4) < need) {
+                    // a loader that has to wait for a slot first publishes what it still holds back: a fill is otherwise published
+                    // only behind the NEXT one's requests, so at every stall (ring full at a hand-off) each loader sat on a landed
+                    // fill the consumers were waiting for
+                    while (npend > 0) publish_oldest();
                     if (sp.give_up(a)) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
@@ -357,7 +361,20 @@ __device__ __forceinline__ void consume_op(const EngArgs& a, const EngOp& o, int
     for (int j = 0; j < JX; ++j) xv[j] = xb[lane + 64 * j];               // zero beyond K (the gather pads)
     const bool tail_masked = (JX * 64 != KV);            // the last vector row reaches beyond the row: the next row's bytes
     const int ngroups = (nfills + grp - 1) / grp;
-    for (int gi = c; gi < ngroups; gi += ncons) {
+    // residual values of this wave's rows, requested before the first fill is waited for: a global load in the epilogue of every
+    // fill was a dependent trip of 1.5-2 us per fill on the wave (lane r: row r of the wave's k-th fill)
+    constexpr int RESK = 8;
+    float resv[RESK];
+    if (o.epi == EPI_RESID && o.res_src == 0) {
+#pragma unroll
+        for (int k = 0; k < RESK; ++k) {
+            const int row_f = (c + k * ncons) * rps;                       // grp == 1 for every op with a residual
+            const int nr = nrows - row_f < rps ? nrows - row_f : rps;
+            resv[k] = (c + k * ncons < ngroups && lane < nr) ? bf2f(o.res[row0 + row_f + lane]) : 0.f;
+        }
+    }
+    int kk = 0;
+    for (int gi = c; gi < ngroups; gi += ncons, ++kk) {
         float gate_val = 0.f;
         for (int fi = 0; fi < grp; ++fi) {
             const int f = gi * grp + fi;
@@ -423,7 +440,16 @@ __device__ __forceinline__ void consume_op(const EngArgs& a, const EngOp& o, int
             } else if (lane < nrow_f) {
                 const int n = row0 + row_f + lane;
                 float v = bfround(myval);
-                if (o.epi == EPI_RESID) v = v + bf2f(o.res_src == 1 ? reinterpret_cast<const bf16_t*>(xraw)[n] : o.res[n]);
+                if (o.epi == EPI_RESID) {
+                    float rv;
+                    if (o.res_src == 1) rv = bf2f(reinterpret_cast<const bf16_t*>(xraw)[n]);
+                    else if (kk < RESK) {
+                        rv = resv[0];
+#pragma unroll
+                        for (int k = 1; k < RESK; ++k) rv = kk == k ? resv[k] : rv;
+                    } else rv = bf2f(o.res[n]);
+                    v = v + rv;
+                }
                 const bf16_t ov = f2bf(v);
                 if (o.out_dst == 0) o.out[n] = ov;
                 else if (o.out_dst == 1) __hip_atomic_store(o.ogran + n, 0x10000u | ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
