@@ -244,6 +244,36 @@ def test_true_width_fp8_transformer_blocks_track_bf16(true_unet):
     assert 1e-4 < e < 0.15, e
 
 
+W8A8_LATENT_TOL_50_STEPS = 0.2    # stated acceptance criterion of the W8A8 transformer-block mode: final latents vs the bf16 loop (measured 0.131)
+
+
+def test_fifty_step_loop_w8a8_blocks_acceptance_criterion(true_unet):
+    """The STATED acceptance criterion of the UNet's W8A8 mode (emu_unet_use_fp8; BASELINE configs[4], not a reference feature): the
+    whole 50-step CFG + Euler loop at the true configuration on the O(1)-activation weights of this file, 64 x 64 latent, the six GEMMs
+    of every transformer block on fp8 operands -- final latents within W8A8_LATENT_TOL_50_STEPS relative L2 of the bf16 loop's, finite,
+    deterministic."""
+    eng, Wr, ocfg = true_unet
+    H = Wd = 64
+    g = torch.Generator().manual_seed(21)
+    prompt = torch.randn(2, 64, 1792, generator=g).to(BF16)
+    sch = eng.set_timesteps(50)
+    eng.set_context(prompt.cuda(), 8 * H, 8 * Wd)
+    lat0 = (torch.randn(1, 4, H, Wd, generator=g) * sch.init_noise_sigma).to(BF16)
+    ref = eng.denoise(lat0.cuda().clone(), guidance=3.0, use_graph=True).clone()
+    eng.use_fp8(True)
+    try:
+        eng.set_timesteps(50)
+        a = eng.denoise(lat0.cuda().clone(), guidance=3.0, use_graph=True).clone()
+        eng.set_timesteps(50)
+        b = eng.denoise(lat0.cuda().clone(), guidance=3.0, use_graph=True).clone()
+    finally:
+        eng.use_fp8(False)
+    e = rel_err(a, ref)
+    print(f"W8A8 transformer blocks, 50-step loop at 64 x 64: final latents rel L2 vs the bf16 loop {e:.4f}")
+    assert torch.equal(a, b) and bool(torch.isfinite(a.float()).all())
+    assert 1e-5 < e < W8A8_LATENT_TOL_50_STEPS, e
+
+
 def test_true_width_fp8_blocks_keep_the_vt_and_cross_attention_epilogues(true_unet):
     """With fp8 operands the epilogues that only look at finished sums stay fused (fusion bits 1, 2; the LayerNorm fold, bit 0, has
     no fp8 form): V^T out of the fp8 qkv projection is bit-identical to the separate transpose launch, the cross-attention inside
