@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libemu_hip.so")
-SOURCES = ["gemv.hip", "gemv_merge.hip", "gemv_thin.hip", "decode_layer.hip", "decode_engine.hip", "gemm.hip", "gemm256.hip", "attention.hip", "beam.hip", "elementwise.hip", "unet.hip", "p2p.hip", "engine.hip", "unet_engine.hip"]
+SOURCES = ["gemv.hip", "gemv_merge.hip", "gemv_thin.hip", "decode_layer.hip", "decode_engine.hip", "gemm.hip", "gemm256.hip", "gemm_w4.hip", "attention.hip", "beam.hip", "elementwise.hip", "unet.hip", "p2p.hip", "engine.hip", "unet_engine.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_tile.h", os.path.join("..", "..", "include", "emu_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -47,6 +47,8 @@
 
 using namespace emu_gemm;
 
+int launch_gemm_w4(const GemmArgs& b, hipStream_t s, int grid, int fx);     // gemm_w4.hip
+
 namespace {
 
 constexpr int UNIT = 128 * 128;          // 128 LDS rows of 128 bytes
@@ -786,9 +788,15 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     }
     const int tail = tiles - b.full_tiles;
     const int fx = gemm_fx(b);
+    // the main launch: the four-wave tile on its LDS ring (gemm_w4.hip) for bf16 operands; this file's eight-wave ping-pong tile for
+    // fp8 operands and, as the A/B twin, under emu_gemm_tune bit 21.  Same tile order, K-slices and slab layout: the reduce launches
+    // below serve both.
+    const bool w4 = !F8 && !(emu_gemm_tune_get() & (1 << 21));
+    const int grid = b.full_tiles + tail * ksplit;
     if (fx & FX_ROPE) {                                 // launch_gemm: EPI_NONE, unsliced, bf16 (launch_v2 checks the plan)
         if constexpr (!CONV && !F8 && EPI == EPI_NONE) {
-            hipLaunchKernelGGL((gemm_pp_kernel<EPI_NONE, false, false, FX_ROPE | FX_VT>), dim3(b.full_tiles), dim3(512), 0, s, b);
+            if (w4) launch_gemm_w4(b, s, b.full_tiles, fx);
+            else hipLaunchKernelGGL((gemm_pp_kernel<EPI_NONE, false, false, FX_ROPE | FX_VT>), dim3(b.full_tiles), dim3(512), 0, s, b);
         }
         return;
     }
@@ -796,13 +804,15 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
         if constexpr (!CONV && !F8) {
             gemm_fx_dispatch<EPI>(fx, [&](auto m) {
                 constexpr int FXM = decltype(m)::value;
-                hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8, FXM>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
+                if (w4) launch_gemm_w4(b, s, grid, fx);
+                else hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8, FXM>), dim3(grid), dim3(512), 0, s, b);
                 if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI, FXM>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
             });
         }
         return;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8>), dim3(b.full_tiles + tail * ksplit), dim3(512), 0, s, b);
+    if (w4) launch_gemm_w4(b, s, grid, 0);
+    else hipLaunchKernelGGL((gemm_pp_kernel<EPI, CONV, F8>), dim3(grid), dim3(512), 0, s, b);
     if (tail > 0 && b.slab_rows) launch_rows_reduce_norm(b, s);     // launch_v2: every tile sliced, bf16, N <= 16384 (gemm_tile.h)
     else if (tail > 0) hipLaunchKernelGGL((pp_reduce_kernel<EPI>), dim3(tail, SPLITK_RED_Y), dim3(256), 0, s, b);
 }

@@ -1,0 +1,440 @@
+// Probe: a 256 x 256 x 64 bf16 GEMM tile on FOUR waves (one per SIMD, up to 512 registers each: 256 fp32 accumulators in
+// AGPRs + double-buffered fragments), wave (wr, wc) owning 128(n) x 128(m) as 4 x 4 v_mfma_f32_32x32x16_bf16 blocks --
+// 32 KiB of LDS reads per wave per k tile (128 KiB per CU; the 8-wave ping-pong tile of gemm256.hip reads 192 KiB).
+// Every wave overlaps its own ds_reads / LDS-DMA with its own MFMAs; one barrier per k tile.
+//   C[m, n] = sum_k A[m, k] W[n, k]   (both operands K-major), M, N multiples of 256, K a multiple of 64.
+// Stand-alone (hipcc tools/probe/gemm_w4_probe.hip -o tools/probe/gemm_w4_probe.bin); prints TFLOP/s per variant.
+// VAR bits (timing ablations; results only valid for VAR = 0): 1 no LDS-DMA in the loop, 2 no barrier in the loop,
+// 4 LDS-DMA issued as one burst ahead of the k-step's MFMAs, 8 no ds_reads in the loop, 16 half the DMA pieces per MFMA gap
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <array>
+#include <algorithm>
+#include <vector>
+#include <string>
+#include <utility>
+
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <int V> struct IC { static constexpr int value = V; };
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void bar() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ uint32_t packbf(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
+
+// ---- accumulators by name: a[16 b .. 16 b + 15] is block b = 4 j + i.  hipcc's allocator, given 256 accumulator registers through the
+// MFMA builtins, parks fragments in AGPRs and shuffles accumulators through v_accvgpr moves and scratch (measured: 84-1020 spills,
+// whatever the constraints); named registers leave it nothing to decide.  The statements below are the ONLY users of AGPRs: the
+// kernel's VGPR demand stays far below 256, so the compiler never spills into them (audit: no v_accvgpr_* outside ASMSTART/ASMEND).
+#define ACC_CLOBBERS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+template <int B>
+__device__ __forceinline__ void mfma_acc(const bf16x8_t& p, const bf16x8_t& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(p), "v"(q), "n"(B * 16), "n"(B * 16 + 15));
+}
+__device__ __forceinline__ void mfma_a(f32x16_t& acc, const bf16x8_t& p, const bf16x8_t& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(p), "v"(q));
+}
+template <int R>
+__device__ __forceinline__ float acc_read() {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "n"(R));
+    return v;
+}
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) { (f(IC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for(std::make_integer_sequence<int, N>{}, f); }
+__device__ __forceinline__ void acc_zero_all() {
+    static_for<256>([](auto r) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"n"(decltype(r)::value)); });
+    asm volatile("s_nop 4" ::: ACC_CLOBBERS);
+}
+
+constexpr int KT = 65536;            // one k tile in LDS: W rows [0, 256) x 128 B, then A rows [0, 256) x 128 B
+
+template <int VAR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware order: block b runs on XCD b % 8; every XCD owns one 8 x (per / 8) block of tiles, walked row-first
+    const int tiles_m = M >> 8, tiles_n = N >> 8, tiles = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    if ((tiles & 7) == 0 && (tiles_m & 7) == 0 && ((tiles >> 3) & 7) == 0 && tiles_n % ((tiles >> 3) >> 3) == 0) {
+        const int per = tiles >> 3, sup_m = 8, sup_n = per >> 3;
+        const int xcd = wg & 7, r = wg >> 3, bm = tiles_m / sup_m;
+        const int bi = xcd % bm, bj = xcd / bm;
+        wg = (bj * sup_n + r / sup_m) * tiles_m + bi * sup_m + r % sup_m;
+    }
+    const int m0 = (wg % tiles_m) << 8, n0 = (wg / tiles_m) << 8;
+
+    // LDS-DMA: piece p = wave + 4 j (j = 0 .. 7) fills LDS rows 8 p + lane / 8 (16-byte slot lane % 8) of an operand with the
+    // source chunk slot ^ ((row >> 1) & 7) of tile row `row`
+    const int prow = wave * 8 + (lane >> 3);
+    const uint32_t sck = (uint32_t)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);
+    const uint32_t vW = (uint32_t)(n0 + prow) * (uint32_t)ldw * 2u + sck;
+    const uint32_t vA = (uint32_t)(m0 + prow) * (uint32_t)lda * 2u + sck;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (uint32_t)N * (uint32_t)ldw * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (uint32_t)M * (uint32_t)lda * 2u, 0x00020000);
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& r, uint32_t voff, int soff, char* lds_wave_base) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+    };
+    const int nk = K >> 6;
+    const int rsW = 32 * ldw * 2, rsA = 32 * lda * 2;          // byte distance of consecutive pieces of a wave
+    // one piece: i = 0 .. 7 weight pieces, 8 .. 15 activation pieces
+    auto piece = [&](int buf, int tau, int i, uint32_t vw, uint32_t va) {
+        char* base = smem + buf * KT + wave * 1024;
+        if (i < 8) dma(rW, vw, (tau << 7) + i * rsW, base + i * 4096);
+        else dma(rA, va, (tau << 7) + (i - 8) * rsA, base + 32768 + (i - 8) * 4096);
+    };
+
+    // fragments: lane (l31, hi) reads row base + l31, chunk (2 kk + hi) ^ ((l31 >> 1) & 7)
+    const int lp0 = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4);
+    const int pb = lp0 + wr * 16384, qb = lp0 + 32768 + wc * 16384;
+    bf16x8_t f0p[4], f0q[4], f1p[4], f1q[4];
+    acc_zero_all();
+
+    auto rd1 = [&](bf16x8_t (&p)[4], bf16x8_t (&q)[4], int buf, int kk, int i) {
+        if (i < 4) p[i] = *reinterpret_cast<const bf16x8_t*>(smem + buf * KT + ((pb ^ (kk << 5)) + i * 4096));
+        else q[i - 4] = *reinterpret_cast<const bf16x8_t*>(smem + buf * KT + ((qb ^ (kk << 5)) + (i - 4) * 4096));
+    };
+    // one k step: 16 MFMAs on (p, q) with the 8 fragment reads of the next k step and (DM) the 16 LDS-DMA pieces of a tile between them,
+    // in exactly this order (the MFMAs are asm statements: no scheduling group sees them, so every step is fenced)
+    auto kstep = [&](const bf16x8_t (&p)[4], const bf16x8_t (&q)[4], bf16x8_t (&np)[4], bf16x8_t (&nq)[4], auto rdc, int rbuf, int rkk,
+                     auto dmc, int dbuf, int dtau, uint32_t vw, uint32_t va) {
+        constexpr bool RD = decltype(rdc)::value != 0 && !(VAR & 8), DM = decltype(dmc)::value != 0 && !(VAR & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DM && (VAR & 4) != 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) piece(dbuf, dtau, i, vw, va);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        static_for<16>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, i = idx & 3, j = idx >> 2;
+            mfma_acc<j * 4 + i>(p[i], q[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DM && (VAR & 4) == 0) piece(dbuf, dtau, idx, vw, va);
+            if constexpr (RD) { if constexpr ((idx & 1) == 0) rd1(np, nq, rbuf, rkk, idx >> 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // prologue
+#pragma unroll
+    for (int i = 0; i < 16; ++i) piece(0, 0, i, vW, vA);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) piece(1, 1, i, vW, vA);
+        wait_vmcnt<16>();
+    } else wait_vmcnt<0>();
+    bar();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rd1(f0p, f0q, 0, 0, i);
+
+    // every tile runs the same body: beyond the last tile the LDS-DMA pieces carry an out-of-range offset (no fetch, zeros land in
+    // a buffer nobody reads) and the fragment reads of "tile nk" are never used
+    auto tile = [&](auto bc, int t) {
+        constexpr int BF = decltype(bc)::value;
+        kstep(f0p, f0q, f1p, f1q, IC<1>{}, BF, 1, IC<0>{}, 0, 0, 0u, 0u);
+        kstep(f1p, f1q, f0p, f0q, IC<1>{}, BF, 2, IC<0>{}, 0, 0, 0u, 0u);
+        kstep(f0p, f0q, f1p, f1q, IC<1>{}, BF, 3, IC<0>{}, 0, 0, 0u, 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
+        if constexpr ((VAR & 2) == 0) bar();
+        const bool st = t + 2 < nk;
+        kstep(f1p, f1q, f0p, f0q, IC<1>{}, BF ^ 1, 0, IC<1>{}, BF, t + 2, st ? vW : 0x80000000u, st ? vA : 0x80000000u);
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile(IC<0>{}, t);
+        if (t + 1 < nk) tile(IC<1>{}, t + 1);
+    }
+
+    // epilogue: accumulator (i, j): rows n = n0 + wr*128 + i*32 + 8 g + 4 hi + e, column m = m0 + wc*128 + j*32 + l31
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results -> v_accvgpr_read
+    static_for<16>([&](auto bc) {
+        constexpr int b = decltype(bc)::value, i = b & 3, j = b >> 2;
+        const int m = m0 + wc * 128 + j * 32 + l31;
+        static_for<4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int nb = n0 + wr * 128 + i * 32 + 8 * g + 4 * hi;
+            u32x2 ov;
+            ov.x = packbf(acc_read<b * 16 + 4 * g>(), acc_read<b * 16 + 4 * g + 1>());
+            ov.y = packbf(acc_read<b * 16 + 4 * g + 2>(), acc_read<b * 16 + 4 * g + 3>());
+            *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + nb) = ov;
+        });
+    });
+}
+
+
+// ---- v2: the same tile on a ring of five 32 KiB half-tile slots (one operand's 256 rows x 128 B of one k tile; all 160 KiB of LDS), so the
+// LDS-DMA pieces are issued four per k step all the time instead of sixteen in the k step behind the barrier (v1: every wave bursts at
+// once and the CU's one texture-address path serialises them -- that k step takes twice its MFMA time; ablation: 1220 -> 1516 TFLOP/s
+// without the DMA).  Half-tile h = 2 t + o (o = 0 weights, 1 activations) lives in slot h % 5.  Issue windows of a wave, 4 pieces per k step:
+//   k step 3 of tile t-1 and k step 0 of tile t : activations of tile t+1   (slot of W(t-1), free since the barrier of tile t-1)
+//   k steps 1, 2 of tile t                      : weights of tile t+2       (slot of A(t-1))
+// One barrier per tile, ahead of k step 3: every wave has read tile t, and waited for its own pieces of tile t+1 (vmcnt(8): the
+// newest eight -- weights of t+2 -- stay in flight).
+template <int VAR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void w4r_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw, int ldc, unsigned long long* trace) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * 32768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tiles_m = M >> 8, tiles_n = N >> 8, tiles = tiles_m * tiles_n;
+    int wg = blockIdx.x;
+    if ((tiles & 7) == 0 && (tiles_m & 7) == 0 && ((tiles >> 3) & 7) == 0 && tiles_n % ((tiles >> 3) >> 3) == 0) {
+        const int per = tiles >> 3, sup_m = 8, sup_n = per >> 3;
+        const int xcd = wg & 7, r = wg >> 3, bm = tiles_m / sup_m;
+        const int bi = xcd % bm, bj = xcd / bm;
+        wg = (bj * sup_n + r / sup_m) * tiles_m + bi * sup_m + r % sup_m;
+    }
+    const int m0 = (wg % tiles_m) << 8, n0 = (wg / tiles_m) << 8;
+    const int prow = wave * 8 + (lane >> 3);
+    const uint32_t sck = (uint32_t)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);
+    const uint32_t vW = (uint32_t)(n0 + prow) * (uint32_t)ldw * 2u + sck;
+    const uint32_t vA = (uint32_t)(m0 + prow) * (uint32_t)lda * 2u + sck;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (uint32_t)N * (uint32_t)ldw * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (uint32_t)M * (uint32_t)lda * 2u, 0x00020000);
+    auto dma = [&](const __amdgpu_buffer_rsrc_t& r, uint32_t voff, int soff, char* lds_wave_base) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+    };
+    const int nk = K >> 6;
+    const int rsW = 32 * ldw * 2, rsA = 32 * lda * 2;
+    constexpr uint32_t OOB = 0x80000000u;
+    // piece j (0 .. 7) of a half-tile of k tile tau into slot s
+    auto pieceW = [&](int s, int tau, int j, uint32_t v) { if ((VAR & 16) != 0) tau &= 1; dma(rW, v, (tau << 7) + j * rsW, smem + s * 32768 + wave * 1024 + j * 4096); };
+    auto pieceA = [&](int s, int tau, int j, uint32_t v) { if ((VAR & 16) != 0) tau &= 1; dma(rA, v, (tau << 7) + j * rsA, smem + s * 32768 + wave * 1024 + j * 4096); };
+
+    const int lp0 = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4);
+    const int pb = lp0 + wr * 16384, qb = lp0 + wc * 16384;
+    bf16x8_t f0p[4], f0q[4], f1p[4], f1q[4];
+    f32x16_t acc[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    auto rd1 = [&](bf16x8_t (&p)[4], bf16x8_t (&q)[4], int pa, int qa, int i) {
+        if (i < 4) p[i] = *reinterpret_cast<const bf16x8_t*>(smem + (pa + i * 4096));
+        else q[i - 4] = *reinterpret_cast<const bf16x8_t*>(smem + (qa + (i - 4) * 4096));
+    };
+    // one k step: 16 MFMAs; the 8 fragment reads of the next k step after MFMAs 0, 2, .. 14; 4 LDS-DMA pieces after MFMAs 1, 5, 9, 13
+    auto kstep = [&](const bf16x8_t (&p)[4], const bf16x8_t (&q)[4], bf16x8_t (&np)[4], bf16x8_t (&nq)[4], int pa, int qa, auto&& dmaf) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, i = idx & 3, j = idx >> 2;
+            mfma_a(acc[j * 4 + i], p[i], q[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((idx & 3) == 1 && (VAR & 1) == 0) dmaf(IC<(idx >> 2)>{});
+            if constexpr ((idx & 1) == 0 && (VAR & 8) == 0) rd1(np, nq, pa, qa, idx >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // prologue: W(0) -> slot 0, A(0) -> slot 1, W(1) -> slot 2, first half of A(1) -> slot 3
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pieceW(0, 0, j, vW);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pieceA(1, 0, j, vA);
+    {
+        const uint32_t v1w = nk > 1 ? vW : OOB, v1a = nk > 1 ? vA : OOB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pieceW(2, 1, j, v1w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pieceA(3, 1, j, v1a);
+    }
+    if constexpr ((VAR & 1) != 0) {             // ablation: every slot holds real data, nothing is loaded in the loop
+#pragma unroll
+        for (int j = 4; j < 8; ++j) pieceA(3, 1, j, vA);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pieceW(4, 2, j, vW);
+        wait_vmcnt<0>();
+    } else wait_vmcnt<12>();
+    bar();
+    int sW = 0, sA = 1;                         // slots of the tile being consumed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rd1(f0p, f0q, pb, qb + 32768, i);
+    if constexpr ((VAR & 8) != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rd1(f1p, f1q, pb ^ 32, (qb + 32768) ^ 32, i);
+    }
+
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int t = 0; t < nk; ++t) {
+        const int sW1 = sW + 2 >= 5 ? sW - 3 : sW + 2, sA1 = sA + 2 >= 5 ? sA - 3 : sA + 2;     // slots of tile t + 1
+        const int sW2 = sW1 + 2 >= 5 ? sW1 - 3 : sW1 + 2, sA2 = sA1 + 2 >= 5 ? sA1 - 3 : sA1 + 2;
+        const int pa = pb + sW * 32768, qa = qb + sA * 32768;
+        const uint32_t va1 = t + 1 < nk ? vA : OOB, vw2 = t + 2 < nk ? vW : OOB, va2 = t + 2 < nk ? vA : OOB;
+        kstep(f0p, f0q, f1p, f1q, pa ^ 32, qa ^ 32, [&](auto jc) { pieceA(sA1, t + 1, 4 + decltype(jc)::value, va1); });
+        kstep(f1p, f1q, f0p, f0q, pa ^ 64, qa ^ 64, [&](auto jc) { pieceW(sW2, t + 2, decltype(jc)::value, vw2); });
+        kstep(f0p, f0q, f1p, f1q, pa ^ 96, qa ^ 96, [&](auto jc) { pieceW(sW2, t + 2, 4 + decltype(jc)::value, vw2); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<8>();
+        if constexpr ((VAR & 2) == 0) bar();
+        kstep(f1p, f1q, f0p, f0q, pb + sW1 * 32768, qb + sA1 * 32768, [&](auto jc) { pieceA(sA2, t + 2, decltype(jc)::value, va2); });
+        sW = sW1; sA = sA1;
+    }
+
+    if (trace && tid == 0) {
+        trace[blockIdx.x * 2] = __builtin_readcyclecounter() - c0;
+        trace[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    static_for<16>([&](auto bc) {
+        constexpr int b = decltype(bc)::value, i = b & 3, j = b >> 2;
+        const int m = m0 + wc * 128 + j * 32 + l31;
+        static_for<4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const int nb = n0 + wr * 128 + i * 32 + 8 * g + 4 * hi;
+            u32x2 ov;
+            ov.x = packbf(acc[b][4 * g], acc[b][4 * g + 1]);
+            ov.y = packbf(acc[b][4 * g + 2], acc[b][4 * g + 3]);
+            *reinterpret_cast<u32x2*>(C + (size_t)m * ldc + nb) = ov;
+        });
+    });
+}
+
+__global__ void ref_rows_kernel(const bf16_t* A, const bf16_t* W, float* out, const int* rows, int nrows, int N, int K) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (n >= N) return;
+    const bf16_t* a = A + (size_t)rows[r] * K;
+    const bf16_t* w = W + (size_t)n * K;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += __uint_as_float((uint32_t)a[k] << 16) * __uint_as_float((uint32_t)w[k] << 16);
+    out[(size_t)r * N + n] = s;
+}
+
+static bf16_t f2bf_host(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+
+unsigned long long* g_trace = nullptr;
+template <int KERN, int VAR>
+void launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K) {
+    const int tiles = (M >> 8) * (N >> 8);
+    if constexpr (KERN == 0) hipLaunchKernelGGL((w4_kernel<VAR>), dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, K, K, N);
+    else hipLaunchKernelGGL((w4r_kernel<VAR>), dim3(tiles), dim3(256), 0, 0, A, W, C, M, N, K, K, K, N, g_trace);
+}
+template <int KERN, int VAR>
+double run(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, int iters) {
+    for (int i = 0; i < 3; ++i) launch<KERN, VAR>(A, W, C, M, N, K);
+    CK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int round = 0; round < 3; ++round) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) launch<KERN, VAR>(A, W, C, M, N, K);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, (double)ms / iters);
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+    return 2.0 * M * N * K / (best * 1e-3) * 1e-12;
+}
+
+template <int VAR>
+void cycles(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, const char* name) {
+    const int tiles = (M >> 8) * (N >> 8), nk = K >> 6;
+    unsigned long long* d;
+    CK(hipMalloc(&d, (size_t)tiles * 16));
+    for (int i = 0; i < 5; ++i) launch<1, VAR>(A, W, C, M, N, K);
+    g_trace = d;
+    launch<1, VAR>(A, W, C, M, N, K);
+    g_trace = nullptr;
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)tiles * 2);
+    CK(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+    double sc = 0, sr = 0;
+    for (int i = 0; i < tiles; ++i) { sc += (double)h[2 * i]; sr += (double)h[2 * i + 1]; }
+    printf("  %-18s shader cycles per k tile %7.1f (MFMA-bound floor 2048), shader clock %.3f GHz\n", name, sc / tiles / nk, sc / sr * 0.1);
+    CK(hipFree(d));
+}
+
+template <int KERN>
+int check(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K) {
+    const int nrows = 48;
+    std::vector<int> rows(nrows);
+    for (int i = 0; i < nrows; ++i) rows[i] = (int)(((long)i * 2654435761u) % M);
+    rows[0] = 0; rows[1] = M - 1; rows[2] = 255; rows[3] = 256 % M;
+    int* drows; float* dref;
+    CK(hipMalloc(&drows, nrows * 4)); CK(hipMalloc(&dref, (size_t)nrows * N * 4));
+    CK(hipMemcpy(drows, rows.data(), nrows * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dC, 0xff, (size_t)M * N * 2));
+    launch<KERN, 0>(dA, dW, dC, M, N, K);
+    hipLaunchKernelGGL(ref_rows_kernel, dim3((N + 255) / 256, nrows), dim3(256), 0, 0, dA, dW, dref, drows, nrows, N, K);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ref((size_t)nrows * N);
+    std::vector<bf16_t> got((size_t)N);
+    CK(hipMemcpy(ref.data(), dref, ref.size() * 4, hipMemcpyDeviceToHost));
+    int bad = 0; double maxerr = 0, maxref = 0;
+    for (int r = 0; r < nrows; ++r) {
+        CK(hipMemcpy(got.data(), dC + (size_t)rows[r] * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            uint32_t u = (uint32_t)got[n] << 16; float g; memcpy(&g, &u, 4);
+            const double e = fabs((double)g - ref[(size_t)r * N + n]);
+            maxerr = std::max(maxerr, e); maxref = std::max(maxref, (double)fabs(ref[(size_t)r * N + n]));
+            if (!(e <= 1e-2 * fabs(ref[(size_t)r * N + n]) + 2e-2 * sqrt((double)K) * 0.33 * 0.02 + 1e-3)) ++bad;
+        }
+    }
+    printf("kernel %d check M=%d N=%d K=%d: %d bad of %d, max err %.4g (max |ref| %.4g)\n", KERN, M, N, K, bad, nrows * N, maxerr, maxref);
+    CK(hipFree(drows)); CK(hipFree(dref));
+    return bad;
+}
+
+int main(int argc, char** argv) {
+    std::vector<std::array<int, 3>> shapes = {{512, 512, 256}, {768, 1024, 192}, {1024, 512, 64}, {4096, 4096, 4096}, {8192, 8192, 8192}, {1536, 35840, 6656}, {2048, 10240, 1280}};
+    const size_t maxA = (size_t)8192 * 8192, maxW = (size_t)35840 * 8192;
+    bf16_t *dA, *dW, *dC;
+    CK(hipMalloc(&dA, maxA * 2)); CK(hipMalloc(&dW, maxW * 2)); CK(hipMalloc(&dC, maxW * 2));
+    {
+        std::vector<bf16_t> h(maxW);
+        uint64_t s = 88172645463325252ull;
+        auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (float)((s >> 40) & 0xffffff) / 8388608.0f - 1.0f; };
+        for (size_t i = 0; i < maxA; ++i) h[i] = f2bf_host(rnd());
+        CK(hipMemcpy(dA, h.data(), maxA * 2, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < maxW; ++i) h[i] = f2bf_host(rnd() * 0.02f);
+        CK(hipMemcpy(dW, h.data(), maxW * 2, hipMemcpyHostToDevice));
+    }
+    int bad = 0;
+    for (auto& s : shapes) { bad += check<0>(dA, dW, dC, s[0], s[1], s[2]); bad += check<1>(dA, dW, dC, s[0], s[1], s[2]); }
+    for (int rep = 0; rep < 2; ++rep)
+    for (auto& s : shapes) {
+        if ((long)s[0] * s[1] * s[2] < (1l << 32)) continue;
+        const int M = s[0], N = s[1], K = s[2], it = 10;
+        printf("M=%5d N=%5d K=%5d  v1 %7.1f   v2 (ring of 5): full %7.1f | noDMA %7.1f | hotDMA %7.1f | noBAR %7.1f | noRD %7.1f | noDMA+noBAR %7.1f | noDMA+noRD %7.1f | noDMA+noBAR+noRD %7.1f\n", M, N, K,
+               run<0, 0>(dA, dW, dC, M, N, K, it),
+               run<1, 0>(dA, dW, dC, M, N, K, it), run<1, 1>(dA, dW, dC, M, N, K, it), run<1, 16>(dA, dW, dC, M, N, K, it), run<1, 2>(dA, dW, dC, M, N, K, it),
+               run<1, 8>(dA, dW, dC, M, N, K, it), run<1, 3>(dA, dW, dC, M, N, K, it), run<1, 9>(dA, dW, dC, M, N, K, it), run<1, 11>(dA, dW, dC, M, N, K, it));
+        if (rep == 1) {
+            cycles<0>(dA, dW, dC, M, N, K, "full"); cycles<1>(dA, dW, dC, M, N, K, "noDMA"); cycles<2>(dA, dW, dC, M, N, K, "noBAR"); cycles<8>(dA, dW, dC, M, N, K, "noRD");
+            cycles<9>(dA, dW, dC, M, N, K, "noDMA+noRD"); cycles<11>(dA, dW, dC, M, N, K, "noDMA+noBAR+noRD");
+        }
+        fflush(stdout);
+    }
+    printf(bad ? "FAILED\n" : "OK\n");
+    return bad != 0;
+}
