@@ -791,7 +791,16 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     // the main launch: the four-wave tile on its LDS ring (gemm_w4.hip) for bf16 operands; this file's eight-wave ping-pong tile for
     // fp8 operands and, as the A/B twin, under emu_gemm_tune bit 21.  Same tile order, K-slices and slab layout: the reduce launches
     // below serve both.
-    const bool w4 = !F8 && !(emu_gemm_tune_get() & (1 << 21));
+    // Where the four-wave tile is taken (same-run A/B, profiles/r06_gemm_w4_*.log): whole-K launches whose tiles all leave through the
+    // staged epilogue, with a light epilogue.  Its one wave per SIMD issues the scattered stores of the direct path -- fp32 K-slices,
+    // tiles that reach past N -- at half the ping-pong tile's rate (S = 770 o_proj 731 vs 824 TFLOP/s), and nothing overlaps the
+    // dependent VALU chains of an erf: behind a GELU / GEGLU epilogue (ViT fc1, the UNet's GEGLU with its folded LayerNorm) the
+    // faster loop loses in the model (same-run: ViT encode 15.93 vs 15.39 ms, denoise step 26.64 vs 25.11 ms with those launches on it;
+    // LLaMA prefill S = 770 49.07 vs 51.35 ms).  emu_gemm_tune bit 22 takes it wherever it is instantiated (tests).
+    constexpr bool ACT = EPI == EPI_GELU || EPI == EPI_GEGLU;
+    const int tune = emu_gemm_tune_get();
+    const bool w4 = !F8 && !(tune & (1 << 21)) &&
+                    ((tune & (1 << 22)) || (tail == 0 && (a.N & 255) == 0 && !ACT && !(gemm_fx(b) & FX_LN)));
     const int grid = b.full_tiles + tail * ksplit;
     if (fx & FX_ROPE) {                                 // launch_gemm: EPI_NONE, unsliced, bf16 (launch_v2 checks the plan)
         if constexpr (!CONV && !F8 && EPI == EPI_NONE) {

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
-CFGS = ["B", "C", "S", "K", "P", "Q", "H", "0"]
+CFGS = ["B", "C", "S", "K", "P", "Q", "H", "0", "W"]     # "W": 'P' with the four-wave tile taken everywhere (emu_gemm_tune bit 22)
 
 
 @pytest.fixture()
@@ -24,8 +24,12 @@ def force():
     L = lib()
     sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")
     L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
-    yield lambda c: L.emu_gemm_force_config(0 if c == "0" else ord(c))
+    def set_cfg(c):
+        L.emu_gemm_tune((1 << 22) if c == "W" else 0)
+        L.emu_gemm_force_config(0 if c == "0" else ord("P" if c == "W" else c))
+    yield set_cfg
     L.emu_gemm_force_config(0)
+    L.emu_gemm_tune(0)
     L.emu_set_splitk_scratch(0, 0)
 
 

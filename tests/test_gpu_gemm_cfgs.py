@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
-CFGS = ["B", "C", "S", "K", "P", "Q", "H", "0"]
+CFGS = ["B", "C", "S", "K", "P", "Q", "H", "0", "W"]     # "W": 'P' with the four-wave tile taken everywhere (emu_gemm_tune bit 22)
 
 
 def bfr(t):
@@ -40,8 +40,12 @@ def force():
     L = lib()
     sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")     # split-K scratch, as the engines carry
     L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
-    yield lambda c: L.emu_gemm_force_config(0 if c == "0" else ord(c))
+    def set_cfg(c):
+        L.emu_gemm_tune((1 << 22) if c == "W" else 0)
+        L.emu_gemm_force_config(0 if c == "0" else ord("P" if c == "W" else c))
+    yield set_cfg
     L.emu_gemm_force_config(0)
+    L.emu_gemm_tune(0)
     L.emu_set_splitk_scratch(0, 0)
 
 
@@ -149,7 +153,7 @@ def test_staged_epilogue_is_bit_identical_to_the_direct_one(force, M, N, K, epis
                 force(cfg)
                 outs = []
                 for tune in (8, 0):
-                    L.emu_gemm_tune(tune)
+                    L.emu_gemm_tune(tune | ((1 << 22) if cfg == "W" else 0))
                     buf = torch.full((M, nout + 8), float("nan"), dtype=BF16, device="cuda")
                     out = buf[:, :nout]
                     ops.linear(x, w, bias=bias, res=res, epi=epi, out=out)
@@ -177,7 +181,7 @@ def test_staged_conv_epilogue_is_bit_identical_to_the_direct_one(force, B, H, Ci
             force(cfg)
             outs = []
             for tune in (8, 0):
-                L.emu_gemm_tune(tune)
+                L.emu_gemm_tune(tune | ((1 << 22) if cfg == "W" else 0))
                 outs.append(ops.conv3x3_nhwc(x, w, bias=bias, bias2=b2, res=res, mode=mode).clone())
             assert torch.equal(outs[0], outs[1]), f"conv cfg {cfg} mode {mode}: staged != direct"
     finally:
