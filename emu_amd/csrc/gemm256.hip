@@ -536,7 +536,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs a) {
     // Staged epilogue (gemm_tile.h::EpiStage): the 256 x 256 results leave through the (now dead) k-tile ring as whole rows
     constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
     using Stage = EpiStage<256, GLU ? 128 : 256, 512>;
-    bool staged = a.stage && nsl == 1 && n0 + 256 <= a.N;
+    bool staged = (a.stage & 1) != 0 && nsl == 1 && n0 + 256 <= a.N;
     bool vt_tile = false;                              // a whole tile of V columns: transposed staging (gemm_tile.h::EpiStageT)
     if constexpr ((FX & FX_VT) != 0) {
         vt_tile = staged && a.stage_vt && n0 >= a.vt_col0;
@@ -772,6 +772,7 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     b.trace = emu_gemm_trace_get();
     b.stage = stage_ok(b) && !(emu_gemm_tune_get() & 8);
     b.stage_vt = b.stage && stage_vt_ok(b, 256, 256) && !(emu_gemm_tune_get() & (1 << 14));
+    if (!(emu_gemm_tune_get() & (1 << 23))) b.stage |= 2;            // four-wave tile: fp32 K-slices leave through LDS too (bit 23: A/B)
     // XCD-aware 2-D tile blocks (gemm.hip::launch_cfg has the rule): unsliced plain GEMMs whose tile count splits evenly over the 8
     // XCDs; the implicit-GEMM convs keep the column-major strips (one weight tile of K = 9 Cin per strip is what their L2 can hold)
     b.sup_m = b.sup_n = 0;
@@ -791,16 +792,19 @@ void launch_pp(const GemmArgs& a, hipStream_t s, int full_tiles, int ksplit) {
     // the main launch: the four-wave tile on its LDS ring (gemm_w4.hip) for bf16 operands; this file's eight-wave ping-pong tile for
     // fp8 operands and, as the A/B twin, under emu_gemm_tune bit 21.  Same tile order, K-slices and slab layout: the reduce launches
     // below serve both.
-    // Where the four-wave tile is taken (same-run A/B, profiles/r06_gemm_w4_*.log): whole-K launches whose tiles all leave through the
-    // staged epilogue, with a light epilogue.  Its one wave per SIMD issues the scattered stores of the direct path -- fp32 K-slices,
-    // tiles that reach past N -- at half the ping-pong tile's rate (S = 770 o_proj 731 vs 824 TFLOP/s), and nothing overlaps the
-    // dependent VALU chains of an erf: behind a GELU / GEGLU epilogue (ViT fc1, the UNet's GEGLU with its folded LayerNorm) the
-    // faster loop loses in the model (same-run: ViT encode 15.93 vs 15.39 ms, denoise step 26.64 vs 25.11 ms with those launches on it;
-    // LLaMA prefill S = 770 49.07 vs 51.35 ms).  emu_gemm_tune bit 22 takes it wherever it is instantiated (tests).
+    // Where the four-wave tile is taken (same-run A/B, profiles/r06_gemm_w4_*.log): plain GEMMs whose tiles all lie inside N (they
+    // leave through LDS: bf16 results and fp32 K-slices alike; a tile that reaches past N takes the direct path, whose scattered
+    // stores its one wave per SIMD issues at half the ping-pong tile's rate) with a light epilogue: nothing overlaps the dependent
+    // VALU chains of an erf on one wave per SIMD, and behind a GELU / GEGLU epilogue (ViT fc1, the UNet's GEGLU with its folded
+    // LayerNorm) the faster loop loses in the model (same-run: ViT encode 15.93 vs 15.39 ms, denoise step 26.64 vs 25.11 ms with those
+    // launches on it; LLaMA prefill S = 770 49.07 vs 51.35 ms).  K-slices shorter than 16 k tiles do not amortise the ring's prologue
+    // (UNet 32^2 attn-out 172 vs 198 TFLOP/s), the implicit-GEMM convs' per-row bias loads cost it more (661 vs 739).
+    // emu_gemm_tune bit 22 takes it wherever it is instantiated (tests).
     constexpr bool ACT = EPI == EPI_GELU || EPI == EPI_GEGLU;
     const int tune = emu_gemm_tune_get();
     const bool w4 = !F8 && !(tune & (1 << 21)) &&
-                    ((tune & (1 << 22)) || (tail == 0 && (a.N & 255) == 0 && !ACT && !(gemm_fx(b) & FX_LN)));
+                    ((tune & (1 << 22)) || (!CONV && (a.N & 255) == 0 && !ACT && !(gemm_fx(b) & FX_LN) &&
+                                            (tail == 0 || (a.K >> 6) / ksplit >= 16)));
     const int grid = b.full_tiles + tail * ksplit;
     if (fx & FX_ROPE) {                                 // launch_gemm: EPI_NONE, unsliced, bf16 (launch_v2 checks the plan)
         if constexpr (!CONV && !F8 && EPI == EPI_NONE) {

@@ -525,10 +525,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return;
     }
 
+    // ---- K-slice of a tile that lies inside N: the raw fp32 tile leaves through LDS as well, 128 columns at a time (256 rows x 512 B
+    // = 128 KiB).  The waves that own the half (wr) drop their accumulator quads as 16-byte LDS writes, the 16-byte slot of a row XORed
+    // with the row (32 lanes = 32 rows would otherwise share a bank); then all four waves store whole 512-byte row segments.  Against
+    // 16 bytes per lane to 32 different rows straight from the accumulators: a quarter of the store instructions, every one of them
+    // coalesced (S = 770 o_proj, same-run: profiles/r06_gemm_w4_sliced_ab.log).
+    const bool slab_stage = (a.stage & 2) != 0 && nsl > 1 && n0 + 256 <= a.N;
+    if (slab_stage) {
+        float* sbase = a.slab_rows ? a.partial + ((size_t)ks * a.M + m0) * a.N + n0
+                                   : a.partial + ((size_t)(wg - a.full_tiles) * nsl + ks) * SLICE;
+        const size_t sld = a.slab_rows ? (size_t)a.N : 256;
+        __syncthreads();                               // every wave is out of the loop
+        static_for<2>([&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            if (wr == H) {
+                static_for<4>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    const int row = wc * 128 + J * 32 + l31;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            f32x16_t t = acc[J * 4 + 2 * x + i];
+                            asm volatile("" : "+v"(t));
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int slot = x * 16 + i * 8 + 2 * g + hi;
+                                *reinterpret_cast<f32x4_t*>(smem + row * 512 + ((slot ^ (row & 31)) << 4)) =
+                                    f32x4_t{t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+                            }
+                        }
+                });
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int idx = r * 256 + tid, row = idx >> 5, ls = (idx & 31) ^ (row & 31);
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + idx * 16);
+                if (m0 + row < a.M) *reinterpret_cast<f32x4_t*>(sbase + (size_t)row * sld + H * 128 + ls * 4) = v;
+            }
+            __syncthreads();
+        });
+    }
+
     // ---- staged epilogue (gemm_tile.h::EpiStage): the 256 x 256 results leave through the (now dead) ring as whole rows
     constexpr bool GLU = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
     using Stage = EpiStage<256, GLU ? 128 : 256, 256>;
-    bool staged = a.stage && nsl == 1 && n0 + 256 <= a.N;
+    bool staged = (a.stage & 1) != 0 && nsl == 1 && n0 + 256 <= a.N;
     bool vt_tile = false;                              // a whole tile of V columns: transposed staging (gemm_tile.h::EpiStageT)
     if constexpr ((FX & FX_VT) != 0) {
         vt_tile = staged && a.stage_vt && n0 >= a.vt_col0;
@@ -597,7 +640,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     f32x16_t h[2][2];                                  // [x][i] of row block j = accumulator block 4 j + 2 x + i
 #pragma clang loop unroll(disable)
-    for (int j = 0; j < 4; ++j) {
+    for (int j = slab_stage ? 4 : 0; j < 4; ++j) {
         RowFx fx;
         auto pick = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
