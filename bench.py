@@ -66,7 +66,7 @@ def gemm_source_hash():
     """sha256 over the sources of the MFMA GEMM kernels: the prefill leg's PMC traffic ratio is only quoted for exactly this code."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm256.hip", "gemm_tile.h", "common.h"):
+    for f in ("gemm.hip", "gemm256.hip", "gemm_w4.hip", "gemm_tile.h", "common.h"):
         h.update(open(os.path.join(ROOT, "emu_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -1,40 +1,52 @@
-// 256(n) x 256(m) x 64(k) bf16 MFMA GEMM tile on FOUR waves -- one per SIMD, 256 fp32 accumulators each in named AGPRs -- fed by a
-// ring of five 32 KiB LDS slots.  The main loop of the MFMA-bound shapes of the path since round 6 (LLaMA prefill, ViT blocks, the
-// UNet's large GEMMs and implicit-GEMM convs); gemm256.hip's 8-wave ping-pong tile stays for fp8 operands and as the A/B twin
-// (emu_gemm_tune bit 21).  C[m, n] = epilogue(sum_k A[m, k] W[n, k]).
+// 256(n) x 256(m) x 64(k) bf16 MFMA GEMM tile on FOUR waves -- one per SIMD, 256 fp32 accumulators each in AGPRs -- fed by a ring of
+// five 32 KiB LDS slots.  Round 6's main loop for the large, light-epilogue GEMMs of the path (LLaMA prefill: qkv with the RoPE / KV /
+// V^T epilogue, gate/up, the K-sliced o_proj / down_proj); gemm256.hip's 8-wave ping-pong tile keeps fp8 operands, the GELU / GEGLU /
+// folded-LayerNorm epilogues, convs and tiles that reach past N (launch_pp has the rule and the measurements), and is the A/B twin
+// everywhere (emu_gemm_tune bit 21; bit 22 takes this tile wherever it is instantiated).  C[m, n] = epilogue(sum_k A[m, k] W[n, k]).
 //
 // Why four waves: a wave that owns 128(n) x 128(m) of the tile reads (128 + 128) x 128 B = 32 KiB of fragments per k tile, 128 KiB
 // per CU; the eight waves of the ping-pong tile (128 x 64 each) read 192 KiB, and on this chip the matrix pipe is power-limited: at
-// 8192^3 a bare MFMA stream on random operands holds 1.73 GHz (1600 TFLOP/s), every LDS byte moved beside it costs clock.  Why named
-// AGPRs: with 256 accumulator registers behind the MFMA builtins hipcc parks fragments in AGPRs and shuffles accumulators through
-// v_accvgpr moves and scratch (84 .. 1020 spills, whatever the constraints: tools/probe/gemm_w4_probe.hip has the history); the MFMAs
-// here are asm statements on a[16 b .. 16 b + 15], block b = 4 j + i = (32 weight rows i, 32 activation rows j) of the wave's tile, the
-// kernel's VGPR demand stays under 128, and nothing else ever touches an AGPR (audit: no v_accvgpr_* outside ASMSTART / ASMEND,
-// .vgpr_spill_count 0).  Because an asm statement is opaque to the scheduler, the order of the loop is pinned instruction by
-// instruction with sched_barrier(0): per k step 16 MFMAs, the 8 ds_read_b128 of the NEXT k step's fragments behind MFMAs 0, 2, .. 14
-// (two fragment sets, 64 VGPRs) and 4 LDS-DMA pieces behind MFMAs 1, 5, 9, 13.
+// 8192^3 a bare MFMA stream on random operands holds 1.73 GHz (1600 TFLOP/s), every LDS byte moved beside it costs clock
+// (profiles/r06_gemm_w4_probe_ablations_cycles_clock.log).  One wave per SIMD overlaps its own ds_reads / LDS-DMA with its own MFMAs.
+//
+// Accumulators.  The MFMAs are asm statements with the register CLASSES in their constraints -- accumulators "a", fragments "v".
+// Behind the MFMA builtins, whose operands may live in either file, hipcc parks fragments in AGPRs and shuffles the 256 accumulator
+// registers through v_accvgpr moves and scratch (84 .. 1020 spills); with literal register names (a[0:15] ...) it does not know they
+// are live and spills INTO them in the epilogue (both tried: tools/probe/gemm_w4_probe.hip, tools/w4_audit.py).  With the classes
+// fixed it allocates 16 x 16 AGPRs once and never moves them.  An asm statement is opaque to the scheduler, so the order of the loop
+// is pinned instruction by instruction with sched_barrier(0): per k step 16 MFMAs, the 8 ds_read_b128 of the NEXT k step's fragments
+// behind MFMAs 0, 2, .. 14 (two fragment sets, 64 VGPRs) and 4 LDS-DMA pieces behind MFMAs 1, 5, 9, 13.
 //
 // The ring.  Half-tile h = 2 t + o (o = 0: the 256 weight rows, 1: the 256 activation rows of k tile t; 128 B per row, the 16-byte
-// slot ^= (row >> 1) & 7 swizzle on the DMA source as in gemm256.hip) lives in slot h % 5.  A wave issues 8 of a half-tile's 32 pieces
-// (piece p = wave + 4 j: rows 8 p .. 8 p + 7), FOUR PER K STEP ALL THE TIME:
+// slot ^= (row >> 1) & 7 swizzle on the DMA source as in gemm256.hip) lives in slot h % 5; the tile loop is unrolled over the five
+// ring positions, so every LDS address is a constant (one s_mov into m0 per piece, one running s_add for the source offset).  A wave
+// issues 8 of a half-tile's 32 pieces (piece p = wave + 4 j: rows 8 p .. 8 p + 7), FOUR PER K STEP ALL THE TIME:
 //     k step 3 of tile t-1, k step 0 of tile t : activations of tile t+1   (slot of W(t-1), free since the barrier of tile t-1)
 //     k steps 1, 2 of tile t                   : weights of tile t+2       (slot of A(t-1))
 // A first version with two 64 KiB buffers issued a tile's 16 pieces per wave in the k step behind the barrier: every wave bursts at
 // once, the CU's single texture-address path serialises 64 instructions, and that k step takes twice its MFMA time (1225 TFLOP/s at
-// 8192^3; this ring 1338 with the probe's direct epilogue; the ping-pong tile 1239).  ONE barrier per k tile, ahead of k step 3: by
-// then every wave has read tile t's last fragments (lgkmcnt(0)) and waited for its own pieces of tile t+1 (vmcnt(8): the newest
-// eight -- weights of t+2 -- stay in flight).  Beyond the last k tile the pieces carry an out-of-range offset (no fetch) and the
-// fragment reads of "tile nk" are never used, so every tile runs the same instruction stream.  Measured in the loop: 2250 shader
-// cycles per k tile against the MFMA floor of 2048 (barrier ~60, reads ~90, DMA ~100), at 1.585 GHz.
+// 8192^3; this ring 1338 with the probe's direct epilogue, 1408-1427 here; the ping-pong tile 1239-1326).  ONE barrier per k tile,
+// ahead of k step 3: by then every wave has read tile t's last fragments (lgkmcnt(0)) and waited for its own pieces of tile t+1
+// (vmcnt(8): the newest eight -- weights of t+2 -- stay in flight).  Beyond the last k tile the pieces carry an out-of-range offset
+// (no fetch) and the fragment reads of "tile nk" are never used, so every tile runs the same instruction stream.  Measured in the
+// loop: 2250 shader cycles per k tile against the MFMA floor of 2048 (barrier ~60, reads ~90, DMA ~100), at 1.585 GHz.
+// Scalar work belongs IN the MFMA gaps: left to itself hipcc emits the address arithmetic of a tile's sixteen pieces (~60 SALU) ahead
+// of the tile's first fenced region, where no MFMA covers it (10 % of the loop); running offsets pass through an empty asm per gap.
 //
 // Ragged M ("extension", as gemm256.hip): when 0 < M mod 256 <= 16 the last row of tiles carries the remainder rows itself.  There is
 // no LDS left for them, and they need none: every wave loads the rows' 16x16x32 fragments straight from global memory (2 KiB per k
 // tile, the same for all waves: L1 hits), two k tiles ahead, with asm loads counted by hand beside the LDS-DMA stream, and multiplies
 // them with its 64 weight rows (re-read in the 16-row layout: 8 ds_read_b128 and 8 v_mfma_f32_16x16x32_bf16 per k tile, +6 %).
 //
-// Epilogue: gemm256.hip's, run twice (a wave's tile = two 128 x 64 halves of the ping-pong tile's wave geometry); accumulators come
-// out of the AGPRs one half at a time.  Replaces the same reference calls as gemm.hip (torch Linear / Conv2d on the ViT,
-// LLaMA-prefill and UNet paths: eva_vit.py:402-431, emu.py:213-229, diffusion.py:130-149).
+// Epilogue: gemm256.hip's arithmetic and rounding points (bit-identical results: tests/test_gpu_gemm_cfgs.py config "W"), re-cut for
+// one wave per SIMD, where nothing hides a dependent round trip: the column operands of the wave's 128 columns and the row statistics
+// of its rows are fetched once, branch-free (a per-quad `if (nb < N)` made hipcc wait for every load inside its own branch: sixteen
+// serialised L2 round trips, 10 of a 15 us epilogue); a run-time loop walks the four 32-row blocks (the body exists once: two unrolled
+// halves were 180-320 KB of code and ran at the speed of their instruction fetch), loop-invariant inputs passing through empty asm
+// statements so that LICM does not hoist several hundred registers' worth of derived values; bf16 results AND fp32 K-slices leave
+// through the dead ring as whole rows.  What stays slower than on the ping-pong tile: VALU-heavy epilogues (GELU / GEGLU: no second
+// wave on the SIMD to overlap the erf's dependent chains) and the direct (unstaged) store path.
+// Replaces the same reference calls as gemm.hip (torch Linear on the LLaMA-prefill path: emu.py:213-229).
 #include <utility>
 
 #include "gemm_tile.h"
@@ -386,9 +398,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 5; ++i) asm volatile("" ::"v"(xf[i][0]), "v"(xf[i][1]));
 
-    // ================= epilogue (gemm256.hip's, per 128(n) x 64(m) half mh of the wave's tile) =================
-    // half mh, accumulator (x, y, i) = block (2 mh + y) * 4 + 2 x + i: rows n = n0 + wr*128 + x*64 + i*32 + 8 g + 4 hi + e,
-    // column m = m0 + wq*64 + y*32 + l31 with wq = 2 wc + mh
+    // ================= epilogue =================
+    // accumulator block 4 j + i' holds rows n = n0 + wr*128 + i'*32 + 8 g + 4 hi + e (register 4 g + e), column m = m0 + wc*128 + j*32 + l31.
+    // load_half (the RoPE epilogue's form): half mh as gemm256.hip's (x, y, i) = block (2 mh + y) * 4 + 2 x + i, wq = 2 wc + mh
     auto load_half = [&](auto mhc, f32x16_t (&h)[2][2][2]) {
         constexpr int mh = decltype(mhc)::value;
 #pragma unroll

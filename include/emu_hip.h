@@ -86,7 +86,10 @@ void emu_gemm_force_config(int cfg);
  * down; bits 8-11: variant of the thin stream (tools/thin_ab.py); bit 16: no successor-weight prefetch from inside the GEMM kernels;
  * bit 17: the 256 x 256 tile keeps the column-major XCD runs instead of 2-D tile blocks per XCD (unsliced plain GEMMs), bit 18: blocks
  * only for launches of more than one round; bit 19 (opt-in): a short tensor-parallel shard's one-row step merges the decode
- * attention's splits in the o_proj launch's prologue instead of a combine launch ahead of it (gemv_merge.hip: bit-identical, measured level). */
+ * attention's splits in the o_proj launch's prologue instead of a combine launch ahead of it (gemv_merge.hip: bit-identical, measured level);
+ * bits 21-23 (round 6, the four-wave 256x256 tile of gemm_w4.hip): 21 = never take it (the eight-wave ping-pong tile everywhere: the
+ * same-run A/B twin), 22 = take it wherever it is instantiated (tests: bf16 plain GEMMs and convs of the 256x256 configuration,
+ * whatever epilogue, slices and raggedness), 23 = its fp32 K-slices leave by direct stores instead of through LDS. */
 void emu_gemm_tune(int mask);
 
 /* Tools hook (tools/gemm_trace.py): per-workgroup timelines of the following GEMM launches -- 8 x uint64 per workgroup at

@@ -17,7 +17,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if row["Counter_Name"] == "FETCH_SIZE" and ("gemm_pp_kernel" in k or "gemm2_kernel" in k or "reduce_kernel" in k):
+        if row["Counter_Name"] == "FETCH_SIZE" and ("gemm_pp_kernel" in k or "gemm_w4_kernel" in k or "gemm2_kernel" in k or "reduce_kernel" in k):
             acc[k].append(float(row["Counter_Value"]))
 bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 n = bench["pmc_prefill_calls"]
