@@ -3,9 +3,11 @@
 set -x
 R=$(pwd)
 mkdir -p gpurun_out
-python -m pytest tests -q -m gpu 2>&1 | tail -4 > gpurun_out/r06_gpu_suite_final.log; cat gpurun_out/r06_gpu_suite_final.log
+python -m pytest tests -q -m gpu 2>&1 | grep -E 'passed|failed|error' | tail -3 > gpurun_out/r06_gpu_suite_final.log; cat gpurun_out/r06_gpu_suite_final.log
 bash tools/pmc_traffic.sh > gpurun_out/r6_final_pmc_gemv.log 2>&1; tail -n 3 gpurun_out/r6_final_pmc_gemv.log
+cp gpurun_out/r06_gemv_pmc_traffic.json profiles/ 2>/dev/null
 bash tools/pmc_prefill_traffic.sh > gpurun_out/r6_final_pmc_prefill.log 2>&1; tail -n 3 gpurun_out/r6_final_pmc_prefill.log
+cp gpurun_out/r06_prefill_gemm_pmc_traffic.json profiles/ 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dn -- python $R/bench.py --only-denoise --denoise-steps 12 --no-fp8 > $R/gpurun_out/r6_final_denoise_bench.json 2> $R/gpurun_out/r6_final_denoise.err
 python $R/tools/kernel_stats.py /tmp/prof_dn 60 > $R/gpurun_out/r06_denoise_kernel_stats.csv
