@@ -186,3 +186,33 @@ def test_staged_conv_epilogue_is_bit_identical_to_the_direct_one(force, B, H, Ci
             assert torch.equal(outs[0], outs[1]), f"conv cfg {cfg} mode {mode}: staged != direct"
     finally:
         L.emu_gemm_tune(0)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(770, 1536, 6656, 1), (770, 1536, 17920, 1), (1544, 1536, 17920, 0), (1025, 1792, 15360, 1),
+                                       (544, 768, 4096, 1), (2048, 1280, 5120, 1)])
+def test_four_wave_tile_slices_through_lds_equal_direct_slices_and_the_ping_pong_tile(M, N, K, epi):
+    """Round 6 (gemm_w4.hip): the fp32 K-slices of the four-wave 256 x 256 tile leave through LDS, 128 columns at a time, as whole
+    512-byte row segments (emu_gemm_tune bit 23 = direct 16-byte stores from the accumulators instead).  Same values, same slab
+    layout, same reduce launch: the bits of the direct form -- and of the eight-wave ping-pong tile (bit 21), whose k order and
+    rounding points the new tile keeps -- on the S = 770 / 1544 o_proj / down_proj shapes (remainder rows included), the ViT's fc2 and
+    the UNet's ff-out."""
+    from emu_amd import ops
+    from emu_amd._lib import lib
+    L = lib()
+    sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")
+    L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
+    x, w = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5)
+    bias, res = rnd(N, seed=53), (rnd(M, N, seed=54) if epi == 1 else None)
+    try:
+        L.emu_gemm_force_config(ord("P"))
+        outs = []
+        for tune in ((1 << 22), (1 << 22) | (1 << 23), (1 << 21)):
+            L.emu_gemm_tune(tune)
+            outs.append(ops.linear(x, w, bias=bias, res=res, epi=epi).clone())
+        assert torch.equal(outs[0], outs[1]), f"M{M} N{N} K{K}: slices through LDS != direct slices ({int((outs[0] != outs[1]).sum())} elements)"
+        assert torch.equal(outs[0], outs[2]), f"M{M} N{N} K{K}: four-wave tile != ping-pong tile ({int((outs[0] != outs[2]).sum())} elements)"
+        check(outs[0], ref_linear(x, w, bias, res, epi), f"four-wave sliced M{M} N{N} K{K}")
+    finally:
+        L.emu_gemm_tune(0)
+        L.emu_gemm_force_config(0)
+        L.emu_set_splitk_scratch(0, 0)
