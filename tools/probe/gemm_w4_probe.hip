@@ -249,8 +249,26 @@ void w4r_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16
             constexpr int idx = decltype(ic)::value, i = idx & 3, j = idx >> 2;
             mfma_a(acc[j * 4 + i], p[i], q[j]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((idx & 3) == 1 && (VAR & 1) == 0) dmaf(IC<(idx >> 2)>{});
-            if constexpr ((idx & 1) == 0 && (VAR & 8) == 0) rd1(np, nq, pa, qa, idx >> 1);
+            if constexpr ((idx & 3) == ((VAR & 32) ? 3 : 1) && (VAR & 1) == 0) dmaf(IC<(idx >> 2)>{});
+            if constexpr ((VAR & 64) != 0) { if constexpr (idx < 8 && (VAR & 8) == 0) rd1(np, nq, pa, qa, idx); }
+            else { if constexpr ((idx & 1) == 0 && (VAR & 8) == 0) rd1(np, nq, pa, qa, idx >> 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // VAR & 128: k step 3 with the barrier behind its first four MFMAs (the next tile's reads and this k step's pieces after it)
+    auto kstep3_late = [&](const bf16x8_t (&p)[4], const bf16x8_t (&q)[4], bf16x8_t (&np)[4], bf16x8_t (&nq)[4], int pa, int qa, auto&& dmaf) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, i = idx & 3, j = idx >> 2;
+            if constexpr (idx == 4) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vmcnt<8>();
+                bar();
+            }
+            mfma_a(acc[j * 4 + i], p[i], q[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (idx >= 5 && idx <= 14 && (idx - 5) % 3 == 0) dmaf(IC<(idx - 5) / 3>{});
+            if constexpr (idx >= 4 && idx < 12) rd1(np, nq, pa, qa, idx - 4);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -292,10 +310,14 @@ void w4r_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16
         kstep(f0p, f0q, f1p, f1q, pa ^ 32, qa ^ 32, [&](auto jc) { pieceA(sA1, t + 1, 4 + decltype(jc)::value, va1); });
         kstep(f1p, f1q, f0p, f0q, pa ^ 64, qa ^ 64, [&](auto jc) { pieceW(sW2, t + 2, decltype(jc)::value, vw2); });
         kstep(f0p, f0q, f1p, f1q, pa ^ 96, qa ^ 96, [&](auto jc) { pieceW(sW2, t + 2, 4 + decltype(jc)::value, vw2); });
+        if constexpr ((VAR & 128) != 0) {
+            kstep3_late(f1p, f1q, f0p, f0q, pb + sW1 * 32768, qb + sA1 * 32768, [&](auto jc) { pieceA(sA2, t + 2, decltype(jc)::value, va2); });
+        } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vmcnt<8>();
         if constexpr ((VAR & 2) == 0) bar();
         kstep(f1p, f1q, f0p, f0q, pb + sW1 * 32768, qb + sA1 * 32768, [&](auto jc) { pieceA(sA2, t + 2, decltype(jc)::value, va2); });
+        }
         sW = sW1; sA = sA1;
     }
 
@@ -425,13 +447,11 @@ int main(int argc, char** argv) {
     for (auto& s : shapes) {
         if ((long)s[0] * s[1] * s[2] < (1l << 32)) continue;
         const int M = s[0], N = s[1], K = s[2], it = 10;
-        printf("M=%5d N=%5d K=%5d  v1 %7.1f   v2 (ring of 5): full %7.1f | noDMA %7.1f | hotDMA %7.1f | noBAR %7.1f | noRD %7.1f | noDMA+noBAR %7.1f | noDMA+noRD %7.1f | noDMA+noBAR+noRD %7.1f\n", M, N, K,
-               run<0, 0>(dA, dW, dC, M, N, K, it),
-               run<1, 0>(dA, dW, dC, M, N, K, it), run<1, 1>(dA, dW, dC, M, N, K, it), run<1, 16>(dA, dW, dC, M, N, K, it), run<1, 2>(dA, dW, dC, M, N, K, it),
-               run<1, 8>(dA, dW, dC, M, N, K, it), run<1, 3>(dA, dW, dC, M, N, K, it), run<1, 9>(dA, dW, dC, M, N, K, it), run<1, 11>(dA, dW, dC, M, N, K, it));
+        printf("M=%5d N=%5d K=%5d  v2 full %7.1f | DMA behind MFMA 3,7,.. %7.1f | reads in gaps 0-7 %7.1f | late barrier %7.1f | late barrier + reads 0-7.. n/a | DMA late + reads early %7.1f | full again %7.1f\n", M, N, K,
+               run<1, 0>(dA, dW, dC, M, N, K, it), run<1, 32>(dA, dW, dC, M, N, K, it), run<1, 64>(dA, dW, dC, M, N, K, it), run<1, 128>(dA, dW, dC, M, N, K, it),
+               run<1, 96>(dA, dW, dC, M, N, K, it), run<1, 0>(dA, dW, dC, M, N, K, it));
         if (rep == 1) {
-            cycles<0>(dA, dW, dC, M, N, K, "full"); cycles<1>(dA, dW, dC, M, N, K, "noDMA"); cycles<2>(dA, dW, dC, M, N, K, "noBAR"); cycles<8>(dA, dW, dC, M, N, K, "noRD");
-            cycles<9>(dA, dW, dC, M, N, K, "noDMA+noRD"); cycles<11>(dA, dW, dC, M, N, K, "noDMA+noBAR+noRD");
+            cycles<0>(dA, dW, dC, M, N, K, "full"); cycles<32>(dA, dW, dC, M, N, K, "DMA late"); cycles<64>(dA, dW, dC, M, N, K, "reads early"); cycles<128>(dA, dW, dC, M, N, K, "late barrier");
         }
         fflush(stdout);
     }
