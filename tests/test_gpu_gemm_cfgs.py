@@ -216,3 +216,39 @@ def test_four_wave_tile_slices_through_lds_equal_direct_slices_and_the_ping_pong
         L.emu_gemm_tune(0)
         L.emu_gemm_force_config(0)
         L.emu_set_splitk_scratch(0, 0)
+
+
+def test_four_wave_tile_equals_the_ping_pong_tile_on_random_shapes():
+    """48 seeded random problems through both 256 x 256 tiles (emu_gemm_tune bit 22 / bit 21 under config 'P'): ragged and remainder
+    rows (M mod 256 in 1 .. 16 and beyond), columns that end inside a tile, 1 .. 40 k tiles (fewer tiles than the ring has slots,
+    odd counts, counts that are not multiples of the five ring positions), every epilogue, with and without K-slices.  Equal bits."""
+    import random
+    from emu_amd import ops
+    from emu_amd._lib import lib
+    L = lib()
+    sk = torch.zeros(256 * 288 * 256, dtype=torch.float32, device="cuda")
+    L.emu_set_splitk_scratch(sk.data_ptr(), sk.numel() * 4)
+    rng = random.Random(20260930)
+    try:
+        L.emu_gemm_force_config(ord("P"))
+        for case in range(48):
+            M = rng.choice([256, 512, 768, 257, 258, 264, 272, 273, 300, 511, 770, 1025, 200, 1300])
+            N = rng.choice([256, 512, 768, 1024, 1280, 320, 384, 1000, 1288, 2048])
+            K = 64 * rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 16, 21, 32, 40, 64, 96])
+            epi = rng.choice([0, 0, 1, 1, 2, 3, 4, 5])
+            if epi in (2, 5) and N % 2:
+                N += 1
+            x, w = rnd(M, K, seed=100 + case), rnd(N, K, seed=200 + case, scale=K ** -0.5)
+            bias = rnd(N, seed=300 + case) if epi in (0, 1, 4) else None
+            res = rnd(M, N, seed=400 + case) if epi == 1 else None
+            outs = []
+            for tune in ((1 << 22), (1 << 21)):
+                L.emu_gemm_tune(tune)
+                outs.append(ops.linear(x, w, bias=bias, res=res, epi=epi).clone())
+            assert torch.equal(outs[0], outs[1]), (f"case {case} M{M} N{N} K{K} epi{epi}: four-wave != ping-pong, "
+                                                   f"{int((outs[0] != outs[1]).sum())} elements")
+            check(outs[0], ref_linear(x, w, bias, res, epi), f"random case {case} M{M} N{N} K{K} epi{epi}")
+    finally:
+        L.emu_gemm_tune(0)
+        L.emu_gemm_force_config(0)
+        L.emu_set_splitk_scratch(0, 0)
